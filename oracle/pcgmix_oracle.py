@@ -1,0 +1,296 @@
+"""CPU oracle for the PCGmix hot path — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A restatement, in this project's own words, of what the upstream reference computes
+on the per-batch augmentation path.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import this module; the product package never
+does (its kernels fail loudly when the HIP library is missing — there is no CPU
+fallback).
+
+Parity pinning: every function below is checked bit-for-bit against golden vectors
+that were produced by running the real reference in the build container
+(tests/golden/make_golden.py; tests/test_oracle_golden.py).  The log-mel restatement
+(``logmel``) is the exception — librosa 0.9.2 is not available offline, the reference
+holds no stored spectrogram, so that function is "parity unpinned" (SURVEY.md §8c).
+
+The structure deliberately follows the reference (per-sample Python loop for the
+splice, one scipy CubicSpline per (sample, channel) for the warp, one candidate loop per
+(sample, state) for the saliency displacement) because it doubles as the timed CPU
+baseline: its cost profile must be the reference's, not a vectorised
+rewrite's.
+
+Reference citations are ``file:line`` into the upstream repository.
+"""
+from __future__ import annotations
+
+import math
+import random
+
+import numpy as np
+import torch
+from scipy.interpolate import CubicSpline
+
+PCGMIX_METHODS = ("durmixmagwarp", "durratiomixup")
+
+
+# --------------------------------------------------------------------------- parsing
+def parse_probability(method: str) -> float:
+    """augmentations.py:865-868 / 932-935: text after the last '+' is the gate p."""
+    parts = method.split("+")
+    return float(parts[-1]) if len(parts) > 1 else 1.0
+
+
+def gate_fires(method: str, step: int) -> bool:
+    """augmentations.py:869-872 / 936-939: fresh Random(step); fire iff u < p."""
+    return random.Random(step).uniform(0, 1) < parse_probability(method)
+
+
+def parse_alpha(method: str, name: str) -> float:
+    """augmentations.py:897-899 / 958-960."""
+    parts = method.split("(alpha=")
+    return float(parts[1].split(")" + name)[0]) if len(parts) > 1 else 1.0
+
+
+def parse_magwarp(method: str):
+    """augmentations.py:919-923: defaults sigma 0.2, 4 knots."""
+    sigma, knot = 0.2, 4
+    if len(method.split("durmixmagwarp(")) > 1:
+        sigma = float(method.split("durmixmagwarp(")[1].split(",")[0])
+        knot = int(method.split(",")[1].split(")")[0])
+    return sigma, knot
+
+
+# --------------------------------------------------------------------------- partners
+def _shuffle_groups(keys, step: int) -> np.ndarray:
+    """Group indices by key in order of first appearance; permute each group with a
+    FRESH Random(step).sample (augmentations.py:500-514, 528-540, 542-556)."""
+    groups = {}
+    for i, k in enumerate(keys):
+        groups.setdefault(k, []).append(i)
+    mix = np.arange(len(keys))
+    for idx in groups.values():
+        mix[idx] = random.Random(step).sample(list(mix[idx]), len(idx))
+    return mix
+
+
+def mix_indices(method: str, labels: np.ndarray, wav, step: int) -> np.ndarray:
+    """Partner selection with the reference's override order
+    (augmentations.py:877-896 / 943-957); later substrings win."""
+    mix = _shuffle_groups([int(v) for v in labels], step)            # same label :500
+    if "(samePCG)" in method:
+        mix = _shuffle_groups(list(wav), step)                       # same recording :528
+    if "(sameDataset)" in method:
+        mix = _shuffle_groups([f"{w[0]}_{int(t)}" for w, t in zip(wav, labels)], step)  # :542
+    if "(mixAll)" in method:
+        mix = np.asarray(random.Random(step).sample(list(np.arange(len(labels))), len(labels)))
+    return mix
+
+
+def get_lambda(alpha: float, step: int) -> float:
+    """augmentations.py:659-666.  Reseeds the GLOBAL numpy stream (side effect kept:
+    magnitude_warp's normal draw continues from here)."""
+    if alpha > 0.0:
+        np.random.seed(step)
+        return np.random.beta(alpha, alpha)
+    return 1.0
+
+
+# --------------------------------------------------------------------------- splice
+def splice_plain(d1, d2, f1, f2, lam, method: str, step: int):
+    """augmentations.py:289-337 (1D) / augmentations2d.py:206-221 (2D, last axis).
+    d1/d2 are torch CPU tensors (..., T); lam is a float32 tensor of shape (1,1[,1])."""
+    out = d1.clone()
+    for k in range(4):
+        len1, len2 = int(f1[k + 1] - f1[k]), int(f2[k + 1] - f2[k])
+        n = min(len1, len2)
+        a, b = int(f1[k]), int(f2[k])
+        if "(rand)" in method:
+            gap = len2 - len1
+            off = random.Random(step).randint(0, abs(gap))
+            if gap >= 0:
+                b += off
+            else:
+                a += off
+        out[..., a:a + n] = out[..., a:a + n] * lam + d2[..., b:b + n] * (1 - lam)
+    return out
+
+
+def displacement_env(s1: np.ndarray, s2: np.ndarray, lam) -> int:
+    """augmentations.py:60-93: first strict maximum of the float32 envelope sum."""
+    n1, n2 = len(s1), len(s2)
+    best, arg = float("-inf"), 0
+    if n1 > n2:
+        pad = np.pad(s2, (0, n1 - n2), "constant")
+        for d in range(n1 - n2 + 1):
+            sh = np.roll(pad, d)[d:d + n2]          # == s2; kept for the reference's cost profile
+            cur = np.sum(s1[:d]) + np.sum(np.maximum(s1[d:d + n2], sh)) + np.sum(s1[d + n2:])
+            if cur > best:
+                best, arg = cur, d
+    else:
+        pad = np.pad(s1, (0, n2 - n1), "constant")
+        for d in range(n2 - n1 + 1):
+            sh = np.roll(pad, d)[d:d + n1]          # == s1
+            cur = np.sum(np.maximum(s2[d:d + n1], sh))
+            if cur > best:
+                best, arg = cur, d
+    return arg
+
+
+def displacement_sum(s1: np.ndarray, s2: np.ndarray, lam) -> int:
+    """augmentations.py:95-128.  ``lam`` is the (1,1) float32 array the reference passes
+    (lams_out[0].numpy()), so the products broadcast to shape (1, n) before np.sum."""
+    n1, n2 = len(s1), len(s2)
+    best, arg = float("-inf"), 0
+    if n1 > n2:
+        pad = np.pad(s2, (0, n1 - n2), "constant")
+        for d in range(n1 - n2 + 1):
+            sh = np.roll(pad, d)[d:d + n2]          # == s2
+            cur = np.sum(s1[:d]) + np.sum(s1[d:d + n2] * lam + sh * (1 - lam)) + np.sum(s1[d + n2:])
+            if cur > best:
+                best, arg = cur, d
+    else:
+        pad = np.pad(s1, (0, n2 - n1), "constant")
+        for d in range(n2 - n1 + 1):
+            sh = np.roll(pad, d)[d:d + n1]          # == s1
+            cur = np.sum(sh * lam + s2[d:d + n1] * (1 - lam))
+            if cur > best:
+                best, arg = cur, d
+    return arg
+
+
+def salopt_displacements(sal1, sal2, f1, f2, lam_np, method: str) -> np.ndarray:
+    """Displacement per heart state (0 where lengths agree); augmentations.py:210-287."""
+    fn = displacement_env if "(saloptenv" in method else displacement_sum
+    disp = np.zeros(4, dtype=np.int64)
+    for k in range(4):
+        len1, len2 = int(f1[k + 1] - f1[k]), int(f2[k + 1] - f2[k])
+        if len1 != len2:
+            disp[k] = fn(sal1[f1[k]:f1[k + 1]], sal2[f2[k]:f2[k + 1]], lam_np)
+    return disp
+
+
+def splice_salopt(d1, d2, f1, f2, sal1, sal2, lam, method: str):
+    """augmentations.py:210-287: place the shorter state inside the longer one at the
+    saliency-optimal displacement, then blend."""
+    out = d1.clone()
+    lam_np = lam.detach().cpu().numpy()
+    disp = salopt_displacements(sal1, sal2, f1, f2, lam_np, method)
+    for k in range(4):
+        len1, len2 = int(f1[k + 1] - f1[k]), int(f2[k + 1] - f2[k])
+        a, b, n = int(f1[k]), int(f2[k]), min(len1, len2)
+        if len1 > len2:
+            a += int(disp[k])
+        elif len1 < len2:
+            b += int(disp[k])
+        out[..., a:a + n] = out[..., a:a + n] * lam + d2[..., b:b + n] * (1 - lam)
+    return out, disp
+
+
+# --------------------------------------------------------------------------- warp
+def magnitude_warp(x: np.ndarray, sigma: float, knot: int, return_knots: bool = False):
+    """augmentations.py:674-683.  x is (B, T, C) float32; draws from the GLOBAL numpy
+    stream; float64 spline * float32 sample, rounded once into a float32 array."""
+    B, T, C = x.shape
+    steps = np.arange(T)
+    knots = np.random.normal(loc=1.0, scale=sigma, size=(B, knot + 2, C))
+    brk = np.linspace(0, T - 1.0, num=knot + 2)
+    ret = np.zeros_like(x)
+    for i in range(B):
+        w = np.array([CubicSpline(brk, knots[i, :, c])(steps) for c in range(C)]).T
+        ret[i] = x[i] * w
+    return (ret, knots) if return_knots else ret
+
+
+# --------------------------------------------------------------------------- saliency
+def gaussian_taps(n: int, sigma: float):
+    """saliency.py:15-18 (not renormalised)."""
+    return [1 / (sigma * math.sqrt(2 * math.pi)) * math.exp(-float(r) ** 2 / (2 * sigma ** 2))
+            for r in range(-int(n / 2), int(n / 2) + 1)]
+
+
+def saliency_post(grad: np.ndarray, frames: np.ndarray, gauss_k_n: int = 101) -> np.ndarray:
+    """saliency.py:63-91 (dim=1): |grad| -> zero tail -> sum channels -> Gaussian
+    smoothing ('same', zero padded) -> zero tail -> per-row (s-min)/max -> NaN->0.
+    Uses torch CPU ops, as the reference does, so the float32 results are its results."""
+    sal = torch.from_numpy(np.abs(grad))
+    for s, f in zip(sal, frames):
+        s[:, int(f[-1]):] = 0
+    sal = torch.sum(sal, dim=1)[:, None, :]
+    sigma = (12 / 101) * gauss_k_n
+    kern = torch.FloatTensor([[gaussian_taps(gauss_k_n, sigma)]])
+    sal = torch.nn.functional.conv1d(sal, kern, padding="same")
+    for s, f in zip(sal, frames):
+        s[:, int(f[-1]):] = 0
+    shape = sal.size()
+    sal = sal.view(sal.size(0), -1)
+    sal -= sal.min(1, keepdim=True)[0]
+    sal /= sal.max(1, keepdim=True)[0]
+    sal = torch.nan_to_num(sal.view(shape), nan=0.0)
+    return np.squeeze(sal.numpy())
+
+
+def input_gradient(model: torch.nn.Module, x: np.ndarray, labels: np.ndarray) -> np.ndarray:
+    """saliency.py:52-61: d(score of the true class)/d(input), model in eval mode."""
+    model.eval()
+    data = torch.from_numpy(x.copy()).requires_grad_()
+    out = model(data)
+    scores = out.gather(1, torch.from_numpy(labels).view(-1, 1)).squeeze()
+    scores.backward(torch.ones_like(scores))
+    return data.grad.detach().numpy()
+
+
+# --------------------------------------------------------------------------- augment
+def augment(method: str, x: np.ndarray, labels: np.ndarray, frames: np.ndarray, wav,
+            step: int, saliency_maps: np.ndarray | None = None, num_classes: int = 2):
+    """The durmixmagwarp / durratiomixup branches of augmentations.py:864-981 (1D, x is
+    (B,C,T)) and the durratiomixup branch of augmentations2d.py:397-427 (x is (B,1,F,W)).
+
+    Returns dict(y, target, mix, fired, lam, knots, disp).  ``y is x`` when the method
+    does not apply or the gate rejects (the reference returns the input object).
+    """
+    target = np.eye(num_classes, dtype=np.int64)[labels]
+    res = dict(y=x, target=target, mix=np.zeros(0, np.int64), fired=False, lam=float("nan"),
+               knots=np.zeros(0), disp=None)
+    is2d = x.ndim == 4
+    names = ("durratiomixup",) if is2d else PCGMIX_METHODS        # no magwarp in 2D (:269-281)
+    name = next((m for m in names if m in method), None)           # dispatch order :864,:931
+    if name is None or not gate_fires(method, step):
+        return res
+    B = x.shape[0]
+    mix = mix_indices(method, labels, wav, step) if not is2d else \
+        _shuffle_groups([int(v) for v in labels], step)              # augmentations2d.py:410
+    alpha = parse_alpha(method, name) if not is2d else 1.0            # augmentations2d.py:411
+    lam64 = get_lambda(alpha, step)
+    lams = torch.from_numpy((np.ones(B) * lam64).astype("float32"))
+    lam = lams[:, None, None, None][0] if is2d else lams[:, None, None][0]
+    data = torch.from_numpy(x)
+    y = torch.zeros(x.shape)
+    disp = np.zeros((B, 4), dtype=np.int64)
+    for i in range(B):
+        m = int(mix[i])
+        if "(salopt" in method:
+            y[i], disp[i] = splice_salopt(data[i], data[m], frames[i], frames[m],
+                                          saliency_maps[i], saliency_maps[m], lam, method)
+        else:
+            y[i] = splice_plain(data[i], data[m], frames[i], frames[m], lam,
+                                "" if is2d else method, step)    # 2D has no (rand) variant
+    if "(mixAll)" in method and not is2d:                             # :915-917 / :978-980
+        lt = lams[:, None]
+        t = torch.from_numpy(target)
+        target = (t * lt + t[mix] * (1 - lt)).numpy()
+    knots = np.zeros(0)
+    y = y.numpy()
+    if name == "durmixmagwarp":                                       # :919-928
+        sigma, knot = parse_magwarp(method)
+        y, knots = magnitude_warp(np.transpose(y, (0, 2, 1)), sigma, knot, return_knots=True)
+        y = np.ascontiguousarray(np.transpose(y, (0, 2, 1)))
+    res.update(y=y, target=target, mix=mix, fired=True, lam=lam64, knots=knots,
+               disp=disp if "(salopt" in method else None)
+    return res
+
+
+# --------------------------------------------------------------------------- loss
+def ce_soft(logits: np.ndarray, target_ohe: np.ndarray) -> float:
+    """train_model.py:45-54: mean over the batch of -sum(log_softmax * target)."""
+    z = logits - logits.max(1, keepdims=True)
+    logp = z - np.log(np.exp(z).sum(1, keepdims=True))
+    return float((-(logp * target_ohe).sum(1)).mean())

@@ -1,0 +1,9 @@
+"""MI355X-native PCGmix hot path (augmentation -> log-mel -> train step).
+
+Drop-in for the reference's per-batch augmentation call
+``augmentations.augment(args, data, target_ohe, frames, wav, step_counter, model,
+device, RESULTS_ARGS)`` (reference augmentations.py:698, called at
+train_model.py:504-507).  The O(B*C*T) work runs in hand-written HIP kernels for
+gfx950 behind the C ABI declared in ``include/pcgmix_hip.h``.
+"""
+from . import synthetic  # noqa: F401
