@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Headline benchmark: augmented PCG samples/s of the drop-in ``augment()`` on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic 2.5 s @ 2 kHz heart cycles, batch 256 per GPU,
+``durratiomixup`` feeding the 1D-CNN, i.e. (256, 4, 5000) float32 — the Potes 1D-CNN needs its
+four band-pass channels.  One step = one ``augment()`` call through the
+reference's own call signature (device-resident input -> device-resident output, labels read
+back, partner permutation drawn, indices uploaded, one fused HIP launch).  Every rank augments
+its own batch (no collective on the data path: weak scaling).
+
+One JSON line is printed by rank 0.  Besides the contract keys it carries
+  roofline      the splice kernel against the HBM roofline (12*C*T algorithmic bytes/sample),
+                kernel time measured with HIP events on the launch stream inside the timed steps
+  cpu_baseline  the CPU oracle (reference structure: per-sample Python loop) timed on this
+                host on a bounded number of batches of the same workload
+  extra         secondary measurements (other shapes/methods, saturating batch, train step/s)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import pcgmix_amd  # noqa: E402,F401
+from pcgmix_amd import augmentations, hostprep, synthetic  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+class Args:
+    def __init__(self, method):
+        self.method = method
+        self.num_classes = 2
+        self.batch_size = 256
+        self.sample_rate = 2000
+        self.model = "Potes"
+        self.dataset = "PhysioNet"
+        self.num_channels = 4
+
+
+class StepCounter:
+    def __init__(self):
+        self.count = 0
+
+    def add(self):
+        self.count += 1
+
+
+class KernelTimer:
+    """HIP-event pairs around the fused kernel launch, on the stream it is launched on (torch's
+    current stream).  Events are only read after the timed region has been synchronised."""
+
+    def __init__(self):
+        self.pairs = []
+        self._orig = augmentations.launch_mix
+
+    def __enter__(self):
+        def timed(*a, **k):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._orig(*a, **k)
+            e1.record()
+            self.pairs.append((e0, e1))
+        augmentations.launch_mix = timed
+        return self
+
+    def __exit__(self, *exc):
+        augmentations.launch_mix = self._orig
+
+    def mean_ms(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
+
+
+def make_device_batch(B, C, T, rate, seed, device):
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=rate, seed=seed)
+    data = torch.from_numpy(x).to(device)
+    tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)
+    return x, data, tgt, torch.from_numpy(frames), labels, wav
+
+
+def run_augment_steps(method, data, tgt, frames, wav, device, steps, warmup, barrier, timer=None):
+    args, sc = Args(method), StepCounter()
+    for _ in range(warmup):
+        augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "")
+        sc.add()
+    barrier()
+    torch.cuda.synchronize()
+    ctx = timer if timer is not None else _Null()
+    t0 = time.perf_counter()
+    with ctx:
+        for _ in range(steps):
+            out = augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "")
+            sc.add()
+    torch.cuda.synchronize()
+    barrier()
+    return time.perf_counter() - t0, out
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200):
+    """The fused kernel alone, launched back to back from one prepared plan (no host prologue
+    between launches): the figure to compare with rocprofv3's per-kernel average."""
+    if B * C * T > 64_000_000:          # saturating batches: random payload made on device
+        frames, labels, wav = synthetic.make_index_data(B, T, sample_rate=rate, seed=0)
+        data = torch.randn(B, C, T, device=device)
+    else:
+        x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=rate, seed=0)
+        data = torch.from_numpy(x).to(device)
+    plan = hostprep.make_plan(method, labels, frames, wav, 1, B, C)
+    dev, offs = augmentations.upload_plan(plan, frames, device)
+    base = dev.data_ptr()
+    out = torch.empty_like(data)
+    knots_ptr = op_ptr = None
+    if plan.knots is not None:
+        op = augmentations.spline_operator(device, T, plan.n_knots)
+        knots_ptr, op_ptr = base + offs["knots"], op.data_ptr()
+
+    def launch():
+        augmentations.launch_mix(data, out, base + offs["frames"], base + offs["mix"], None,
+                                 float(plan.lam32), knots_ptr, op_ptr, plan.n_knots, B, C, T)
+    for _ in range(10):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def cpu_baseline(method, B, C, T, rate, budget_s=12.0):
+    """CPU oracle on the host cores of this box: whole batches of the benchmark workload until
+    about ``budget_s`` seconds of CPU work have been timed."""
+    from oracle import pcgmix_oracle as O
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=rate, seed=0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    O.augment(method, x, labels, frames, wav, 0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.augment(method, x, labels, frames, wav, n + 1)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 2000:
+            break
+    return {"value": B * n / dt, "unit": "samples/s", "cores": torch.get_num_threads(),
+            "kind": "port", "ms_per_batch": 1e3 * dt / n,
+            "sample": f"{n} batches of {method} ({B},{C},{T}) through oracle/pcgmix_oracle.py "
+                      f"(reference structure: per-sample loop of torch CPU slice ops) in {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--channels", type=int, default=4)
+    ap.add_argument("--sig-len", type=int, default=5000)
+    ap.add_argument("--method", default="durratiomixup")
+    ap.add_argument("--no-extra", action="store_true", help="skip secondary measurements")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    B, C, T, rate = a.batch, a.channels, a.sig_len, 2000
+    _, data, tgt, frames, labels, wav = make_device_batch(B, C, T, rate, seed=rank, device=device)
+
+    kt = KernelTimer()
+    dt, _ = run_augment_steps(a.method, data, tgt, frames, wav, device, a.steps, a.warmup,
+                              barrier, timer=kt)
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * B * a.steps / dt
+
+    kern_ms = kt.mean_ms()
+    alg_bytes = 12.0 * C * T * B                     # read own + read partner + write, fp32
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    result = {
+        "metric": "augmented PCG samples/s", "value": value, "unit": "samples/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{a.method} augment() on synthetic 2.5 s @ 2 kHz PCG cycles, "
+                               f"({B},{C},{T}) float32 per GPU (BASELINE.json configs[1])",
+                   "batch_per_gpu": B, "channels": C, "sig_len": T, "method": a.method,
+                   "parallelism": f"dp{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "pcgmix::mix_warp_kernel<4,false>", "kernel_ms": kern_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "timing": "HIP events around each launch inside the timed steps"},
+    }
+
+    if rank == 0 and world == 1:
+        extra = {}
+        if not a.no_extra:
+            b2b = kernel_back_to_back_ms(a.method, B, C, T, rate, device)
+            extra["kernel_back_to_back_ms"] = b2b
+            extra["kernel_back_to_back_GBs"] = alg_bytes / (b2b * 1e-3) / 1e9
+            for tag, (m, b, c, t) in {
+                "mix_256x1x5000": ("durratiomixup", 256, 1, 5000),
+                "magwarp_256x1x5000": ("durmixmagwarp(0.2,4)", 256, 1, 5000),
+                "magwarp_256x4x5000": ("durmixmagwarp(0.2,4)", 256, 4, 5000),
+                "mix_sat_16384x4x5000": ("durratiomixup", 16384, 4, 5000),
+                "magwarp_sat_16384x4x5000": ("durmixmagwarp(0.2,4)", 16384, 4, 5000),
+            }.items():
+                ms = kernel_back_to_back_ms(m, b, c, t, rate, device, iters=50 if b > 1000 else 200)
+                gbs = 12.0 * b * c * t / (ms * 1e-3) / 1e9
+                extra[tag] = {"kernel_ms": ms, "GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS}
+            _, d1, t1, f1, _, w1 = make_device_batch(256, 1, 5000, rate, 0, device)
+            for tag, m, (dd, tt, ff, ww) in (
+                ("augment_mix_256x1x5000", "durratiomixup", (d1, t1, f1, w1)),
+                ("augment_magwarp_256x1x5000", "durmixmagwarp(0.2,4)", (d1, t1, f1, w1)),
+                ("augment_magwarp_256x4x5000", "durmixmagwarp(0.2,4)", (data, tgt, frames, wav)),
+            ):
+                dte, _ = run_augment_steps(m, dd, tt, ff, ww, device, a.steps, a.warmup, barrier)
+                extra[tag] = {"samples_per_s": 256 * a.steps / dte, "ms_per_step": 1e3 * dte / a.steps}
+        result["extra"] = extra
+        if not a.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(a.method, B, C, T, rate)
+            result["extra"]["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

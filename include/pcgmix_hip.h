@@ -1,0 +1,155 @@
+/*
+ * pcgmix_hip.h — C ABI of libpcgmix_hip.so, the MI355X (gfx950) implementation of the
+ * PCGmix per-batch hot path.
+ *
+ * This is the drop-in boundary.  The upstream reference is pure Python and
+ * has no FFI of its own; each entry point below replaces the O(B*C*T) part of one reference
+ * function and is what a ctypes binding inside the reference's augmentations.py would call
+ * (INTEGRATION.md shows that binding).  Conventions:
+ *
+ *   - every pointer documented "device" is a device pointer owned by the caller;
+ *   - no entry point allocates device memory, synchronises, or touches the default stream:
+ *     kernels are enqueued on `stream` and the call returns;
+ *   - return value: 0 (hipSuccess) or a hipError_t; pcgmix_error_string() names it;
+ *   - tensors are dense row-major ("contiguous" in torch terms), float32 unless noted;
+ *   - `frames` holds cumulative heart-state boundaries per sample,
+ *     [0, S1end, sysEnd, S2end, cycleEnd] (dataloader_physionet.py:151-172), as int32.
+ *
+ * File:line citations are into the upstream repository
+ * (Liisjak/PCGmix-A-Data-Augmentation-Method-for-Heart-Sound-Classification-EXTENDED).
+ */
+#ifndef PCGMIX_HIP_H
+#define PCGMIX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Opaque HIP stream handle (same type as hipStream_t; declared here so that a host
+ * language binding does not need the HIP headers). */
+typedef struct ihipStream_t* pcgmix_stream_t;
+
+#define PCGMIX_ABI_VERSION 1
+
+/* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
+int pcgmix_abi_version(void);
+
+/* Human-readable name of an error code returned by any entry point. */
+const char* pcgmix_error_string(int err);
+
+/* ------------------------------------------------------------------------------------------
+ * Constant operator of the magnitude-warp spline.                                  [host]
+ *
+ * Replaces the per-(sample, channel) construction
+ *     CubicSpline(linspace(0, T-1, n_knots), random_warps[b, :, c])
+ * in magnitude_warp(), augmentations.py:674-683 (scipy default bc_type 'not-a-knot').  The
+ * break points are the same for every (b, c), so knots -> piecewise-cubic coefficients is
+ * one constant linear map; this fills
+ *     op[0 .. n_knots-1]                              break points, float64, as numpy's
+ *                                                     linspace(0, T-1, n_knots) rounds them
+ *     op[n_knots + (p*4 + j)*n_knots + i]             d coef[p][j] / d knot[i],
+ *                                                     p = piece 0..n_knots-2,
+ *                                                     j = 0..3 multiplies (t - brk[p])^(3-j)
+ * Pure host arithmetic; no device is touched.  n_knots >= 2, T >= 2.
+ * Size of `op` in doubles: pcgmix_spline_operator_size(n_knots).
+ */
+int pcgmix_spline_operator_size(int n_knots);
+int pcgmix_spline_operator_f64(int T, int n_knots, double* op /* host */);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused segment-aware splice (+ optional magnitude warp).                        [device]
+ *
+ * Replaces, for a whole batch in one launch:
+ *   mixup_keepdur_multidim_tensors            augmentations.py:289-337   (plain and '(rand)')
+ *   mixup_keepdur_multidim_tensors_salopt     augmentations.py:210-287   (blend part; the
+ *                                             displacement comes from pcgmix_salopt_disp_f32)
+ *   the per-sample loop around them           augmentations.py:909-917 / 969-977
+ *   magnitude_warp + its D2H/H2D round trip   augmentations.py:674-683, 924-928
+ *   augmentations2d.mixup_keepdur_multidim_tensors  augmentations2d.py:206-221 (call with
+ *                                             C = F rows, T = W columns of the spectrogram)
+ *
+ * For sample b with partner m = mix_idx[b], heart state k = 0..3:
+ *     len1 = frames[b][k+1]-frames[b][k],  len2 = frames[m][k+1]-frames[m][k],  n = min(len1,len2)
+ *     o    = off ? min(off[b][k], |len1-len2|) : 0
+ *     a    = frames[b][k] + (len1 > len2 ? o : 0)        own-side start
+ *     s    = frames[m][k] + (len2 > len1 ? o : 0)        partner-side start
+ *     y[b,c,a+i] = x[b,c,a+i]*lam + x[m,c,s+i]*(1-lam)   i = 0..n-1   (fp32 mul, mul, add —
+ *                                                        never contracted to an FMA)
+ *   everywhere else y = x.  (1-lam) is formed in float32.  Elements whose source index would
+ *   fall outside [0,T) are left unblended (the reference would raise on such frames).
+ * If `knots` is non-NULL each output is then multiplied by the not-a-knot cubic spline through
+ * knots[b,:,c] evaluated at t in float64 (scipy's term order c3 + c2*s + c1*s^2 + c0*s^3 with a
+ * running power) and rounded once to float32, as `ret[i] = pat * warper` does.
+ *
+ *   x, y        device, (B, C, T); y must not alias x
+ *   frames      device, int32 (B, 5)
+ *   mix_idx     device, int32 (B), values in [0, B)
+ *   off         device, int32 (B, 4) >= 0, or NULL
+ *   knots       device, float64 (B, n_knots, C) exactly as numpy.random.normal fills it, or NULL
+ *   spline_op   device, float64 (pcgmix_spline_operator_size(n_knots)); required iff knots
+ */
+int pcgmix_mix_warp_f32(const float* x, float* y,
+                        const int32_t* frames, const int32_t* mix_idx, const int32_t* off,
+                        float lam,
+                        const double* knots, const double* spline_op, int n_knots,
+                        int B, int C, int T, pcgmix_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Saliency post-processing.                                                       [device]
+ *
+ * Replaces saliency.get_saliency_maps(), saliency.py:63-91 (dim == 1), after the model's
+ * backward pass: |grad| -> zero t >= frames[b][4] -> sum over channels -> `ksize`-tap Gaussian
+ * (weights 1/(sigma*sqrt(2*pi)) * exp(-r^2 / (2 sigma^2)), not renormalised, zero 'same'
+ * padding, saliency.py:15-18) -> zero the tail again -> per row (s - min) / max(s - min),
+ * NaN -> 0.
+ *
+ *   grad        device, (B, C, T)
+ *   sal         device, (B, T) out
+ *   ksize       odd, <= 1023
+ */
+int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames, float* sal,
+                             int ksize, float sigma, int B, int C, int T,
+                             pcgmix_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Saliency-optimal displacement search.                                           [device]
+ *
+ * Replaces optimal_displacement_max_envelope (mode 0, augmentations.py:60-93) and
+ * optimal_displacement_max_sum (mode 1, augmentations.py:95-128) for every (sample, state):
+ * disp[b][k] = first strict argmax over d in [0, |len1-len2|] of the float32 objective,
+ * evaluated in numpy's pairwise-summation order so that the integer result is the
+ * reference's; 0 where the two lengths agree.
+ *
+ *   sal         device, (B, T) saliency maps
+ *   disp        device, int32 (B, 4) out — feeds pcgmix_mix_warp_f32's `off`
+ */
+int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames, const int32_t* mix_idx,
+                           float lam, int mode, int32_t* disp, int B, int T,
+                           pcgmix_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Log-mel front end.                                                              [device]
+ *
+ * Replaces the offline librosa pipeline of databuilder.ipynb cell 6:19-23, 81-101, 127-142
+ * (melspectrogram -> power_to_db(ref=max) -> (x-mean)/std -> crop to the cycle -> zero-pad
+ * to W columns) per heart cycle, on device.  librosa 0.9.2 semantics restated (centered
+ * frames with reflect padding, periodic Hann of n_fft, power 2, Slaney mel scale and
+ * normalisation, amin 1e-10, top_db 80); parity with librosa itself is unpinned.
+ *
+ *   x           device, (B, T) one channel per row
+ *   frames      device, int32 (B, 5) waveform boundaries; columns >= round(f4 * n_frames / T)
+ *               are zero-filled after normalisation
+ *   spec        device, (B, n_mels, W) out
+ *   frames_out  device, int32 (B, 5) out or NULL: boundaries in spectrogram columns
+ */
+int pcgmix_logmel_f32(const float* x, const int32_t* frames, float* spec, int32_t* frames_out,
+                      int B, int T, int n_fft, int hop, int n_mels,
+                      float fmin, float fmax, float sr, float mean, float std, int W,
+                      pcgmix_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCGMIX_HIP_H */

@@ -1,0 +1,81 @@
+"""ctypes binding of libpcgmix_hip.so (the C ABI declared in include/pcgmix_hip.h).
+
+There is no fallback: if the library is missing or an entry point fails, the caller gets
+an exception.  The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C <package>/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
+ABI_VERSION = 1
+
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_ptr = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/pcgmix_hip.h one to one
+SIGNATURES = {
+    "pcgmix_abi_version": (_c_int, []),
+    "pcgmix_error_string": (ctypes.c_char_p, [_c_int]),
+    "pcgmix_spline_operator_size": (_c_int, [_c_int]),
+    "pcgmix_spline_operator_f64": (_c_int, [_c_int, _c_int, _ptr]),
+    "pcgmix_mix_warp_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _ptr, _ptr, _c_int,
+                                     _c_int, _c_int, _c_int, _ptr]),
+    "pcgmix_saliency_post_f32": (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_float, _c_int, _c_int,
+                                          _c_int, _ptr]),
+    "pcgmix_salopt_disp_f32": (_c_int, [_ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _c_int, _c_int,
+                                        _ptr]),
+    "pcgmix_logmel_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                   _c_float, _c_float, _c_float, _c_float, _c_float, _c_int, _ptr]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class PcgmixLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the library.  Raises PcgmixLibraryError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise PcgmixLibraryError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` or `make -C {os.path.join(_HERE, 'csrc')}`. "
+                "There is no CPU fallback for the PCGmix kernels.")
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # missing ROCm runtime, wrong arch, ...
+            raise PcgmixLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (restype, argtypes) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise PcgmixLibraryError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = restype
+            fn.argtypes = argtypes
+        got = lib.pcgmix_abi_version()
+        if got != ABI_VERSION:
+            raise PcgmixLibraryError(f"ABI version mismatch: library {got}, binding {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def check(err: int, what: str) -> None:
+    """Raise RuntimeError carrying the hipError_t name when an entry point failed."""
+    if err != 0:
+        msg = load().pcgmix_error_string(err)
+        raise RuntimeError(f"{what} failed: hipError_t {err} "
+                           f"({msg.decode() if msg else 'unknown'})")

@@ -1,0 +1,172 @@
+"""Drop-in replacement for the PCGmix branches of the reference's ``augmentations.augment``.
+
+Same name, same positional signature, same return tuple as augmentations.py:698 (called once
+per batch from train_model.py:507):
+
+    data, target_ohe, mix_indices, cut = augment(args, data, target_ohe, frames, wav,
+                                                 step_counter, model, device, RESULTS_ARGS)
+
+Implemented methods (the PCGmix hot path): ``durratiomixup`` (augmentations.py:931-981) and
+``durmixmagwarp(sigma,knot)`` (augmentations.py:864-929) with the selectors ``(rand)``,
+``(alpha=a)``, ``(samePCG)``, ``(sameDataset)``, ``(mixAll)``, ``(saloptenv…)``,
+``(saloptsum…)`` and the ``+p`` probability gate.  The host part (RNG, partner indices) is in
+``hostprep``; the O(B*C*T) part is ONE launch of ``pcgmix_mix_warp_f32`` (HIP, gfx950) on the
+current torch stream, with no host synchronisation after the labels have been read.
+
+The split form ``make_plan`` / ``apply_plan`` lets a training loop that already holds the
+labels on the host prepare step n+1 while the GPU still runs step n.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib, hostprep
+from .hostprep import MixPlan
+
+_OP_CACHE: dict = {}      # (device index, T, n_knots) -> device tensor with the spline operator
+
+
+def _as_numpy_frames(frames) -> np.ndarray:
+    if isinstance(frames, torch.Tensor):
+        frames = frames.detach().cpu().numpy()
+    return np.ascontiguousarray(frames, dtype=np.int64)
+
+
+def _check_data(data: torch.Tensor, ndim: int) -> None:
+    if not isinstance(data, torch.Tensor) or data.dim() != ndim:
+        raise ValueError(f"data must be a {ndim}-D tensor")
+    if data.dtype != torch.float32:
+        raise ValueError(f"data must be float32, got {data.dtype}")
+    if not data.is_contiguous():
+        raise ValueError("data must be contiguous")
+    if not data.is_cuda:
+        raise ValueError("data must live on a HIP device: the PCGmix kernels have no CPU path")
+
+
+def spline_operator(device: torch.device, sig_len: int, n_knots: int) -> torch.Tensor:
+    """Constant knots->coefficients operator of the warp spline, resident on ``device``."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           sig_len, n_knots)
+    op = _OP_CACHE.get(key)
+    if op is None:
+        lib = _lib.load()
+        host = np.empty(lib.pcgmix_spline_operator_size(n_knots), dtype=np.float64)
+        _lib.check(lib.pcgmix_spline_operator_f64(sig_len, n_knots, host.ctypes.data),
+                   "pcgmix_spline_operator_f64")
+        op = torch.from_numpy(host).to(device)
+        _OP_CACHE[key] = op
+    return op
+
+
+def upload_plan(plan: MixPlan, frames: np.ndarray, device: torch.device):
+    """One H2D copy with every small per-step array: int32 frames (B,5) | mix (B) | offsets
+    (B,4, optional) | float64 knots (optional).  Returns (buffer, byte offsets)."""
+    B = frames.shape[0]
+    n_off = B * 4 if plan.rand_off is not None else 0
+    n_int = B * 5 + B + n_off
+    n_int_pad = (n_int + 1) & ~1                      # keep the float64 block 8-byte aligned
+    n_kn = plan.knots.size if plan.knots is not None else 0
+    buf = np.empty(n_int_pad * 4 + n_kn * 8, dtype=np.uint8)
+    ints = buf[:n_int_pad * 4].view(np.int32)
+    ints[:B * 5] = frames.reshape(-1)
+    ints[B * 5:B * 6] = plan.mix
+    if n_off:
+        ints[B * 6:B * 6 + n_off] = plan.rand_off.reshape(-1)
+    if n_kn:
+        buf[n_int_pad * 4:].view(np.float64)[:] = plan.knots.reshape(-1)
+    # pinned staging + async copy: the call never waits for earlier GPU work (a pageable
+    # copy would synchronise the stream); the host allocator keeps the pinned block alive
+    # until the copy has run
+    dev = torch.from_numpy(buf).pin_memory().to(device, non_blocking=True)
+    offs = {"frames": 0, "mix": B * 5 * 4, "off": B * 6 * 4 if n_off else None,
+            "knots": n_int_pad * 4 if n_kn else None}
+    return dev, offs
+
+
+def launch_mix(data: torch.Tensor, out: torch.Tensor, frames_ptr: int, mix_ptr: int,
+               off_ptr: Optional[int], lam: float, knots_ptr: Optional[int],
+               op_ptr: Optional[int], n_knots: int, B: int, C: int, T: int) -> None:
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(data.device).cuda_stream
+    err = lib.pcgmix_mix_warp_f32(data.data_ptr(), out.data_ptr(), frames_ptr, mix_ptr, off_ptr,
+                                  ctypes.c_float(lam), knots_ptr, op_ptr, n_knots, B, C, T,
+                                  ctypes.c_void_p(stream))
+    _lib.check(err, "pcgmix_mix_warp_f32")
+
+
+def apply_plan(plan: MixPlan, data: torch.Tensor, frames: np.ndarray,
+               saliency_maps: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Run the device part of a fired plan; returns the new (B,C,T) tensor."""
+    B, C, T = data.shape
+    device = data.device
+    with torch.cuda.device(device):
+        dev, offs = upload_plan(plan, frames, device)
+        base = dev.data_ptr()
+        frames_ptr, mix_ptr = base + offs["frames"], base + offs["mix"]
+        off_ptr = base + offs["off"] if offs["off"] is not None else None
+        keep = [dev]
+        if plan.salopt_mode is not None:
+            if saliency_maps is None:
+                raise ValueError("saliency-guided mixing needs saliency maps")
+            from . import saliency as _sal
+            disp = _sal.optimal_displacements(saliency_maps, frames_ptr, mix_ptr,
+                                              float(plan.lam32), plan.salopt_mode, B, T)
+            keep.append(disp)
+            off_ptr = disp.data_ptr()
+        knots_ptr = op_ptr = None
+        if plan.knots is not None:
+            op = spline_operator(device, T, plan.n_knots)
+            keep.append(op)
+            knots_ptr, op_ptr = base + offs["knots"], op.data_ptr()
+        out = torch.empty_like(data)
+        launch_mix(data, out, frames_ptr, mix_ptr, off_ptr, float(plan.lam32), knots_ptr, op_ptr,
+                   plan.n_knots, B, C, T)
+        # the small buffers are only read by work already enqueued on this stream; torch's
+        # caching allocator reuses them in stream order, so dropping the references is safe
+        del keep
+    return out
+
+
+def blend_targets(target_ohe: torch.Tensor, plan: MixPlan) -> torch.Tensor:
+    """'(mixAll)': float blend of the one-hot targets (augmentations.py:915-917, 978-980)."""
+    B = target_ohe.shape[0]
+    lams = torch.from_numpy((np.ones(B) * plan.lam64).astype("float32")).to(target_ohe.device)
+    lt = lams[:, None]
+    mix = torch.from_numpy(plan.mix).to(target_ohe.device)
+    return target_ohe * lt + target_ohe[mix] * (1 - lt)
+
+
+def labels_from_ohe(target_ohe: torch.Tensor) -> np.ndarray:
+    """Reverse the one-hot encoding on the host (augmentations.py:501): one D2H sync."""
+    return target_ohe.max(1, keepdim=True)[1].detach().cpu().numpy().reshape(-1)
+
+
+def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RESULTS_ARGS):
+    """See module docstring.  Returns ``(data, target_ohe, mix_indices, cut)``; when the method
+    does not apply or the gate rejects the step, ``data`` is the very object passed in and
+    ``mix_indices`` is ``[]`` (augmentations.py:731-732, 871-872, 938-939)."""
+    method = args.method
+    step = int(step_counter.count)
+    if hostprep.select_method(method, is2d=False) is None:
+        return data, target_ohe, [], None
+    _check_data(data, 3)
+    B, C, T = data.shape
+    frames_np = _as_numpy_frames(frames)
+    plan = hostprep.make_plan(method, lambda: labels_from_ohe(target_ohe), frames_np, wav, step,
+                              B, C, is2d=False)
+    if not plan.fired:
+        return data, target_ohe, [], None
+    hostprep.validate_frames(frames_np, T)
+    sal = None
+    if plan.salopt_mode is not None:
+        from . import saliency as _sal
+        sal = _sal.get_saliency_maps(args, data.device, data, target_ohe, frames_np, dim=1,
+                                     gauss_k_n=101)
+    out = apply_plan(plan, data, frames_np, sal)
+    if plan.mix_all:
+        target_ohe = blend_targets(target_ohe, plan)
+    return out, target_ohe, plan.mix, None

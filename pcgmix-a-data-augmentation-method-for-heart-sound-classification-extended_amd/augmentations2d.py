@@ -1,0 +1,32 @@
+"""Drop-in replacement for the PCGmix branch of the reference's ``augmentations2d.augment``
+(augmentations2d.py:267, ``durratiomixup`` branch :397-427; called from train_model.py:505).
+
+Spectrogram batches are (B, 1, F, W); the four heart states are ranges of the last (time)
+axis and ``frames`` holds their boundaries in spectrogram columns.  The splice is the 1D one
+applied to every frequency row, so the same kernel runs with C = F rows and T = W columns
+(augmentations2d.py:206-221).  alpha is fixed to 1 and only same-label partners exist in 2D
+(augmentations2d.py:410-411).
+"""
+from __future__ import annotations
+
+from . import hostprep
+from .augmentations import (_as_numpy_frames, _check_data, apply_plan, labels_from_ohe)
+
+
+def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RESULTS_ARGS):
+    method = args.method
+    step = int(step_counter.count)
+    if hostprep.select_method(method, is2d=True) is None:
+        return data, target_ohe, [], None
+    if "(salopt" in method:
+        raise NotImplementedError("saliency-guided mixing of spectrograms is out of scope")
+    _check_data(data, 4)
+    B, Cc, F, W = data.shape
+    frames_np = _as_numpy_frames(frames)
+    plan = hostprep.make_plan(method, lambda: labels_from_ohe(target_ohe), frames_np, wav, step,
+                              B, Cc * F, is2d=True)
+    if not plan.fired:
+        return data, target_ohe, [], None
+    hostprep.validate_frames(frames_np, W)
+    out = apply_plan(plan, data.view(B, Cc * F, W), frames_np).view(B, Cc, F, W)
+    return out, target_ohe, plan.mix, None

@@ -1,0 +1,120 @@
+// pcgmix_host.hip — host-only entry points of libpcgmix_hip.so (no device code).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
+
+#include "pcgmix_kernels.h"
+
+extern "C" int pcgmix_abi_version(void) { return PCGMIX_ABI_VERSION; }
+
+extern "C" const char* pcgmix_error_string(int err) {
+  return hipGetErrorString(static_cast<hipError_t>(err));
+}
+
+extern "C" int pcgmix_spline_operator_size(int n_knots) {
+  return n_knots < 2 ? 0 : n_knots + 4 * (n_knots - 1) * n_knots;
+}
+
+namespace {
+
+// Solve A s = rhs (n x n dense, partial pivoting).  n <= 64.
+bool solve_dense(std::vector<double>& A, std::vector<double>& rhs, int n) {
+  for (int col = 0; col < n; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < n; ++r)
+      if (std::fabs(A[r * n + col]) > std::fabs(A[piv * n + col])) piv = r;
+    if (A[piv * n + col] == 0.0) return false;
+    if (piv != col) {
+      for (int c = 0; c < n; ++c) std::swap(A[piv * n + c], A[col * n + c]);
+      std::swap(rhs[piv], rhs[col]);
+    }
+    for (int r = col + 1; r < n; ++r) {
+      const double f = A[r * n + col] / A[col * n + col];
+      if (f == 0.0) continue;
+      for (int c = col; c < n; ++c) A[r * n + c] -= f * A[col * n + c];
+      rhs[r] -= f * rhs[col];
+    }
+  }
+  for (int r = n - 1; r >= 0; --r) {
+    double acc = rhs[r];
+    for (int c = r + 1; c < n; ++c) acc -= A[r * n + c] * rhs[c];
+    rhs[r] = acc / A[r * n + r];
+  }
+  return true;
+}
+
+// Piecewise-cubic coefficients (scipy PPoly layout, c[j][p] multiplies (t-x[p])^(3-j)) of the
+// not-a-knot spline through (x[i], yv[i]).  Same equations as scipy's CubicSpline: unknowns
+// are the first derivatives at the knots; interior rows are the C2 conditions, the two end
+// rows the not-a-knot conditions; n == 3 is the single parabola, n == 2 the straight line.
+bool notaknot_coeffs(const std::vector<double>& x, const std::vector<double>& yv,
+                     std::vector<double>& coef /* (n-1)*4 */) {
+  const int n = (int)x.size();
+  std::vector<double> dx(n - 1), slope(n - 1), s(n);
+  for (int i = 0; i < n - 1; ++i) {
+    dx[i] = x[i + 1] - x[i];
+    slope[i] = (yv[i + 1] - yv[i]) / dx[i];
+  }
+  if (n == 2) {
+    s[0] = s[1] = slope[0];
+  } else {
+    std::vector<double> A((size_t)n * n, 0.0), rhs(n, 0.0);
+    if (n == 3) {
+      A[0] = 1.0; A[1] = 1.0;
+      A[3] = dx[1]; A[4] = 2.0 * (dx[0] + dx[1]); A[5] = dx[0];
+      A[7] = 1.0; A[8] = 1.0;
+      rhs[0] = 2.0 * slope[0];
+      rhs[1] = 3.0 * (dx[0] * slope[1] + dx[1] * slope[0]);
+      rhs[2] = 2.0 * slope[1];
+    } else {
+      for (int i = 1; i < n - 1; ++i) {
+        A[i * n + i - 1] = dx[i];
+        A[i * n + i] = 2.0 * (dx[i - 1] + dx[i]);
+        A[i * n + i + 1] = dx[i - 1];
+        rhs[i] = 3.0 * (dx[i] * slope[i - 1] + dx[i - 1] * slope[i]);
+      }
+      double d = x[2] - x[0];
+      A[0] = dx[1];
+      A[1] = d;
+      rhs[0] = ((dx[0] + 2.0 * d) * dx[1] * slope[0] + dx[0] * dx[0] * slope[1]) / d;
+      d = x[n - 1] - x[n - 3];
+      A[(n - 1) * n + n - 1] = dx[n - 3];
+      A[(n - 1) * n + n - 2] = d;
+      rhs[n - 1] = (dx[n - 2] * dx[n - 2] * slope[n - 3] +
+                    (2.0 * d + dx[n - 2]) * dx[n - 3] * slope[n - 2]) / d;
+    }
+    if (!solve_dense(A, rhs, n)) return false;
+    s = rhs;
+  }
+  for (int p = 0; p < n - 1; ++p) {
+    const double t = (s[p] + s[p + 1] - 2.0 * slope[p]) / dx[p];
+    coef[p * 4 + 0] = t / dx[p];
+    coef[p * 4 + 1] = (slope[p] - s[p]) / dx[p] - t;
+    coef[p * 4 + 2] = s[p];
+    coef[p * 4 + 3] = yv[p];
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int pcgmix_spline_operator_f64(int T, int n_knots, double* op) {
+  if (!op || n_knots < 2 || n_knots > 64 || T < 2) return hipErrorInvalidValue;
+  const int n = n_knots;
+  // numpy.linspace(0, T-1, n): step = (T-1)/(n-1); y[i] = i*step; last point forced to T-1.
+  std::vector<double> x(n);
+  const double step = (double)(T - 1) / (double)(n - 1);
+  for (int i = 0; i < n; ++i) x[i] = (double)i * step;
+  x[n - 1] = (double)(T - 1);
+  for (int i = 0; i < n; ++i) op[i] = x[i];
+  double* M = op + n;
+  std::vector<double> e(n), coef((size_t)(n - 1) * 4);
+  for (int i = 0; i < n; ++i) {
+    std::fill(e.begin(), e.end(), 0.0);
+    e[i] = 1.0;
+    if (!notaknot_coeffs(x, e, coef)) return hipErrorInvalidValue;
+    for (int r = 0; r < (n - 1) * 4; ++r) M[(size_t)r * n + i] = coef[r];
+  }
+  return hipSuccess;
+}

@@ -1,0 +1,206 @@
+"""Host prologue of one PCGmix augmentation call: everything that is integer or random.
+
+The reference derives all randomness of a step from ``step_counter.count`` through CPython's
+``random.Random`` and numpy's legacy global ``RandomState`` (augmentations.py:869, 936, 500-514,
+659-666, 677).  Those streams *define* parity, are O(B) work, and are therefore kept on the
+host and called in the reference's order:
+
+    Random(step).uniform          probability gate                 augmentations.py:869-872
+    Random(step).sample per group partner permutation              augmentations.py:500-514
+    np.random.seed(step); beta    lambda (global numpy stream!)    augmentations.py:659-666
+    Random(step).randint          '(rand)' placement offsets       augmentations.py:305-337
+    np.random.normal              magnitude-warp knots             augmentations.py:677
+
+The result is a small ``MixPlan`` of index/scalar data that the device kernels consume; no
+waveform data is touched here.
+"""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+# Methods this package implements, in the reference's dispatch order (augmentations.py:864, 931).
+PCGMIX_METHODS_1D = ("durmixmagwarp", "durratiomixup")
+PCGMIX_METHODS_2D = ("durratiomixup",)            # augmentations2d.py:397 (no magwarp in 2D)
+
+# Every name the reference dispatcher knows (augmentations.py:700-729, augmentations2d.py:269-281).
+# A method string that names one of these but none of ours is refused loudly instead of being
+# passed through un-augmented.
+_REFERENCE_METHODS_1D = (
+    "durratiocutmix", "lengthcutmix", "datasetcutmix", "wav-durratiocutmix", "wavcutmix",
+    "lc-nointrusion", "labelcutmix", "swapsysdia", "s1s2mask", "cont-cutmix", "saliency-cutmix",
+    "latentmixup", "manifold-cutmix(ch)", "manifold-cutmix", "manifold-cutout(ch)",
+    "manifold-cutout", "cutmix(ch)", "cutmix", "cutout(ch)", "cutout", "gaussiannoise",
+    "magnitudewarp", "timewarp", "mixup", "timemask", "durratiomixup", "durmixmagwarp",
+    "respiratoryscale", "durmixrespscale")
+_REFERENCE_METHODS_2D = (
+    "durratiocutmix", "cutmix", "mixup", "latentmixup", "freqmask", "timemask", "cutout",
+    "durratiomixup", "durmixfreqmask", "durmixtimemask", "durmixcutout")
+# Branches the reference tests BEFORE ours (augmentations.py:731-862; augmentations2d.py:286-395)
+_EARLIER_1D = ("durmixrespscale", "respiratoryscale", "timemask")
+_EARLIER_2D = ("durmixcutout", "durmixfreqmask", "durmixtimemask")
+_UNSUPPORTED_SELECTORS = ("(sameCVD)", "(closestbins=", "(closestknn=")
+
+
+@dataclass
+class MixPlan:
+    """Index/scalar description of one augmentation step (host memory only)."""
+    fired: bool
+    name: str = ""
+    step: int = 0
+    mix: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int64))   # (B,) partner of b
+    lam64: float = float("nan")                # np.random.beta result
+    lam32: np.float32 = np.float32("nan")      # what multiplies the waveforms
+    rand_off: Optional[np.ndarray] = None      # int32 (B,4) for '(rand)'
+    salopt_mode: Optional[int] = None          # 0 = '(saloptenv', 1 = '(saloptsum'
+    knots: Optional[np.ndarray] = None         # float64 (B, n_knots, C) as numpy drew them
+    n_knots: int = 0
+    mix_all: bool = False                      # '(mixAll)': targets are blended too
+
+
+def select_method(method: str, is2d: bool) -> Optional[str]:
+    """Which of our branches the reference's if-chain would reach, or None for passthrough.
+
+    Raises NotImplementedError for reference augmentations outside this package's scope."""
+    ours = PCGMIX_METHODS_2D if is2d else PCGMIX_METHODS_1D
+    known = _REFERENCE_METHODS_2D if is2d else _REFERENCE_METHODS_1D
+    if not any(m in method for m in known):
+        return None                                            # augmentations.py:731-732
+    earlier = _EARLIER_2D if is2d else _EARLIER_1D
+    hit = next((m for m in ours if m in method), None)
+    if hit is None or any(e in method for e in earlier):
+        raise NotImplementedError(
+            f"method {method!r} selects a reference augmentation outside the PCGmix hot path; "
+            f"this package implements {ours} only")
+    for sel in _UNSUPPORTED_SELECTORS:
+        if sel in method and not is2d:
+            raise NotImplementedError(f"partner selector {sel!r} is out of scope (SURVEY.md §2)")
+    return hit
+
+
+def parse_probability(method: str) -> float:
+    """Text after the last '+' (augmentations.py:865-868)."""
+    parts = method.split("+")
+    return float(parts[-1]) if len(parts) > 1 else 1.0
+
+
+def parse_alpha(method: str, name: str) -> float:
+    """'(alpha=a)' immediately in front of the method name (augmentations.py:897-899)."""
+    parts = method.split("(alpha=")
+    return float(parts[1].split(")" + name)[0]) if len(parts) > 1 else 1.0
+
+
+def parse_magwarp(method: str):
+    """'durmixmagwarp(sigma,knot)' (augmentations.py:919-923); defaults 0.2, 4."""
+    sigma, knot = 0.2, 4
+    parts = method.split("durmixmagwarp(")
+    if len(parts) > 1:
+        sigma = float(parts[1].split(",")[0])
+        knot = int(method.split(",")[1].split(")")[0])
+    return sigma, knot
+
+
+def gate_fires(method: str, step: int) -> bool:
+    """Fresh ``Random(step)``; the method runs iff u < p (augmentations.py:869-872)."""
+    return random.Random(step).uniform(0, 1) < parse_probability(method)
+
+
+def shuffle_within_groups(keys: Sequence, step: int) -> np.ndarray:
+    """Partner permutation: group positions by key (order of first appearance) and permute
+    every group with a fresh ``Random(step).sample`` (augmentations.py:500-514)."""
+    groups: dict = {}
+    for i, k in enumerate(keys):
+        groups.setdefault(k, []).append(i)
+    mix = np.arange(len(keys), dtype=np.int64)
+    for idx in groups.values():
+        # the reference samples from the list of numpy ints; only the positions matter
+        mix[idx] = random.Random(step).sample(idx, len(idx))
+    return mix
+
+
+def partner_indices(method: str, labels: np.ndarray, wav: Sequence[str], step: int,
+                    is2d: bool = False) -> np.ndarray:
+    """Partner selection with the reference's override order (augmentations.py:877-896)."""
+    labels = np.asarray(labels).reshape(-1)
+    mix = shuffle_within_groups(labels.tolist(), step)                      # same label
+    if is2d:
+        return mix                                                          # augmentations2d.py:410
+    if "(samePCG)" in method:                                               # augmentations.py:528
+        mix = shuffle_within_groups(list(wav), step)
+    if "(sameDataset)" in method:                                           # augmentations.py:542
+        mix = shuffle_within_groups([f"{w[0]}_{int(t)}" for w, t in zip(wav, labels)], step)
+    if "(mixAll)" in method:                                                # augmentations.py:883
+        mix = np.asarray(random.Random(step).sample(list(range(len(labels))), len(labels)),
+                         dtype=np.int64)
+    return mix
+
+
+def rand_offsets(frames: np.ndarray, mix: np.ndarray, step: int) -> np.ndarray:
+    """'(rand)': offset of the shorter state inside the longer one,
+    ``Random(step).randint(0, |gap|)`` with a fresh generator per (sample, state), so the value
+    depends on (step, |gap|) only (augmentations.py:305-337)."""
+    lens = np.diff(frames, axis=1)
+    gap = np.abs(lens[mix] - lens)
+    cache: dict = {}
+    off = np.zeros(gap.shape, dtype=np.int32)
+    for g in np.unique(gap):
+        cache[int(g)] = random.Random(step).randint(0, int(g))
+    for g, v in cache.items():
+        off[gap == g] = v
+    return off
+
+
+def validate_frames(frames: np.ndarray, sig_len: int) -> None:
+    """The reference silently mis-slices (and usually raises a shape error) when a cycle runs
+    past the padded length; refuse such input up front."""
+    if frames.ndim != 2 or frames.shape[1] != 5:
+        raise ValueError(f"frames must be (B, 5), got {frames.shape}")
+    if (np.diff(frames, axis=1) < 0).any() or (frames[:, 0] < 0).any():
+        raise ValueError("frames must be non-decreasing and non-negative")
+    if int(frames[:, 4].max(initial=0)) > sig_len:
+        raise ValueError(f"heart cycle ends at {int(frames[:, 4].max())} > signal length {sig_len}")
+
+
+def make_plan(method: str, labels, frames: np.ndarray, wav: Sequence[str], step: int,
+              batch: int, channels: int, is2d: bool = False) -> MixPlan:
+    """Everything random/integer for one step, in the reference's RNG order.
+
+    ``labels`` may be an array or a zero-argument callable returning one: they are needed only
+    when the gate fires (on a GPU they cost a device->host sync, augmentations.py:501), so a
+    callable lets rejected steps skip the sync."""
+    name = select_method(method, is2d)
+    if name is None or not gate_fires(method, step):
+        return MixPlan(fired=False, step=step)
+    if callable(labels):
+        labels = labels()
+    labels = np.asarray(labels).reshape(-1)
+    if labels.shape[0] != batch or frames.shape[0] != batch:
+        raise ValueError("labels/frames do not match the batch size")
+    plan = MixPlan(fired=True, name=name, step=step)
+    plan.mix = partner_indices(method, labels, wav, step, is2d)
+    alpha = 1.0 if is2d else parse_alpha(method, name)                      # augmentations2d.py:411
+    if alpha > 0.0:                                                         # augmentations.py:661-663
+        np.random.seed(step)            # global stream, as the reference (side effect kept)
+        plan.lam64 = float(np.random.beta(alpha, alpha))
+    else:
+        plan.lam64 = 1.0
+    plan.lam32 = np.float32(plan.lam64)                                     # augmentations.py:903
+    if not is2d:
+        if "(rand)" in method and "(salopt" not in method:
+            plan.rand_off = rand_offsets(frames, plan.mix, step)
+        if "(saloptenv" in method:
+            plan.salopt_mode = 0
+        elif "(saloptsum" in method:
+            plan.salopt_mode = 1
+        elif "(salopt" in method:
+            raise NotImplementedError("only (saloptenv…) and (saloptsum…) exist in the reference")
+        plan.mix_all = "(mixAll)" in method
+        if name == "durmixmagwarp":
+            sigma, knot = parse_magwarp(method)
+            plan.n_knots = knot + 2
+            # continues the global stream right after the beta draw (augmentations.py:677)
+            plan.knots = np.random.normal(loc=1.0, scale=sigma, size=(batch, knot + 2, channels))
+    return plan

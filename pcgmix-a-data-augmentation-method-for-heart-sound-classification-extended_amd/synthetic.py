@@ -49,6 +49,18 @@ def make_batch(batch: int, channels: int, sig_len: int, sample_rate: int = 1000,
     return x, frames, labels, wav
 
 
+def make_index_data(batch: int, sig_len: int, sample_rate: int = 1000, seed: int = 0):
+    """Boundaries, labels and recording ids only (for batches whose waveforms are generated
+    directly on the device).  NOT the same label stream as ``make_batch`` (no waveform draw)."""
+    rs = np.random.RandomState(seed)
+    frames = make_frames(batch, sample_rate / 1000.0, rs)
+    if int(frames[:, 4].max()) > sig_len:
+        raise ValueError("cycle does not fit")
+    labels = rs.randint(0, 2, size=batch).astype(np.int64)
+    wav = tuple(f"{'abcdef'[i % 6]}{(i // 4):04d}" for i in range(batch))
+    return frames, labels, wav
+
+
 def spec_frames(frames: np.ndarray, n_cols: int, sig_len: int) -> np.ndarray:
     """Waveform boundaries -> spectrogram-column boundaries, Python banker's
     ``round`` as databuilder.ipynb cell 6:101 does."""

@@ -1,0 +1,125 @@
+"""Host prologue (method DSL, gate, partner permutation, RNG order) against the goldens that
+the running reference produced, plus the C-ABI surface — no GPU needed."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pcgmix_amd  # noqa: F401
+from pcgmix_amd import _lib, hostprep
+from conftest import ROOT, golden_files, load_golden
+
+CASES = golden_files("mix1d_") + golden_files("salopt_")
+
+
+@pytest.mark.parametrize("path", CASES + golden_files("mix2d_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_plan_matches_reference(path):
+    g = load_golden(path)
+    is2d = g["x"].ndim == 4
+    B = g["x"].shape[0]
+    C = 1 if is2d else g["x"].shape[1]
+    plan = hostprep.make_plan(g["method"], g["labels"], g["frames"], g["wav"], g["step"], B, C,
+                              is2d=is2d)
+    assert plan.fired == bool(g["fired"])
+    if not plan.fired:
+        return
+    assert np.array_equal(plan.mix, g["mix"])                 # segment/partner indices bit-exact
+    assert plan.lam64 == float(g["lam"])
+    if g["knots"].size:
+        assert np.array_equal(plan.knots, g["knots"].reshape(plan.knots.shape))
+    else:
+        assert plan.knots is None
+
+
+def test_gate_statistics_and_labels_not_needed_when_rejected():
+    fired = 0
+    for step in range(200):
+        called = []
+        plan = hostprep.make_plan("durratiomixup+0.2", lambda: called.append(1) or np.zeros(4, int),
+                                  np.zeros((4, 5), np.int64), ("a",) * 4, step, 4, 1)
+        fired += plan.fired
+        assert bool(called) == plan.fired        # rejected steps never touch the labels
+    assert fired == 43
+
+
+def test_rand_offsets_depend_on_gap_only():
+    import random
+    frames = np.array([[0, 10, 30, 40, 90], [0, 14, 30, 45, 80]], dtype=np.int64)
+    off = hostprep.rand_offsets(frames, np.array([1, 0]), step=9)
+    lens = np.diff(frames, axis=1)
+    for b, m in ((0, 1), (1, 0)):
+        for k in range(4):
+            assert off[b, k] == random.Random(9).randint(0, abs(int(lens[m, k] - lens[b, k])))
+
+
+def test_unknown_method_is_passthrough_and_foreign_method_is_refused():
+    assert hostprep.select_method("base", False) is None
+    assert hostprep.select_method("durmixmagwarp(0.2,4)+0.4", False) == "durmixmagwarp"
+    assert hostprep.select_method("(saloptenv)durratiomixup", False) == "durratiomixup"
+    with pytest.raises(NotImplementedError):
+        hostprep.select_method("cutmix", False)
+    with pytest.raises(NotImplementedError):
+        hostprep.select_method("(sameCVD)durratiomixup", False)
+    assert hostprep.select_method("durmixmagwarp(0.2,4)", True) is None   # unknown to the 2D dispatcher
+    with pytest.raises(NotImplementedError):
+        hostprep.select_method("durmixcutout", True)
+
+
+def test_validate_frames():
+    ok = np.array([[0, 5, 9, 12, 20]])
+    hostprep.validate_frames(ok, 20)
+    with pytest.raises(ValueError):
+        hostprep.validate_frames(ok, 19)
+    with pytest.raises(ValueError):
+        hostprep.validate_frames(np.array([[0, 5, 4, 12, 20]]), 30)
+
+
+# ------------------------------------------------------------------ C ABI surface
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pcgmix_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pcgmix_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_symbols()
+    assert len(names) >= 8
+    lib = ctypes.CDLL(_lib.LIB_PATH)          # loads without a GPU (no device call is made)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/pcgmix_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
+    assert _lib.load().pcgmix_abi_version() == _lib.ABI_VERSION
+
+
+@pytest.mark.parametrize("T,n", [(2500, 6), (5000, 6), (640, 8), (640, 4), (128, 3), (64, 2), (5000, 12)])
+def test_spline_operator_matches_scipy(T, n):
+    """knots -> PPoly coefficients is linear; the library's operator must reproduce scipy's
+    not-a-knot CubicSpline (magnitude_warp, augmentations.py:674-683)."""
+    from scipy.interpolate import CubicSpline
+    lib = _lib.load()
+    op = np.empty(lib.pcgmix_spline_operator_size(n))
+    assert lib.pcgmix_spline_operator_f64(T, n, op.ctypes.data) == 0
+    brk = np.linspace(0, T - 1.0, num=n)
+    assert np.array_equal(op[:n], brk)                       # numpy's linspace rounding
+    M = op[n:].reshape(n - 1, 4, n)
+    rs = np.random.RandomState(T + n)
+    t = np.arange(T)
+    for _ in range(5):
+        k = rs.normal(1.0, 0.2, n)
+        cs = CubicSpline(brk, k)
+        coef = M @ k                                         # (pieces, 4)
+        assert np.allclose(coef.T, cs.c, rtol=1e-11, atol=1e-13 * np.abs(cs.c).max())
+        p = np.clip(np.searchsorted(brk, t, "right") - 1, 0, n - 2)
+        s = t - brk[p]
+        w = coef[p, 3] + coef[p, 2] * s + coef[p, 1] * (s * s) + coef[p, 0] * (s * s * s)
+        assert np.abs(w - cs(t)).max() < 5e-13
+
+
+def test_spline_operator_rejects_bad_arguments():
+    lib = _lib.load()
+    assert lib.pcgmix_spline_operator_size(1) == 0
+    buf = np.empty(64)
+    assert lib.pcgmix_spline_operator_f64(100, 1, buf.ctypes.data) != 0
+    assert lib.pcgmix_spline_operator_f64(1, 4, buf.ctypes.data) != 0

@@ -1,0 +1,127 @@
+"""Parity of the HIP splice/warp kernel (through the drop-in augment() and the C ABI) with the
+golden vectors produced by the reference and with the CPU oracle.
+
+Bars (BASELINE.json north_star): partner/segment indices bit-exact; mixed waveforms within
+1e-4.  The splice alone is in fact bit-exact (same three fp32 roundings); the fp64 spline is
+evaluated from a precomputed linear operator, so warped outputs may differ from scipy's by
+one float32 ulp in rare elements — the tolerance below states that."""
+import numpy as np
+import pytest
+import torch
+
+import pcgmix_amd  # noqa: F401
+from pcgmix_amd import augmentations, augmentations2d, synthetic
+from conftest import Args, StepCounter, golden_files, load_golden
+from oracle import pcgmix_oracle as O
+
+pytestmark = pytest.mark.gpu
+WAVE_TOL = 1e-4          # north_star tolerance on mixed waveforms / spectrograms
+
+
+def run(mod, g, device, method=None, x=None):
+    x = g["x"] if x is None else x
+    data = torch.from_numpy(x).to(device)
+    tgt = torch.nn.functional.one_hot(torch.from_numpy(g["labels"]), 2).to(device)
+    out = mod.augment(Args(method or g["method"]), data, tgt, torch.from_numpy(g["frames"]),
+                      g["wav"], StepCounter(g["step"]), None, device, "")
+    return data, tgt, out
+
+
+@pytest.mark.parametrize("path", golden_files("mix1d_") + golden_files("mix2d_"),
+                         ids=lambda p: p.split("/")[-1][:-4])
+def test_augment_matches_reference_goldens(path, device):
+    g = load_golden(path)
+    mod = augmentations2d if g["x"].ndim == 4 else augmentations
+    data, tgt, (y, t_out, mix, cut) = run(mod, g, device)
+    assert cut is None
+    if not g["fired"]:
+        assert y is data and t_out is tgt and mix == []          # same objects, as the reference
+        return
+    assert y is not data and y.data_ptr() != data.data_ptr()
+    assert torch.equal(data.cpu(), torch.from_numpy(g["x"]))     # input untouched
+    assert np.array_equal(mix, g["mix"])                         # indices: bit-exact
+    got = y.cpu().numpy()
+    if "magwarp" in g["method"]:
+        assert np.abs(got - g["y"]).max() <= WAVE_TOL
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - g["y"].view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1 and (ulp > 0).mean() < 1e-3
+    else:
+        assert np.array_equal(got, g["y"])                       # splice: bit-exact
+    assert np.array_equal(t_out.cpu().numpy().astype(np.float64), g["target_out"].astype(np.float64))
+
+
+@pytest.mark.parametrize("method", ["durratiomixup", "durmixmagwarp(0.2,4)", "(rand)durmixmagwarp(0.1,3)"])
+@pytest.mark.parametrize("shape", [(6, 3, 637), (5, 1, 1001), (4, 2, 130)])
+def test_odd_lengths_scalar_path(method, shape, device):
+    """T % 4 != 0 takes the one-element-per-lane kernel."""
+    B, C, T = shape
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, seed=3, rate_scale=T / 1400.0)
+    ref = O.augment(method, x, labels, frames, wav, 17)
+    g = dict(x=x, labels=labels, frames=frames, wav=wav, step=17, method=method)
+    _, _, (y, _, mix, _) = run(augmentations, g, device)
+    assert np.array_equal(mix, ref["mix"])
+    assert np.abs(y.cpu().numpy() - ref["y"]).max() <= (WAVE_TOL if "magwarp" in method else 0.0)
+
+
+@pytest.mark.parametrize("method,shape", [("durratiomixup", (256, 4, 5000)),
+                                          ("durmixmagwarp(0.2,4)", (256, 1, 5000)),
+                                          ("durratiomixup", (32, 4, 2500))])
+def test_full_size_against_oracle(method, shape, device):
+    """BASELINE.json configs at full size; the oracle finishes these in well under a second."""
+    B, C, T = shape
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=2000 if T == 5000 else 1000, seed=0)
+    ref = O.augment(method, x, labels, frames, wav, 5)
+    g = dict(x=x, labels=labels, frames=frames, wav=wav, step=5, method=method)
+    _, _, (y, _, mix, _) = run(augmentations, g, device)
+    assert np.array_equal(mix, ref["mix"])
+    got = y.cpu().numpy()
+    if "magwarp" in method:
+        assert np.abs(got - ref["y"]).max() <= WAVE_TOL
+    else:
+        assert np.array_equal(got, ref["y"])
+
+
+def test_properties_large_batch(device):
+    """Size-independent properties at a batch the oracle is not run on (B=4096):
+    (1) partners are a same-label permutation; (2) outside every blended range y == x bit for
+    bit; (3) a sample whose partner is itself is x*lam + x*(1-lam) inside its cycle; (4) the
+    zero padding stays zero; (5) a second call with the same step is bit-identical."""
+    B, C, T = 4096, 1, 5000
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=2000, seed=1)
+    labels[:] = 0
+    labels[7] = 1                                   # singleton class -> partner is itself
+    g = dict(x=x, labels=labels, frames=frames, wav=wav, step=3, method="durratiomixup")
+    _, _, (y, _, mix, _) = run(augmentations, g, device)
+    _, _, (y2, _, _, _) = run(augmentations, g, device)
+    assert torch.equal(y, y2)
+    y = y.cpu().numpy()
+    assert sorted(mix.tolist()) == list(range(B)) and (labels[mix] == labels).all() and mix[7] == 7
+    lens = np.diff(frames, axis=1)
+    n = np.minimum(lens, lens[mix])
+    t = np.arange(T)[None, :]
+    blended = np.zeros((B, T), bool)
+    for k in range(4):
+        blended |= (t >= frames[:, k:k + 1]) & (t < frames[:, k:k + 1] + n[:, k:k + 1])
+    assert np.array_equal(y[:, 0][~blended], x[:, 0][~blended])
+    assert (y[:, 0][t >= frames[:, 4:5]] == 0).all()
+    lam = np.float32(O.get_lambda(1.0, 3))
+    own = x[7, 0, :frames[7, 4]]
+    assert np.array_equal(y[7, 0, :frames[7, 4]], own * lam + own * (np.float32(1) - lam))
+
+
+def test_rejects_bad_inputs(device):
+    x, frames, labels, wav = synthetic.make_batch(4, 1, 2500, seed=2)
+    tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)
+    a = Args("durratiomixup")
+    with pytest.raises(ValueError):
+        augmentations.augment(a, torch.from_numpy(x), tgt, frames, wav, StepCounter(0), None, device, "")
+    with pytest.raises(ValueError):
+        augmentations.augment(a, torch.from_numpy(x).to(device).double(), tgt, frames, wav,
+                              StepCounter(0), None, device, "")
+    with pytest.raises(ValueError):
+        augmentations.augment(a, torch.from_numpy(x).to(device).transpose(0, 1), tgt, frames, wav,
+                              StepCounter(0), None, device, "")
+    bad = frames.copy(); bad[0, 4] = 2501
+    with pytest.raises(ValueError):
+        augmentations.augment(a, torch.from_numpy(x).to(device), tgt, bad, wav, StepCounter(0),
+                              None, device, "")

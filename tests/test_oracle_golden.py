@@ -1,0 +1,48 @@
+"""The CPU oracle must reproduce, bit for bit, what the real reference produced
+(tests/golden/*.npz were written by tests/golden/make_golden.py running the reference)."""
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden
+from oracle import pcgmix_oracle as O
+
+CASES = golden_files("mix1d_") + golden_files("mix2d_") + golden_files("salopt_")
+
+
+def test_golden_inventory():
+    assert len(golden_files("mix1d_")) >= 25
+    assert len(golden_files("mix2d_")) == 3
+    assert len(golden_files("salopt_")) == 3
+
+
+@pytest.mark.parametrize("path", CASES, ids=lambda p: p.split("/")[-1][:-4])
+def test_oracle_matches_reference(path):
+    g = load_golden(path)
+    r = O.augment(g["method"], g["x"], g["labels"], g["frames"], g["wav"], g["step"],
+                  saliency_maps=g.get("sal"))
+    assert r["fired"] == bool(g["fired"])
+    if not r["fired"]:
+        assert r["y"] is g["x"] and int(g["same_object"]) == 1 and g["mix"].size == 0
+        return
+    assert np.array_equal(r["mix"], g["mix"])                      # partner indices: bit-exact
+    assert r["lam"] == float(g["lam"])
+    assert np.array_equal(r["knots"].ravel(), g["knots"].ravel())
+    assert np.array_equal(r["y"], g["y"])                          # waveforms: bit-exact
+    assert np.array_equal(np.asarray(r["target"], np.float64), np.asarray(g["target_out"], np.float64))
+    if "disp" in g:
+        assert np.array_equal(r["disp"], g["disp"])                # displacements: bit-exact
+
+
+@pytest.mark.parametrize("path", golden_files("salopt_")[:1], ids=lambda p: p.split("/")[-1][:-4])
+def test_oracle_saliency_post(path):
+    g = load_golden(path)
+    assert np.array_equal(O.saliency_post(g["grad"], g["frames"]), g["sal"])
+
+
+def test_oracle_ce_soft():
+    import torch
+    rs = np.random.RandomState(0)
+    logits = rs.randn(16, 2).astype(np.float32)
+    t = np.eye(2)[rs.randint(0, 2, 16)] * 0.7 + 0.15
+    ref = -(torch.log_softmax(torch.from_numpy(logits), 1) * torch.from_numpy(t)).sum(1).mean()
+    assert abs(O.ce_soft(logits, t) - float(ref)) < 1e-6
