@@ -126,7 +126,8 @@ def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200):
         x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=rate, seed=0)
         data = torch.from_numpy(x).to(device)
     plan = hostprep.make_plan(method, labels, frames, wav, 1, B, C)
-    dev, offs = augmentations.upload_plan(plan, frames, device)
+    with torch.cuda.device(device):
+        dev, offs = augmentations.upload_plan(plan, frames, device)
     base = dev.data_ptr()
     out = torch.empty_like(data)
     knots_ptr = op_ptr = None
@@ -180,6 +181,10 @@ def main():
     ap.add_argument("--method", default="durratiomixup")
     ap.add_argument("--no-extra", action="store_true", help="skip secondary measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--kernels-only", action="store_true",
+                    help="only the back-to-back kernel table (diagnostic)")
+    ap.add_argument("--profile-host", action="store_true",
+                    help="cProfile the host side of the timed steps to stderr (diagnostic)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,8 +204,26 @@ def main():
             dist.barrier()
 
     B, C, T, rate = a.batch, a.channels, a.sig_len, 2000
+    if a.kernels_only:
+        for m, b, c, t in (("durratiomixup", 256, 1, 5000), ("durratiomixup", 256, 4, 5000),
+                           ("durmixmagwarp(0.2,4)", 256, 1, 5000), ("durmixmagwarp(0.2,4)", 256, 4, 5000),
+                           ("durratiomixup", 4096, 4, 5000), ("durmixmagwarp(0.2,4)", 4096, 4, 5000),
+                           ("durratiomixup", 16384, 4, 5000), ("durmixmagwarp(0.2,4)", 16384, 4, 5000)):
+            ms = kernel_back_to_back_ms(m, b, c, t, rate, device, iters=50 if b > 1000 else 200)
+            print(f"{m:24s} ({b},{c},{t})  {ms * 1e3:9.2f} us  {12.0 * b * c * t / ms / 1e6:8.1f} GB/s",
+                  flush=True)
+        return
     _, data, tgt, frames, labels, wav = make_device_batch(B, C, T, rate, seed=rank, device=device)
 
+    if a.profile_host:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        run_augment_steps(a.method, data, tgt, frames, wav, device, 5, 5, barrier)
+        pr.enable()
+        run_augment_steps(a.method, data, tgt, frames, wav, device, a.steps, 0, barrier)
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumtime").print_stats(25)
     kt = KernelTimer()
     dt, _ = run_augment_steps(a.method, data, tgt, frames, wav, device, a.steps, a.warmup,
                               barrier, timer=kt)

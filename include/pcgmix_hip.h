@@ -59,6 +59,30 @@ int pcgmix_spline_operator_size(int n_knots);
 int pcgmix_spline_operator_f64(int T, int n_knots, double* op /* host */);
 
 /* ------------------------------------------------------------------------------------------
+ * Partner permutation.                                                              [host]
+ *
+ * Replaces the per-group shuffle of get_same_label_mix_indices / get_same_wav_mix_indices /
+ * get_same_dataset_mix_indices (augmentations.py:500-514, 528-540, 542-556) and the '(mixAll)'
+ * draw (augmentations.py:883-884):
+ *     mix[group] = random.Random(seed).sample(list(group), len(group))
+ * with a FRESH generator per group.  CPython's algorithm is restated exactly: MT19937 seeded by
+ * init_by_array over the 32-bit words of |seed|, sample()'s pool branch (always taken when
+ * k == n), _randbelow by rejection on getrandbits(n.bit_length()).  Integer results are
+ * bit-identical to CPython 3.8-3.12 (checked against `random` in tests/test_host_logic.py).
+ *
+ *   group_id    host, int32 (B): any labelling of the groups, values in [0, n_groups)
+ *   mix         host, int64 (B) out: mix[b] = partner of sample b
+ */
+int pcgmix_partner_permutation_i64(const int32_t* group_id, int B, int n_groups, uint64_t seed,
+                                   int64_t* mix);
+
+/* random.Random(seed).uniform(0, 1) — the probability-gate draw (augmentations.py:869-870). */
+double pcgmix_py_uniform01(uint64_t seed);
+
+/* random.Random(seed).randint(0, hi) — the '(rand)' placement offset (augmentations.py:307). */
+int64_t pcgmix_py_randint0(uint64_t seed, int64_t hi);
+
+/* ------------------------------------------------------------------------------------------
  * Fused segment-aware splice (+ optional magnitude warp).                        [device]
  *
  * Replaces, for a whole batch in one launch:

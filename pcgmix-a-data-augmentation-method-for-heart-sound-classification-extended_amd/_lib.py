@@ -24,6 +24,9 @@ SIGNATURES = {
     "pcgmix_error_string": (ctypes.c_char_p, [_c_int]),
     "pcgmix_spline_operator_size": (_c_int, [_c_int]),
     "pcgmix_spline_operator_f64": (_c_int, [_c_int, _c_int, _ptr]),
+    "pcgmix_partner_permutation_i64": (_c_int, [_ptr, _c_int, _c_int, ctypes.c_uint64, _ptr]),
+    "pcgmix_py_uniform01": (ctypes.c_double, [ctypes.c_uint64]),
+    "pcgmix_py_randint0": (ctypes.c_int64, [ctypes.c_uint64, ctypes.c_int64]),
     "pcgmix_mix_warp_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _ptr, _ptr, _c_int,
                                      _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_saliency_post_f32": (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_float, _c_int, _c_int,

@@ -62,26 +62,66 @@ def spline_operator(device: torch.device, sig_len: int, n_knots: int) -> torch.T
     return op
 
 
+class _StagingRing:
+    """Pinned host staging for the per-step index upload.
+
+    ``tensor.pin_memory()`` per call costs ~1 ms on this stack (a fresh hipHostMalloc whenever
+    the previous block's copy has not retired yet), so a small ring of pinned buffers is kept
+    per device instead; a slot is reused only after the event recorded behind its last copy has
+    completed, which keeps the async H2D copy race-free without ever blocking in steady state."""
+
+    SLOTS = 8
+
+    def __init__(self):
+        self.bufs = [None] * self.SLOTS
+        self.events = [None] * self.SLOTS
+        self.next = 0
+
+    def stage(self, nbytes: int):
+        i = self.next
+        self.next = (i + 1) % self.SLOTS
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        buf = self.bufs[i]
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(4096, 1 << (nbytes - 1).bit_length()), dtype=torch.uint8,
+                              pin_memory=True)
+            self.bufs[i] = buf
+        return i, buf
+
+    def sent(self, i: int):
+        ev = self.events[i]
+        if ev is None:
+            ev = self.events[i] = torch.cuda.Event()
+        ev.record()
+
+
+_RINGS: dict = {}
+
+
 def upload_plan(plan: MixPlan, frames: np.ndarray, device: torch.device):
-    """One H2D copy with every small per-step array: int32 frames (B,5) | mix (B) | offsets
-    (B,4, optional) | float64 knots (optional).  Returns (buffer, byte offsets)."""
+    """One async H2D copy with every small per-step array: int32 frames (B,5) | mix (B) |
+    offsets (B,4, optional) | float64 knots (optional).  Returns (device buffer, byte offsets).
+    Must be called with ``device`` current."""
     B = frames.shape[0]
     n_off = B * 4 if plan.rand_off is not None else 0
     n_int = B * 5 + B + n_off
     n_int_pad = (n_int + 1) & ~1                      # keep the float64 block 8-byte aligned
     n_kn = plan.knots.size if plan.knots is not None else 0
-    buf = np.empty(n_int_pad * 4 + n_kn * 8, dtype=np.uint8)
+    nbytes = n_int_pad * 4 + n_kn * 8
+    ring = _RINGS.setdefault(device.index, _StagingRing())
+    slot, pinned = ring.stage(nbytes)
+    buf = pinned.numpy()
     ints = buf[:n_int_pad * 4].view(np.int32)
     ints[:B * 5] = frames.reshape(-1)
     ints[B * 5:B * 6] = plan.mix
     if n_off:
         ints[B * 6:B * 6 + n_off] = plan.rand_off.reshape(-1)
     if n_kn:
-        buf[n_int_pad * 4:].view(np.float64)[:] = plan.knots.reshape(-1)
-    # pinned staging + async copy: the call never waits for earlier GPU work (a pageable
-    # copy would synchronise the stream); the host allocator keeps the pinned block alive
-    # until the copy has run
-    dev = torch.from_numpy(buf).pin_memory().to(device, non_blocking=True)
+        buf[n_int_pad * 4:nbytes].view(np.float64)[:] = plan.knots.reshape(-1)
+    dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dev.copy_(pinned[:nbytes], non_blocking=True)
+    ring.sent(slot)
     offs = {"frames": 0, "mix": B * 5 * 4, "off": B * 6 * 4 if n_off else None,
             "knots": n_int_pad * 4 if n_kn else None}
     return dev, offs
@@ -141,8 +181,9 @@ def blend_targets(target_ohe: torch.Tensor, plan: MixPlan) -> torch.Tensor:
 
 
 def labels_from_ohe(target_ohe: torch.Tensor) -> np.ndarray:
-    """Reverse the one-hot encoding on the host (augmentations.py:501): one D2H sync."""
-    return target_ohe.max(1, keepdim=True)[1].detach().cpu().numpy().reshape(-1)
+    """Reverse the one-hot encoding on the host (augmentations.py:501): one D2H copy of the
+    (B, classes) matrix, argmax (first maximum, like torch.max) in numpy — no reduce kernel."""
+    return target_ohe.detach().cpu().numpy().argmax(axis=1)
 
 
 def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RESULTS_ARGS):

@@ -118,3 +118,126 @@ extern "C" int pcgmix_spline_operator_f64(int T, int n_knots, double* op) {
   }
   return hipSuccess;
 }
+
+// ------------------------------------------------------------------------------------------------
+// CPython's random.Random, restated: MT19937 (Matsumoto & Nishimura reference algorithm, as
+// Modules/_randommodule.c uses it) plus Lib/random.py's sample()/_randbelow()/uniform().
+namespace {
+
+struct PyRandom {
+  uint32_t mt[624];
+  int idx;
+
+  void init_genrand(uint32_t s) {
+    mt[0] = s;
+    for (int i = 1; i < 624; ++i)
+      mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    idx = 624;
+  }
+
+  void init_by_array(const uint32_t* key, int len) {
+    init_genrand(19650218u);
+    int i = 1, j = 0;
+    for (int k = (624 > len ? 624 : len); k; --k) {
+      mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+      ++i; ++j;
+      if (i >= 624) { mt[0] = mt[623]; i = 1; }
+      if (j >= len) j = 0;
+    }
+    for (int k = 623; k; --k) {
+      mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+      ++i;
+      if (i >= 624) { mt[0] = mt[623]; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+  }
+
+  // random.seed(int): key = little-endian 32-bit words of abs(seed), at least one word
+  explicit PyRandom(uint64_t seed) {
+    uint32_t key[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
+    init_by_array(key, key[1] ? 2 : 1);
+  }
+
+  uint32_t next32() {
+    if (idx >= 624) {
+      int kk;
+      for (kk = 0; kk < 624 - 397; ++kk) {
+        uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+        mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      for (; kk < 623; ++kk) {
+        uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+        mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+      mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  }
+
+  double random() {  // 53-bit resolution, genrand_res53
+    const uint32_t a = next32() >> 5, b = next32() >> 6;
+    return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
+  }
+
+  // getrandbits(k), 1 <= k <= 64: little-endian 32-bit words, the last one shifted down
+  uint64_t getrandbits(int k) {
+    if (k <= 32) return next32() >> (32 - k);
+    const uint64_t lo = next32();
+    const uint64_t hi = next32() >> (64 - k);
+    return lo | (hi << 32);
+  }
+
+  // Random._randbelow_with_getrandbits(n), n >= 1
+  uint64_t randbelow(uint64_t n) {
+    int k = 0;
+    for (uint64_t v = n; v; v >>= 1) ++k;  // n.bit_length()
+    uint64_t r = getrandbits(k);
+    while (r >= n) r = getrandbits(k);
+    return r;
+  }
+};
+
+}  // namespace
+
+extern "C" double pcgmix_py_uniform01(uint64_t seed) {
+  PyRandom r(seed);
+  return 0.0 + (1.0 - 0.0) * r.random();  // a + (b - a) * random()
+}
+
+extern "C" int64_t pcgmix_py_randint0(uint64_t seed, int64_t hi) {
+  if (hi < 0) return -1;
+  PyRandom r(seed);
+  return (int64_t)r.randbelow((uint64_t)hi + 1u);  // randrange(0, hi + 1)
+}
+
+extern "C" int pcgmix_partner_permutation_i64(const int32_t* group_id, int B, int n_groups,
+                                              uint64_t seed, int64_t* mix) {
+  if (!group_id || !mix || B < 0 || n_groups < 0) return hipErrorInvalidValue;
+  std::vector<std::vector<int64_t>> members((size_t)n_groups);
+  for (int b = 0; b < B; ++b) {
+    const int g = group_id[b];
+    if (g < 0 || g >= n_groups) return hipErrorInvalidValue;
+    members[(size_t)g].push_back(b);
+  }
+  std::vector<int64_t> pool;
+  for (const auto& idx : members) {
+    const size_t n = idx.size();
+    if (!n) continue;
+    PyRandom rng(seed);  // a fresh Random(seed) per group, as the reference
+    pool = idx;
+    // sample(population, k = n): pool branch of Lib/random.py
+    for (size_t i = 0; i < n; ++i) {
+      const uint64_t j = rng.randbelow((uint64_t)(n - i));
+      mix[idx[i]] = pool[j];
+      pool[j] = pool[n - i - 1];
+    }
+  }
+  return hipSuccess;
+}

@@ -14,6 +14,7 @@
 // fp64 and stores 16 bytes.  HBM-bound: 12 algorithmic bytes per element.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pcgmix_kernels.h"
 
@@ -87,32 +88,59 @@ __device__ __forceinline__ float blend(float own, float other, float lam, float 
   return __fadd_rn(__fmul_rn(own, lam), __fmul_rn(other, oml));
 }
 
-// Spline value at integer position t for the piece table `cf` (4 doubles per piece, scipy
-// layout c0..c3 with c0 the cubic term).  Order of operations as scipy's PPoly evaluation.
-__device__ __forceinline__ double spline_at(const double* __restrict__ cf,
-                                            const double* __restrict__ brk, int n_knots, int t) {
-  double td = (double)t;
-  int p = 0;
-  for (int i = 1; i <= n_knots - 2; ++i) p += (brk[i] <= td) ? 1 : 0;
-  double s = __dsub_rn(td, brk[p]);
-  const double* c = cf + p * 4;
-  double r = c[3];
-  r = __dadd_rn(r, __dmul_rn(c[2], s));
-  double z = __dmul_rn(s, s);
-  r = __dadd_rn(r, __dmul_rn(c[1], z));
-  z = __dmul_rn(z, s);
-  r = __dadd_rn(r, __dmul_rn(c[0], z));
-  return r;
+// ---- magnitude-warp spline -------------------------------------------------------------------
+// LDS image built per block: for every channel the chunk touches, one 6-double record per
+// cubic piece {c0, c1, c2, c3, brk[p], pad} (scipy PPoly layout: c0 multiplies s^3), followed by
+// the integer thresholds thr[i] = ceil(brk[i]) so that "brk[i] <= t" is an integer compare.
+constexpr int kRec = 6;
+
+__device__ __forceinline__ int spline_piece(const int* __restrict__ thr, int n_knots, int t) {
+  int p = 0;  // searchsorted(brk, t, 'right') - 1, clipped to the last piece
+  for (int i = 1; i <= n_knots - 2; ++i) p += (t >= thr[i]) ? 1 : 0;
+  return p;
 }
 
-// VEC = 4: T % 4 == 0, rows are 16-byte aligned.  VEC = 1: any T.
-template <int VEC, bool WARP>
+// scipy's PPoly evaluation order: c3 + c2*s + c1*s^2 + c0*s^3 with a running power, every
+// operation rounded separately in float64; then float32(float64(v) * w) as numpy stores it.
+__device__ __forceinline__ float spline_scale(float v, int t, double c0, double c1, double c2,
+                                              double c3, double brk) {
+  const double s = __dsub_rn((double)t, brk);
+  double r = __dadd_rn(c3, __dmul_rn(c2, s));
+  double z = __dmul_rn(s, s);
+  r = __dadd_rn(r, __dmul_rn(c1, z));
+  z = __dmul_rn(z, s);
+  r = __dadd_rn(r, __dmul_rn(c0, z));
+  return __double2float_rn(__dmul_rn((double)v, r));
+}
+
+template <int VEC>
+__device__ __forceinline__ void spline_apply(float (&out)[VEC], const double* __restrict__ tab,
+                                             const int* __restrict__ thr, int n_knots, int t0) {
+  const int p0 = spline_piece(thr, n_knots, t0);
+  const int p1 = VEC > 1 ? spline_piece(thr, n_knots, t0 + VEC - 1) : p0;
+  if (p0 == p1) {  // the usual case: pieces are hundreds of samples long
+    const double* r = tab + p0 * kRec;
+    const double c0 = r[0], c1 = r[1], c2 = r[2], c3 = r[3], brk = r[4];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) out[e] = spline_scale(out[e], t0 + e, c0, c1, c2, c3, brk);
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const double* r = tab + spline_piece(thr, n_knots, t0 + e) * kRec;
+      out[e] = spline_scale(out[e], t0 + e, r[0], r[1], r[2], r[3], r[4]);
+    }
+  }
+}
+
+// VEC = 4: T % 4 == 0, rows are 16-byte aligned, U quads per lane (epb = 256*4*U).
+// VEC = 1: any T, one element per lane and iteration.
+template <int VEC, bool WARP, int U>
 __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
     const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ frames,
     const int32_t* __restrict__ mix_idx, const int32_t* __restrict__ off, float lam, float oml,
     const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots, int B,
     int C, int T, int epb) {
-  extern __shared__ __align__(16) double lds[];  // [n_knots] break points, then coef tables
+  extern __shared__ __align__(16) double lds[];  // spline records per channel, then thresholds
 
   const int b = blockIdx.z * kBatchPerGridZ + blockIdx.y;
   if (b >= B) return;  // block-uniform
@@ -126,82 +154,107 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
   const size_t par_base = (size_t)m * plane;
 
   int c_lo = 0;
+  const int rec_per_ch = (n_knots - 1) * kRec;
+  const int* thr = nullptr;
   if (WARP) {
-    // Coefficient tables for the channels this chunk touches: coef = op * knots[b,:,c].
+    // Coefficient records for the channels this chunk touches: coef = op * knots[b,:,c].
     c_lo = chunk0 / T;
     int last = chunk0 + epb - 1;
     if (last > plane - 1) last = plane - 1;
-    const int c_hi = last / T;
-    const int pieces4 = (n_knots - 1) * 4;
-    double* brk = lds;
-    double* cf = lds + n_knots;
-    for (int i = threadIdx.x; i < n_knots; i += kThreads) brk[i] = spline_op[i];
-    const int total = (c_hi - c_lo + 1) * pieces4;
+    const int nch = last / T - c_lo + 1;
+    int* thr_w = reinterpret_cast<int*>(lds + (size_t)(epb / T + 2) * rec_per_ch);
+    thr = thr_w;
+    for (int i = threadIdx.x; i < n_knots; i += kThreads) thr_w[i] = (int)ceil(spline_op[i]);
+    const int total = nch * rec_per_ch;
     for (int i = threadIdx.x; i < total; i += kThreads) {
-      const int c = c_lo + i / pieces4;
-      const int row = i % pieces4;
-      const double* mrow = spline_op + n_knots + (size_t)row * n_knots;
+      const int c = c_lo + i / rec_per_ch;
+      const int r = i % rec_per_ch;
+      const int piece = r / kRec, j4 = r % kRec;
       double acc = 0.0;
-      for (int j = 0; j < n_knots; ++j)
-        acc = __dadd_rn(acc, __dmul_rn(mrow[j], knots[((size_t)b * n_knots + j) * C + c]));
-      cf[i] = acc;
+      if (j4 < 4) {
+        const double* mrow = spline_op + n_knots + (size_t)(piece * 4 + j4) * n_knots;
+        for (int j = 0; j < n_knots; ++j)
+          acc = __dadd_rn(acc, __dmul_rn(mrow[j], knots[((size_t)b * n_knots + j) * C + c]));
+      } else if (j4 == 4) {
+        acc = spline_op[piece];
+      }
+      lds[i] = acc;
     }
     __syncthreads();
   }
 
-  for (int i = chunk0 + threadIdx.x * VEC; i < chunk0 + epb && i < plane; i += kThreads * VEC) {
-    const int c = i / T;
-    const int t0 = i - c * T;
-    float own[VEC], out[VEC];
-    if constexpr (VEC == 4) {
-      float4_a v = *reinterpret_cast<const float4_a*>(x + own_base + i);
-      own[0] = v.x; own[1] = v.y; own[2] = v.z; own[3] = v.w;
-    } else {
-      own[0] = x[own_base + i];
-    }
-    const float* prow = x + par_base + (size_t)c * T;
-
-    bool hit[VEC];
-    int d[VEC];
+  if constexpr (VEC == 4) {
+    // Two phases so that all U own-row and partner-row loads of a lane are in flight together.
+    // Phase 1 is branch-free: the partner quad is fetched with ONE unaligned 16-byte load at
+    // the shift of the first blended element (clamped into the row); elements of the quad that
+    // blend with a different shift (a state boundary inside the quad) or whose quad load had to
+    // be clamped are patched by a scalar load in phase 2 (at most a handful of quads per row).
+    float4_a own[U];
+    float4_u par[U];
+    int t0s[U], cs[U], masks[U];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) d[e] = blend_shift(sm, t0 + e, hit[e]);
-
-    bool uniform = false;
-    if constexpr (VEC == 4)
-      uniform = hit[0] && hit[1] && hit[2] && hit[3] && d[0] == d[1] && d[0] == d[2] &&
-                d[0] == d[3];
-    if (uniform) {
-      if constexpr (VEC == 4) {
-        float4_u p = *reinterpret_cast<const float4_u*>(prow + t0 + d[0]);
-        out[0] = blend(own[0], p.x, lam, oml);
-        out[1] = blend(own[1], p.y, lam, oml);
-        out[2] = blend(own[2], p.z, lam, oml);
-        out[3] = blend(own[3], p.w, lam, oml);
-      }
-    } else {
+    for (int q = 0; q < U; ++q) {
+      const int i = chunk0 + (q * kThreads + (int)threadIdx.x) * 4;
+      const bool valid = i < plane;
+      const int ii = valid ? i : 0;
+      const int c = ii / T;
+      const int t0 = ii - c * T;
+      bool hit[4];
+      int d[4];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        float o = own[e];
-        if (hit[e]) o = blend(o, prow[t0 + e + d[e]], lam, oml);
-        out[e] = o;
-      }
-    }
-
-    if (WARP) {
-      const double* brk = lds;
-      const double* cf = lds + n_knots + (size_t)(c - c_lo) * (n_knots - 1) * 4;
+      for (int e = 0; e < 4; ++e) d[e] = blend_shift(sm, t0 + e, hit[e]);
+      const int dsel = hit[0] ? d[0] : hit[1] ? d[1] : hit[2] ? d[2] : hit[3] ? d[3] : 0;
+      int src0 = t0 + dsel;
+      src0 = src0 < 0 ? 0 : (src0 > T - 4 ? T - 4 : src0);
+      const bool clamped = src0 != t0 + dsel;
+      int mask = valid ? 0x100 : 0;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        double w = spline_at(cf, brk, n_knots, t0 + e);
-        out[e] = __double2float_rn(__dmul_rn((double)out[e], w));
+      for (int e = 0; e < 4; ++e) {
+        if (hit[e]) mask |= 1 << e;
+        if (hit[e] && (clamped || d[e] != dsel)) mask |= 16 << e;
       }
+      own[q] = *reinterpret_cast<const float4_a*>(x + own_base + ii);
+      // the zero-padded tail and the unmatched part of longer states never touch the partner
+      float4_u pz = {0.f, 0.f, 0.f, 0.f};
+      if (mask & 0xf) pz = *reinterpret_cast<const float4_u*>(x + par_base + (size_t)c * T + src0);
+      par[q] = pz;
+      t0s[q] = t0;
+      cs[q] = c;
+      masks[q] = mask;
     }
-
-    if constexpr (VEC == 4) {
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int mask = masks[q];
+      if (!(mask & 0x100)) continue;
+      const int t0 = t0s[q], c = cs[q];
+      float o[4] = {own[q].x, own[q].y, own[q].z, own[q].w};
+      float pv[4] = {par[q].x, par[q].y, par[q].z, par[q].w};
+      float out[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = pv[e];
+        if (mask & (16 << e)) {  // rare: patch with the element's own shift
+          bool h;
+          const int de = blend_shift(sm, t0 + e, h);
+          v = x[par_base + (size_t)c * T + t0 + e + de];
+        }
+        out[e] = (mask & (1 << e)) ? blend(o[e], v, lam, oml) : o[e];
+      }
+      if (WARP) spline_apply<4>(out, lds + (size_t)(c - c_lo) * rec_per_ch, thr, n_knots, t0);
       float4_a v;
       v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
+      const int i = chunk0 + (q * kThreads + (int)threadIdx.x) * 4;
       *reinterpret_cast<float4_a*>(y + own_base + i) = v;
-    } else {
+    }
+  } else {
+    for (int i = chunk0 + threadIdx.x; i < chunk0 + epb && i < plane; i += kThreads) {
+      const int c = i / T;
+      const int t0 = i - c * T;
+      bool hit;
+      const int d = blend_shift(sm, t0, hit);
+      float out[1] = {x[own_base + i]};
+      if (hit) out[0] = blend(out[0], x[par_base + (size_t)c * T + t0 + d], lam, oml);
+      if (WARP) spline_apply<1>(out, lds + (size_t)(c - c_lo) * rec_per_ch, thr, n_knots, t0);
       y[own_base + i] = out[0];
     }
   }
@@ -224,12 +277,22 @@ extern "C" int pcgmix_mix_warp_f32(const float* x, float* y, const int32_t* fram
 
   const bool vec4 = (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  const int epb = kThreads * 4;  // elements of one sample's plane per block
+  // Elements of one sample's plane per block: 1024 * U.  Fatter blocks amortise the block
+  // prologue (dependent index loads, spline records) and keep more loads in flight per lane;
+  // thinner ones waste fewer lanes on the last chunk of a short plane.  Chosen from measurements
+  // on MI355X ("Block shape"); PCGMIX_MIX_UNROLL overrides it for tuning runs.
+  int U = plane >= 8192 ? 2 : 1;
+  if (warp && plane >= 16384 && (long long)B * plane >= (64LL << 20)) U = 4;
+  if (const char* env = getenv("PCGMIX_MIX_UNROLL")) {
+    const int v = atoi(env);
+    if (v == 1 || v == 2 || v == 4) U = v;
+  }
+  const int epb = kThreads * 4 * U;
   const unsigned chunks = (unsigned)((plane + epb - 1) / epb);
   size_t lds = 0;
   if (warp) {
     const int nch = epb / T + 2;
-    lds = sizeof(double) * ((size_t)n_knots + (size_t)nch * (n_knots - 1) * 4);
+    lds = sizeof(double) * (size_t)nch * (n_knots - 1) * kRec + sizeof(int) * (size_t)n_knots;
     if (lds > 64 * 1024) return hipErrorInvalidValue;
   }
   const float oml = 1.0f - lam;  // float32 subtraction, as torch's (1 - lam) on a float32 tensor
@@ -238,14 +301,21 @@ extern "C" int pcgmix_mix_warp_f32(const float* x, float* y, const int32_t* fram
   const unsigned gy = (unsigned)(B < kBatchPerGridZ ? B : kBatchPerGridZ);
   const unsigned gz = (unsigned)((B + kBatchPerGridZ - 1) / kBatchPerGridZ);
   dim3 grid(chunks, gy, gz), block(kThreads);
-#define PCGMIX_LAUNCH(V, W)                                                                   \
-  hipLaunchKernelGGL((mix_warp_kernel<V, W>), grid, block, lds, s, x, y, frames, mix_idx, off, \
-                     lam, oml, knots, spline_op, n_knots, B, C, T, epb)
+#define PCGMIX_LAUNCH(V, W, UU)                                                              \
+  hipLaunchKernelGGL((mix_warp_kernel<V, W, UU>), grid, block, lds, s, x, y, frames, mix_idx, \
+                     off, lam, oml, knots, spline_op, n_knots, B, C, T, epb)
+#define PCGMIX_LAUNCH_U(W)                                \
+  do {                                                    \
+    if (U == 4) PCGMIX_LAUNCH(4, W, 4);                   \
+    else if (U == 2) PCGMIX_LAUNCH(4, W, 2);              \
+    else PCGMIX_LAUNCH(4, W, 1);                          \
+  } while (0)
   if (vec4) {
-    if (warp) PCGMIX_LAUNCH(4, true); else PCGMIX_LAUNCH(4, false);
+    if (warp) PCGMIX_LAUNCH_U(true); else PCGMIX_LAUNCH_U(false);
   } else {
-    if (warp) PCGMIX_LAUNCH(1, true); else PCGMIX_LAUNCH(1, false);
+    if (warp) PCGMIX_LAUNCH(1, true, 1); else PCGMIX_LAUNCH(1, false, 1);
   }
+#undef PCGMIX_LAUNCH_U
 #undef PCGMIX_LAUNCH
   return (int)hipGetLastError();
 }

@@ -54,6 +54,32 @@ def test_rand_offsets_depend_on_gap_only():
             assert off[b, k] == random.Random(9).randint(0, abs(int(lens[m, k] - lens[b, k])))
 
 
+@pytest.mark.parametrize("seed", [0, 1, 77, 1234, 2**31 - 1, 2**32 + 7])
+def test_c_sampler_is_cpython_random(seed):
+    """The library's MT19937/sample/uniform/randint restatement against CPython itself."""
+    import random
+    lib = _lib.load()
+    assert lib.pcgmix_py_uniform01(seed) == random.Random(seed).uniform(0, 1)
+    for hi in (0, 1, 2, 5, 255, 256, 1345, 2**33):
+        assert lib.pcgmix_py_randint0(seed, hi) == random.Random(seed).randint(0, hi)
+    rs = np.random.RandomState(seed % 2**31)
+    for B in (1, 2, 3, 17, 64, 255, 256, 1000):
+        keys = rs.randint(0, 3, B)
+        got = hostprep.shuffle_within_groups(keys, seed)
+        ref = np.arange(B)
+        for k in np.unique(keys):
+            idx = [i for i in range(B) if keys[i] == k]
+            ref[idx] = random.Random(seed).sample(idx, len(idx))
+        assert np.array_equal(got, ref)
+    names = [f"w{i % 5}" for i in range(40)]
+    got = hostprep.shuffle_within_groups(names, seed)
+    ref = np.arange(40)
+    for k in set(names):
+        idx = [i for i in range(40) if names[i] == k]
+        ref[idx] = random.Random(seed).sample(idx, len(idx))
+    assert np.array_equal(got, ref)
+
+
 def test_unknown_method_is_passthrough_and_foreign_method_is_refused():
     assert hostprep.select_method("base", False) is None
     assert hostprep.select_method("durmixmagwarp(0.2,4)+0.4", False) == "durmixmagwarp"
