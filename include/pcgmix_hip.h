@@ -131,10 +131,13 @@ int pcgmix_mix_warp_f32(const float* x, float* y,
  *
  *   grad        device, (B, C, T)
  *   sal         device, (B, T) out
- *   ksize       odd, <= 1023
+ *   ksize       odd, <= 255 (the reference uses 101); weights are formed on the host in
+ *               float64 exactly as gaussian_kernel() does and rounded to float32
+ *   sigma       float64, the reference's (12/101)*ksize
+ *   T           <= 19000 (the row is staged in LDS)
  */
 int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames, float* sal,
-                             int ksize, float sigma, int B, int C, int T,
+                             int ksize, double sigma, int B, int C, int T,
                              pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -148,6 +151,7 @@ int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames, float* sa
  *
  *   sal         device, (B, T) saliency maps
  *   disp        device, int32 (B, 4) out — feeds pcgmix_mix_warp_f32's `off`
+ *   B <= 65535, T <= 19000
  */
 int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames, const int32_t* mix_idx,
                            float lam, int mode, int32_t* disp, int B, int T,

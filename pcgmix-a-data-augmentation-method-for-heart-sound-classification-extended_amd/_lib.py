@@ -29,7 +29,7 @@ SIGNATURES = {
     "pcgmix_py_randint0": (ctypes.c_int64, [ctypes.c_uint64, ctypes.c_int64]),
     "pcgmix_mix_warp_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _ptr, _ptr, _c_int,
                                      _c_int, _c_int, _c_int, _ptr]),
-    "pcgmix_saliency_post_f32": (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_float, _c_int, _c_int,
+    "pcgmix_saliency_post_f32": (_c_int, [_ptr, _ptr, _ptr, _c_int, ctypes.c_double, _c_int, _c_int,
                                           _c_int, _ptr]),
     "pcgmix_salopt_disp_f32": (_c_int, [_ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _c_int, _c_int,
                                         _ptr]),

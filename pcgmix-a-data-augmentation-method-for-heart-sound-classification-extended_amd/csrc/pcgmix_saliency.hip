@@ -1,7 +1,308 @@
-// placeholder translation unit — replaced by the saliency kernels
+// pcgmix_saliency.hip — saliency post-processing and saliency-optimal displacement search (gfx950).
+//
+//  saliency_post_kernel   saliency.py:63-91   |grad| -> zero tail -> sum channels -> Gaussian ->
+//                                             zero tail -> per-row min/max normalisation
+//  salopt_disp_kernel     augmentations.py:60-128, 210-287   first strict argmax over the
+//                                             displacement d of a float32 objective summed in
+//                                             numpy's pairwise order
+//
+// Both are tiny next to the splice (4*C*T + 4*T and 8*T algorithmic bytes per sample); they exist
+// so that a saliency-guided step needs no host round trip: the displacement table they produce is
+// consumed directly by pcgmix_mix_warp_f32 as its `off` argument.
 #include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
 #include "pcgmix_kernels.h"
-extern "C" int pcgmix_saliency_post_f32(const float*, const int32_t*, float*, int, float, int, int,
-                                        int, pcgmix_stream_t) { return hipErrorNotSupported; }
-extern "C" int pcgmix_salopt_disp_f32(const float*, const int32_t*, const int32_t*, float, int,
-                                      int32_t*, int, int, pcgmix_stream_t) { return hipErrorNotSupported; }
+
+namespace pcgmix {
+
+constexpr int kSalThreads = 256;
+constexpr int kMaxTaps = 255;
+
+struct Taps {
+  float w[kMaxTaps];
+};
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  // wave64 shuffle reduction, then one LDS hop across the 4 waves of the block
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float other = __shfl_xor(v, o, 64);
+    v = is_max ? fmaxf(v, other) : fminf(v, other);
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < kSalThreads / 64; ++i) r = is_max ? fmaxf(r, red[i]) : fminf(r, red[i]);
+  return r;
+}
+
+// One block per row b.  LDS: a[T + ksize - 1] (channel-summed |grad| with zero halo), s[T].
+__global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
+    const float* __restrict__ grad, const int32_t* __restrict__ frames, float* __restrict__ sal,
+    Taps taps, int ksize, int B, int C, int T) {
+  extern __shared__ __align__(16) float smem[];
+  __shared__ float red[kSalThreads / 64];
+  const int b = blockIdx.x;
+  const int half = ksize / 2;
+  float* a = smem;                  // a[half + t]
+  float* s = smem + T + ksize - 1;  // s[t]
+  int f4 = frames[b * 5 + 4];
+  f4 = f4 < 0 ? 0 : (f4 > T ? T : f4);
+
+  for (int i = threadIdx.x; i < T + ksize - 1; i += kSalThreads) {
+    const int t = i - half;
+    float acc = 0.f;
+    if (t >= 0 && t < f4) {  // saliency.py:66-67 zeroes t >= f[-1] before the channel sum
+      const float* g = grad + ((size_t)b * C) * T + t;
+      for (int c = 0; c < C; ++c) acc = __fadd_rn(acc, fabsf(g[(size_t)c * T]));
+    }
+    a[i] = acc;
+  }
+  __syncthreads();
+
+  float lmin = INFINITY;
+  for (int t = threadIdx.x; t < T; t += kSalThreads) {
+    float acc = 0.f;
+    if (t < f4) {  // saliency.py:78-79 zeroes the tail again after smoothing
+      for (int j = 0; j < ksize; ++j) acc = __fadd_rn(acc, __fmul_rn(taps.w[j], a[t + j]));
+    }
+    s[t] = acc;
+    lmin = fminf(lmin, acc);
+  }
+  const float rmin = block_reduce(lmin, red, false);
+  float lmax = -INFINITY;
+  for (int t = threadIdx.x; t < T; t += kSalThreads) {
+    const float v = __fsub_rn(s[t], rmin);  // saliency.py:83
+    s[t] = v;
+    lmax = fmaxf(lmax, v);
+  }
+  const float rmax = block_reduce(lmax, red, true);
+  for (int t = threadIdx.x; t < T; t += kSalThreads) {
+    float v = __fdiv_rn(s[t], rmax);  // saliency.py:84; 0/0 -> NaN -> 0 (saliency.py:87)
+    if (v != v) v = 0.f;
+    sal[(size_t)b * T + t] = v;
+  }
+}
+
+// ---- numpy's pairwise float32 summation (numpy/_core/src/umath/loops_utils.h.src), restated ----
+// np.sum over a contiguous float32 array of n elements = 0 + pairwise(a, n) where
+//   n < 8      sequential from 0
+//   n <= 128   8 strided accumulators, combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the
+//              n % 8 tail added sequentially
+//   n > 128    n2 = n/2 - (n/2) % 8;  pairwise(a, n2) + pairwise(a + n2, n - n2)
+// Every operation is a separately rounded float32 add.  `elem(i)` yields element i.
+template <class F>
+__device__ __forceinline__ float pw_leaf(F elem, int start, int n) {
+  if (n < 8) {
+    float res = 0.f;
+    for (int i = 0; i < n; ++i) res = __fadd_rn(res, elem(start + i));
+    return res;
+  }
+  float r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = elem(start + j);
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], elem(start + i + j));
+  }
+  float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
+                        __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+  for (; i < n; ++i) res = __fadd_rn(res, elem(start + i));
+  return res;
+}
+
+template <class F>
+__device__ float pw_sum(F elem, int n) {
+  if (n <= 128) return pw_leaf(elem, 0, n);
+  // explicit post-order walk of the split tree (depth <= log2(n/64) < 32)
+  int st_start[32], st_n[32];
+  float st_left[32];
+  unsigned have_left = 0;  // bit sp: the node at depth sp already holds its left sum
+  int sp = 0;
+  st_start[0] = 0;
+  st_n[0] = n;
+  float ret = 0.f;
+  bool returning = false;
+  while (sp >= 0) {
+    if (!returning) {
+      const int cn = st_n[sp];
+      if (cn <= 128) {
+        ret = pw_leaf(elem, st_start[sp], cn);
+        returning = true;
+        --sp;
+      } else {  // descend into the left child
+        int n2 = cn / 2;
+        n2 -= n2 % 8;
+        have_left &= ~(1u << sp);
+        st_start[sp + 1] = st_start[sp];
+        st_n[sp + 1] = n2;
+        ++sp;
+      }
+    } else {
+      if (!(have_left & (1u << sp))) {  // left done -> right child
+        st_left[sp] = ret;
+        have_left |= 1u << sp;
+        int n2 = st_n[sp] / 2;
+        n2 -= n2 % 8;
+        st_start[sp + 1] = st_start[sp] + n2;
+        st_n[sp + 1] = st_n[sp] - n2;
+        ++sp;
+        returning = false;
+      } else {  // both done
+        ret = __fadd_rn(st_left[sp], ret);
+        --sp;
+      }
+    }
+  }
+  return ret;
+}
+
+// One block per (state k, sample b); candidates d are strided over the lanes.
+// LDS: lng[nL] (the longer state's saliency), sht[nS] (the shorter one's).
+template <int MODE>  // 0: envelope (max), 1: lambda-weighted sum
+__global__ __launch_bounds__(kSalThreads) void salopt_disp_kernel(
+    const float* __restrict__ sal, const int32_t* __restrict__ frames,
+    const int32_t* __restrict__ mix_idx, float lam, float oml, int32_t* __restrict__ disp, int B,
+    int T) {
+  extern __shared__ __align__(16) float smem[];
+  __shared__ float best_v[kSalThreads / 64];
+  __shared__ int best_d[kSalThreads / 64];
+  const int k = blockIdx.x, b = blockIdx.y;
+  int m = mix_idx[b];
+  m = (m < 0 || m >= B) ? b : m;
+  int a1 = frames[b * 5 + k], e1 = frames[b * 5 + k + 1];
+  int a2 = frames[m * 5 + k], e2 = frames[m * 5 + k + 1];
+  a1 = a1 < 0 ? 0 : (a1 > T ? T : a1);
+  e1 = e1 < a1 ? a1 : (e1 > T ? T : e1);
+  a2 = a2 < 0 ? 0 : (a2 > T ? T : a2);
+  e2 = e2 < a2 ? a2 : (e2 > T ? T : e2);
+  const int n1 = e1 - a1, n2 = e2 - a2;
+  if (n1 == n2) {  // equal lengths: no search (augmentations.py:226-229)
+    if (threadIdx.x == 0) disp[b * 4 + k] = 0;
+    return;
+  }
+  const bool own_longer = n1 > n2;
+  const int nL = own_longer ? n1 : n2, nS = own_longer ? n2 : n1;
+  const float* gl = sal + (size_t)(own_longer ? b : m) * T + (own_longer ? a1 : a2);
+  const float* gs = sal + (size_t)(own_longer ? m : b) * T + (own_longer ? a2 : a1);
+  float* lng = smem;
+  float* sht = smem + nL;
+  for (int i = threadIdx.x; i < nL; i += kSalThreads) lng[i] = gl[i];
+  for (int i = threadIdx.x; i < nS; i += kSalThreads) sht[i] = gs[i];
+  __syncthreads();
+
+  float bv = -INFINITY;
+  int bd = 0x7fffffff;
+  for (int d = threadIdx.x; d <= nL - nS; d += kSalThreads) {
+    auto mid = [&](int i) -> float {
+      const float l = lng[d + i], s = sht[i];
+      if (MODE == 0) return fmaxf(l, s);
+      // s1*lam + s2*(1-lam): s1 is the OWN sample's saliency in both branches
+      const float s1 = own_longer ? l : s, s2 = own_longer ? s : l;
+      return __fadd_rn(__fmul_rn(s1, lam), __fmul_rn(s2, oml));
+    };
+    float cur = pw_sum(mid, nS);
+    if (own_longer) {  // np.sum(s1[:d]) + np.sum(mid) + np.sum(s1[d+n2:])   (:76-78, :111-113)
+      const float head = pw_sum([&](int i) -> float { return lng[i]; }, d);
+      const float tail = pw_sum([&](int i) -> float { return lng[d + nS + i]; }, nL - nS - d);
+      cur = __fadd_rn(__fadd_rn(head, cur), tail);
+    }
+    if (cur > bv) {  // ascending d per lane: strict '>' keeps the first maximum
+      bv = cur;
+      bd = d;
+    }
+  }
+  // arg-max across the block; ties go to the smallest d (= first strict maximum of the scan)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int od = __shfl_xor(bd, o, 64);
+    if (ov > bv || (ov == bv && od < bd)) {
+      bv = ov;
+      bd = od;
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    best_v[threadIdx.x >> 6] = bv;
+    best_d[threadIdx.x >> 6] = bd;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < kSalThreads / 64; ++i)
+      if (best_v[i] > bv || (best_v[i] == bv && best_d[i] < bd)) {
+        bv = best_v[i];
+        bd = best_d[i];
+      }
+    disp[b * 4 + k] = (bd == 0x7fffffff) ? 0 : bd;  // all-NaN objective: reference keeps 0
+  }
+}
+
+}  // namespace pcgmix
+
+extern "C" int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames, float* sal,
+                                        int ksize, double sigma, int B, int C, int T,
+                                        pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!grad || !frames || !sal) return hipErrorInvalidValue;
+  if (B < 0 || C <= 0 || T <= 0 || ksize < 1 || ksize > kMaxTaps || !(ksize & 1) || !(sigma > 0))
+    return hipErrorInvalidValue;
+  if (B == 0) return hipSuccess;
+  const size_t lds = sizeof(float) * ((size_t)2 * T + ksize - 1);
+  if (lds > 150 * 1024) return hipErrorInvalidValue;
+  // gaussian_kernel(), saliency.py:15-18: Python float64 arithmetic, then torch.FloatTensor
+  Taps taps;
+  const int half = ksize / 2;
+  for (int j = 0; j < ksize; ++j) {
+    const double xr = (double)(j - half);
+    const double w = 1.0 / (sigma * sqrt(2.0 * M_PI)) * exp(-(xr * xr) / (2.0 * (sigma * sigma)));
+    taps.w[j] = (float)w;
+  }
+  for (int j = ksize; j < kMaxTaps; ++j) taps.w[j] = 0.f;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(saliency_post_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(saliency_post_kernel, dim3((unsigned)B), dim3(kSalThreads), lds,
+                     reinterpret_cast<hipStream_t>(stream), grad, frames, sal, taps, ksize, B, C,
+                     T);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
+                                      const int32_t* mix_idx, float lam, int mode, int32_t* disp,
+                                      int B, int T, pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!sal || !frames || !mix_idx || !disp) return hipErrorInvalidValue;
+  if (B < 0 || B > 65535 || T <= 0 || (mode != 0 && mode != 1)) return hipErrorInvalidValue;
+  if (B == 0) return hipSuccess;
+  const size_t lds = sizeof(float) * (size_t)2 * T;
+  if (lds > 150 * 1024) return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(salopt_disp_kernel<0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(salopt_disp_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const float oml = 1.0f - lam;
+  dim3 grid(4, (unsigned)B), block(kSalThreads);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (mode == 0)
+    hipLaunchKernelGGL(salopt_disp_kernel<0>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
+                       disp, B, T);
+  else
+    hipLaunchKernelGGL(salopt_disp_kernel<1>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
+                       disp, B, T);
+  return (int)hipGetLastError();
+}

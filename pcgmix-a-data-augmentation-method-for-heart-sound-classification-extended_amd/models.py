@@ -1,0 +1,165 @@
+"""1D models of the PCGmix hot path, re-declared on PyTorch-ROCm with the reference's
+``state_dict`` layout so checkpoints are interchangeable.
+
+  CNN_potes     the "1D-CNN" (Potes et al.), reference models.py:367-465, factory :345-350
+  ResNet9       Myrtle ResNet9 with 1D convolutions, reference models.py:520-589
+
+Both keep the reference's ``forward(x, depth=None, pass_part=None)`` signature; the training
+loop calls ``model(data, depth=0, pass_part='second')`` (train_model.py:537), which is the plain
+full forward pass.  Convolutions run through MIOpen (MFMA paths for the ResNet9 GEMMs).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _potes_block(c_in: int, c_out: int, dropout: float = 0.0) -> nn.Sequential:
+    # Conv1d(k=5, padding=1) + ReLU + MaxPool(2) [+ Dropout]   (reference models.py:359-365)
+    layers = [nn.Conv1d(c_in, c_out, kernel_size=5, padding=1), nn.ReLU(inplace=True),
+              nn.MaxPool1d(2)]
+    if dropout:
+        layers.append(nn.Dropout(dropout))
+    return nn.Sequential(*layers)
+
+
+def potes_flat_features(sig_len: int, width: int = 4, bands: int = 4) -> int:
+    """Length of the concatenated feature vector: each band goes conv(k5,p1) -> pool2 twice."""
+    n = (sig_len - 2) // 2
+    n = (n - 2) // 2
+    return bands * width * n
+
+
+class CNN_potes(nn.Module):
+    """Four band-pass channels, each through the SAME branch ``cnn1`` (the reference allocates
+    ``cnn2..cnn4`` but never calls them, models.py:444-455; they are kept here so that
+    ``state_dict`` keys and parameter counts match — their ``.grad`` stays ``None``)."""
+
+    def __init__(self, c_in: int, c_out: int, layers, linear: int, dropout: float = 0.25):
+        super().__init__()
+        def branch():
+            return nn.Sequential(_potes_block(1, layers[0]),
+                                 _potes_block(layers[0], layers[1], dropout=dropout))
+        self.cnn1 = branch()
+        self.cnn2 = branch()
+        self.cnn3 = branch()
+        self.cnn4 = branch()
+        self.flat1 = nn.Flatten()
+        self.flat2 = nn.Flatten()
+        self.flat3 = nn.Flatten()
+        self.flat4 = nn.Flatten()
+        self.dimreduc = nn.Linear(linear, 20)
+        self.dropout = nn.Dropout(0.5)
+        self.linear = nn.Linear(20, c_out)
+
+    def features(self, x: torch.Tensor) -> torch.Tensor:
+        B, C, T = x.shape
+        # the four bands share cnn1's weights: run them as one (4B,1,T) batch, then restore the
+        # reference's concatenation order [band0 | band1 | band2 | band3] per sample
+        z = self.cnn1(x[:, :4, :].reshape(B * 4, 1, T))
+        z = z.reshape(B, -1)
+        z = F.relu(self.dimreduc(z))
+        return self.dropout(z)
+
+    def forward(self, x, depth=None, pass_part=None):
+        if pass_part == "first":
+            if depth == 0:
+                return x
+            return self.features(x)
+        if pass_part == "latent_space":
+            return self.features(x)
+        if pass_part == "second":
+            if depth <= 0:
+                x = self.features(x)
+            if depth <= 1:
+                x = self.linear(x)
+            return x
+        return self.linear(self.features(x))
+
+
+def CNN_potes_TS(num_channels: int = 4, num_classes: int = 2, dataset: str = "PhysioNet",
+                 dropout: float = 0.25, sig_len: int | None = None) -> CNN_potes:
+    """Reference factory (models.py:345-350): linear = 9968 for PhysioNet (T=2500), 7968 for UMC.
+    ``sig_len`` (an extension) sizes the head for other lengths, e.g. 5000 -> 19968."""
+    if sig_len is not None:
+        linear = potes_flat_features(sig_len)
+    elif dataset == "PhysioNet":
+        linear = 9968
+    elif dataset == "UMC":
+        linear = 7968
+    else:
+        raise ValueError(dataset)
+    return CNN_potes(c_in=num_channels, c_out=num_classes, layers=[8, 4], linear=linear,
+                     dropout=dropout)
+
+
+def _res_block(c_in: int, c_out: int, pool: bool = False) -> nn.Sequential:
+    # Conv1d(k=3,p=1) + BatchNorm1d + ReLU [+ MaxPool(2)]     (reference models.py:468-473)
+    layers = [nn.Conv1d(c_in, c_out, kernel_size=3, padding=1), nn.BatchNorm1d(c_out),
+              nn.ReLU(inplace=True)]
+    if pool:
+        layers.append(nn.MaxPool1d(2))
+    return nn.Sequential(*layers)
+
+
+class ResNet9_myrtle(nn.Module):
+    """reference models.py:520-589 (the second definition, which shadows the first)."""
+
+    def __init__(self, in_channels: int, num_classes: int, filters, linear: int):
+        super().__init__()
+        self.conv1 = _res_block(in_channels, filters[0])
+        self.conv2 = _res_block(filters[0], filters[1], pool=True)
+        self.res1 = nn.Sequential(_res_block(filters[1], filters[1]), _res_block(filters[1], filters[1]))
+        self.conv3 = _res_block(filters[1], filters[2], pool=True)
+        self.conv4 = _res_block(filters[2], filters[3], pool=True)
+        self.res2 = nn.Sequential(_res_block(filters[3], filters[3]), _res_block(filters[3], filters[3]))
+        self.pool1d = nn.MaxPool1d(4)
+        self.flat = nn.Flatten()
+        self.linear = nn.Linear(linear, num_classes)
+
+    def _stage1(self, out):
+        out = self.conv2(self.conv1(out))
+        return self.res1(out) + out
+
+    def _stage2(self, out):
+        out = self.conv4(self.conv3(out))
+        return self.res2(out) + out
+
+    def forward(self, out, depth=None, pass_part=None):
+        if pass_part == "first":
+            if depth == 0:
+                return out
+            out = self._stage1(out)
+            if depth == 1:
+                return out
+            out = self._stage2(out)
+            if depth == 2:
+                return out
+            out = self.flat(self.pool1d(out))
+            if depth == 3:
+                return out
+            return self.linear(out)
+        if pass_part == "second":
+            if depth <= 0:
+                out = self._stage1(out)
+            if depth <= 1:
+                out = self._stage2(out)
+            if depth <= 2:
+                out = self.flat(self.pool1d(out))
+            if depth <= 3:
+                out = self.linear(out)
+            return out
+        return self.linear(self.flat(self.pool1d(self._stage2(self._stage1(out)))))
+
+
+def resnet9_flat_features(sig_len: int, width: int = 512) -> int:
+    """512 channels x (T / 2 / 2 / 2 / 4) positions: 39936 at T=2500, 79872 at T=5000."""
+    return width * (sig_len // 2 // 2 // 2 // 4)
+
+
+def ResNet9(in_channels: int, num_classes: int, filters=(64, 128, 256, 512),
+            linear: int = 39936) -> ResNet9_myrtle:
+    """Reference factory, models.py:588."""
+    return ResNet9_myrtle(in_channels=in_channels, num_classes=num_classes, filters=list(filters),
+                          linear=linear)
