@@ -294,3 +294,72 @@ def ce_soft(logits: np.ndarray, target_ohe: np.ndarray) -> float:
     z = logits - logits.max(1, keepdims=True)
     logp = z - np.log(np.exp(z).sum(1, keepdims=True))
     return float((-(logp * target_ohe).sum(1)).mean())
+
+
+# --------------------------------------------------------------------------- log-mel (UNPINNED)
+# Restatement of librosa 0.9.2 as called by databuilder.ipynb cell 6:81-101, 127-142.  librosa is
+# not available offline and the reference stores no spectrogram, so NOTHING below is checked
+# against the reference's own output: "parity unpinned".  The HIP kernel is tested against this
+# restatement only.
+LOGMEL_MEAN = -59.606563568115234        # databuilder.ipynb cell 6 (train_mean, train_std)
+LOGMEL_STD = 15.96771240234375
+
+
+def _hz_to_mel(f):
+    f = np.asanyarray(f, dtype=float)
+    f_sp, min_log_hz = 200.0 / 3, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-300) / min_log_hz) / logstep,
+                    f / f_sp)
+
+
+def _mel_to_hz(m):
+    m = np.asanyarray(m, dtype=float)
+    f_sp, min_log_hz = 200.0 / 3, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
+    """librosa.filters.mel(htk=False, norm='slaney', dtype=float32)."""
+    fftfreqs = np.fft.rfftfreq(n=n_fft, d=1.0 / sr)
+    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    weights = np.zeros((n_mels, 1 + n_fft // 2), dtype=np.float32)
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        weights[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+    weights *= enorm[:, np.newaxis]
+    return weights
+
+
+def logmel(x: np.ndarray, frames: np.ndarray, n_fft=136, hop=34, n_mels=128, fmin=25.0,
+           fmax=1000.0, sr=2000.0, mean=LOGMEL_MEAN, std=LOGMEL_STD, W=128):
+    """x (B,T) float32 heart cycles, frames (B,5) -> (spec (B,n_mels,W) float32, frames_spec).
+    Per item: centred STFT (reflect padding, periodic Hann, float64 FFT rounded to complex64),
+    power, Slaney mel, power_to_db(ref=np.max over THIS item, amin 1e-10, top_db 80),
+    (x-mean)/std, keep columns < round(f4*n_frames/T), zero-fill up to W."""
+    B, T = x.shape
+    n_frames = 1 + T // hop
+    n = np.arange(n_fft)
+    window = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)
+    basis = mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    out = np.zeros((B, n_mels, W), dtype=np.float32)
+    fspec = np.zeros_like(frames)
+    for b in range(B):
+        yp = np.pad(x[b], n_fft // 2, mode="reflect")
+        idx = np.arange(n_fft)[:, None] + hop * np.arange(n_frames)[None, :]
+        S = np.fft.rfft(window[:, None] * yp[idx], axis=0).astype(np.complex64)
+        P = np.abs(S) ** 2.0
+        mel = np.einsum("ft,mf->mt", P, basis, optimize=True)
+        db = 10.0 * np.log10(np.maximum(1e-10, mel))
+        db -= 10.0 * np.log10(np.maximum(1e-10, np.max(mel)))
+        db = np.maximum(db, db.max() - 80.0)
+        db = ((db - mean) / std).astype(np.float32)
+        fspec[b] = [int(round(int(f) * n_frames / T)) for f in frames[b]]
+        c4 = min(int(fspec[b, 4]), W)
+        out[b, :, :c4] = db[:, :c4]
+    return out, fspec
