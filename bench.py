@@ -33,7 +33,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import pcgmix_amd  # noqa: E402,F401
-from pcgmix_amd import augmentations, hostprep, synthetic  # noqa: E402
+from pcgmix_amd import augmentations, hostprep, synthetic, train_model as tm  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -152,11 +152,22 @@ def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200):
 
 def cpu_baseline(method, B, C, T, rate, budget_s=12.0):
     """CPU oracle on the host cores of this box: whole batches of the benchmark workload until
-    about ``budget_s`` seconds of CPU work have been timed."""
+    about ``budget_s`` seconds of CPU work have been timed.  torch's intra-op thread count is
+    first probed (1, 8, all cores; 3 batches each) and the fastest setting is used, so the
+    baseline is not handicapped by oversubscription on tiny slice ops."""
     from oracle import pcgmix_oracle as O
     x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=rate, seed=0)
-    torch.set_num_threads(os.cpu_count() or 1)
-    O.augment(method, x, labels, frames, wav, 0)
+    ncpu = os.cpu_count() or 1
+    probe = {}
+    for nt in sorted({1, min(8, ncpu), ncpu}):
+        torch.set_num_threads(nt)
+        O.augment(method, x, labels, frames, wav, 0)
+        t0 = time.perf_counter()
+        for i in range(3):
+            O.augment(method, x, labels, frames, wav, i)
+        probe[nt] = (time.perf_counter() - t0) / 3
+    best = min(probe, key=probe.get)
+    torch.set_num_threads(best)
     n, t0 = 0, time.perf_counter()
     while True:
         O.augment(method, x, labels, frames, wav, n + 1)
@@ -164,10 +175,47 @@ def cpu_baseline(method, B, C, T, rate, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt >= budget_s or n >= 2000:
             break
-    return {"value": B * n / dt, "unit": "samples/s", "cores": torch.get_num_threads(),
-            "kind": "port", "ms_per_batch": 1e3 * dt / n,
+    return {"value": B * n / dt, "unit": "samples/s", "cores": best, "kind": "port",
+            "ms_per_batch": 1e3 * dt / n, "host_cpus": ncpu,
+            "thread_probe_ms": {str(k): 1e3 * v for k, v in probe.items()},
             "sample": f"{n} batches of {method} ({B},{C},{T}) through oracle/pcgmix_oracle.py "
                       f"(reference structure: per-sample loop of torch CPU slice ops) in {dt:.1f} s"}
+
+
+class TrainArgs:
+    def __init__(self, method, model, B, C, T, steps):
+        self.dataset, self.model, self.method = "PhysioNet", model, method
+        self.num_epochs, self.batch_size, self.op, self.use_sched = 50, B, "adam", True
+        self.lr_max, self.weight_decay, self.grad_clip, self.seed = 0.01, 1e-4, 0.1, 4
+        self.num_classes, self.num_channels, self.sig_len, self.depth = 2, C, T, 0
+        self.num_steps, self.sample_rate = steps, 2000
+
+
+def train_steps_per_s(method, model_name, B, C, T, rate, device, steps, warmup, barrier, rank):
+    """Full training step (train_model.py:498-582): augment + forward + soft CE + backward +
+    clip + Adam + OneCycleLR, batch resident in HBM, DDP gradient all-reduce when world > 1."""
+    args = TrainArgs(method, model_name, B, C, T, steps + warmup + 1)
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=rate, seed=100 + rank)
+    batch = (torch.from_numpy(x).to(device), torch.from_numpy(labels), torch.from_numpy(frames), wav,
+             torch.ones(B, dtype=torch.long), torch.arange(B))
+    torch.manual_seed(4)
+    model = tm.wrap_distributed(tm.build_model(args).to(device), device)
+    model.train()
+    opt, sched = tm.make_optimizer(args, model)
+    crit = tm.SELCLoss(labels, 2, es=args.num_epochs + 1, device=device)
+    sc = tm.step_counter_class()
+    for _ in range(warmup):
+        tm.train_step(args, model, batch, device, opt, sched, crit, 0, sc)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tm.train_step(args, model, batch, device, opt, sched, crit, 0, sc)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    return {"steps_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "loss": float(loss),
+            "model": model_name, "method": method, "batch_per_gpu": B, "shape": [B, C, T]}
 
 
 def main():
@@ -181,6 +229,7 @@ def main():
     ap.add_argument("--method", default="durratiomixup")
     ap.add_argument("--no-extra", action="store_true", help="skip secondary measurements")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-train", action="store_true", help="skip the train-step leg")
     ap.add_argument("--kernels-only", action="store_true",
                     help="only the back-to-back kernel table (diagnostic)")
     ap.add_argument("--profile-host", action="store_true",
@@ -233,7 +282,12 @@ def main():
         dt = float(t.item())
     value = world * B * a.steps / dt
 
-    kern_ms = kt.mean_ms()
+    # Kernel time for the roofline: HIP events on the launch stream around R back-to-back
+    # launches of the same kernel on this workload (the figure rocprofv3's per-kernel average
+    # agrees with).  An event PAIR around each single launch inside the steps is also recorded;
+    # it carries ~7 us of event/launch overhead and is reported as in_step_event_pair_ms.
+    kern_ms = kernel_back_to_back_ms(a.method, B, C, T, rate, device)
+    pair_ms = kt.mean_ms()
     alg_bytes = 12.0 * C * T * B                     # read own + read partner + write, fp32
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     result = {
@@ -247,17 +301,29 @@ def main():
                    "parallelism": f"dp{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "pcgmix::mix_warp_kernel<4,false>", "kernel_ms": kern_ms,
+                     "kernel": "pcgmix::mix_warp_kernel<4,false,2>", "kernel_ms": kern_ms,
+                     "in_step_event_pair_ms": pair_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "timing": "HIP events around each launch inside the timed steps"},
+                     "timing": "HIP events on the launch stream over 200 back-to-back launches"},
     }
+
+    # train step/s (second half of BASELINE.json's metric): 1D-CNN, bs 256 per GPU, DDP if N>1
+    train = None
+    if not a.no_train:
+        train = train_steps_per_s(a.method, "Potes", B, C, T, rate, device, max(20, a.steps // 4),
+                                  max(5, a.warmup // 2), barrier, rank)
+        if dist is not None:
+            t = torch.tensor([train["ms_per_step"]], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            train["ms_per_step"] = float(t.item())
+            train["steps_per_s"] = 1e3 / train["ms_per_step"]
+        train["global_batch"] = B * world
+        train["samples_per_s"] = train["steps_per_s"] * B * world
+        result["train"] = train
 
     if rank == 0 and world == 1:
         extra = {}
         if not a.no_extra:
-            b2b = kernel_back_to_back_ms(a.method, B, C, T, rate, device)
-            extra["kernel_back_to_back_ms"] = b2b
-            extra["kernel_back_to_back_GBs"] = alg_bytes / (b2b * 1e-3) / 1e9
             for tag, (m, b, c, t) in {
                 "mix_256x1x5000": ("durratiomixup", 256, 1, 5000),
                 "magwarp_256x1x5000": ("durmixmagwarp(0.2,4)", 256, 1, 5000),
@@ -276,6 +342,9 @@ def main():
             ):
                 dte, _ = run_augment_steps(m, dd, tt, ff, ww, device, a.steps, a.warmup, barrier)
                 extra[tag] = {"samples_per_s": 256 * a.steps / dte, "ms_per_step": 1e3 * dte / a.steps}
+            if not a.no_train:
+                extra["train_resnet9_1d_magwarp"] = train_steps_per_s(
+                    "durmixmagwarp(0.2,4)", "resnet9", 256, 4, 5000, rate, device, 10, 3, barrier, rank)
         result["extra"] = extra
         if not a.no_cpu:
             result["cpu_baseline"] = cpu_baseline(a.method, B, C, T, rate)

@@ -186,10 +186,16 @@ def labels_from_ohe(target_ohe: torch.Tensor) -> np.ndarray:
     return target_ohe.detach().cpu().numpy().argmax(axis=1)
 
 
-def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RESULTS_ARGS):
+def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RESULTS_ARGS,
+            host_labels=None):
     """See module docstring.  Returns ``(data, target_ohe, mix_indices, cut)``; when the method
     does not apply or the gate rejects the step, ``data`` is the very object passed in and
-    ``mix_indices`` is ``[]`` (augmentations.py:731-732, 871-872, 938-939)."""
+    ``mix_indices`` is ``[]`` (augmentations.py:731-732, 871-872, 938-939).
+
+    ``host_labels`` (extension, keyword only in spirit): the integer class labels as a host
+    array.  A training loop that still has the loader's CPU ``target`` can pass it to spare the
+    device->host read-back of ``target_ohe`` (the reference's only unavoidable sync,
+    augmentations.py:501); results are identical."""
     method = args.method
     step = int(step_counter.count)
     if hostprep.select_method(method, is2d=False) is None:
@@ -197,8 +203,8 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
     _check_data(data, 3)
     B, C, T = data.shape
     frames_np = _as_numpy_frames(frames)
-    plan = hostprep.make_plan(method, lambda: labels_from_ohe(target_ohe), frames_np, wav, step,
-                              B, C, is2d=False)
+    labels = (lambda: labels_from_ohe(target_ohe)) if host_labels is None else np.asarray(host_labels)
+    plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, C, is2d=False)
     if not plan.fired:
         return data, target_ohe, [], None
     hostprep.validate_frames(frames_np, T)

@@ -13,7 +13,8 @@ from . import hostprep
 from .augmentations import (_as_numpy_frames, _check_data, apply_plan, labels_from_ohe)
 
 
-def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RESULTS_ARGS):
+def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RESULTS_ARGS,
+            host_labels=None):
     method = args.method
     step = int(step_counter.count)
     if hostprep.select_method(method, is2d=True) is None:
@@ -23,8 +24,8 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
     _check_data(data, 4)
     B, Cc, F, W = data.shape
     frames_np = _as_numpy_frames(frames)
-    plan = hostprep.make_plan(method, lambda: labels_from_ohe(target_ohe), frames_np, wav, step,
-                              B, Cc * F, is2d=True)
+    labels = (lambda: labels_from_ohe(target_ohe)) if host_labels is None else host_labels
+    plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, Cc * F, is2d=True)
     if not plan.fired:
         return data, target_ohe, [], None
     hostprep.validate_frames(frames_np, W)

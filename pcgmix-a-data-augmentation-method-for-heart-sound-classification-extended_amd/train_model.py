@@ -1,0 +1,271 @@
+"""Per-step training path of the reference's ``train_model.py`` (train_epoch, :490-589) on
+MI355X: augment -> forward -> soft-target CE -> backward -> clip_grad_value_ -> Adam ->
+OneCycleLR, one process per GPU with DistributedDataParallel over RCCL (the reference's
+single-process ``nn.DataParallel``, train_model.py:385, is replaced).
+
+What is kept: the loss (CELoss :45-54, SELCLoss :56-80), optimiser and scheduler setup
+(:404-410), gradient value clipping (:557-558), the step counter that seeds the augmentation
+(:105-109, :581), the per-epoch reseeding of the loader shuffle (:497), and the
+``train_epoch`` signature.  What is deliberately not reproduced: the per-sample ``.item()``
+loop (:542-552) — loss and hit counts stay on the device and are read once per epoch — and the
+model zoo / plotting / pickling around the loop (out of scope).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import augmentations, augmentations2d, models, models2d
+
+SPECTROGRAM_DATASETS = ("PhysioNet(spec128)", "UMC(spec128)", "UMC(spec64)")
+
+
+class CELoss(nn.Module):
+    """Cross-entropy with soft targets: mean_b( -sum_c log_softmax(logits)[b,c] * t[b,c] )
+    (train_model.py:45-54)."""
+
+    def __init__(self, num_classes: int):
+        super().__init__()
+        self.num_classes = num_classes
+
+    def forward(self, logits, target_ohe):
+        return -(F.log_softmax(logits, dim=1) * target_ohe).sum(dim=1).mean()
+
+
+class SELCLoss(nn.Module):
+    """train_model.py:56-80.  Plain CE until epoch ``es``; afterwards the self-ensembled soft
+    labels.  With the reference's default (``es = num_epochs + 1`` unless the method contains
+    'SELC', :394-402) it is CELoss.  Soft labels live on ``device`` (the reference hard-codes
+    ``.cuda()``, :60)."""
+
+    def __init__(self, labels, num_classes: int, es: int = 10, momentum: float = 0.9,
+                 device: Optional[torch.device] = None):
+        super().__init__()
+        labels = torch.as_tensor(np.asarray(labels), dtype=torch.long)
+        soft = torch.zeros(len(labels), num_classes, dtype=torch.float)
+        soft[torch.arange(len(labels)), labels] = 1
+        self.register_buffer("soft_labels", soft.to(device) if device is not None else soft)
+        self.num_classes, self.es, self.momentum = num_classes, es, momentum
+        self.CEloss = CELoss(num_classes)
+
+    def forward(self, logits, labels, index, epoch, mode):
+        if mode == "test" or epoch <= self.es:
+            return self.CEloss(logits, labels)
+        pred = F.softmax(logits, dim=1)
+        index = torch.as_tensor(index, device=self.soft_labels.device)
+        with torch.no_grad():
+            self.soft_labels[index] = (self.momentum * self.soft_labels[index]
+                                       + (1 - self.momentum) * pred.detach())
+        return -(torch.log(pred) * self.soft_labels[index]).sum(dim=1).mean()
+
+
+class step_counter_class:
+    """train_model.py:105-109: the only source of augmentation randomness."""
+
+    def __init__(self):
+        self.count = 0
+
+    def add(self):
+        self.count += 1
+
+
+def selc_turning_point(args) -> int:
+    """train_model.py:394-402."""
+    if "SELC" in args.method and ("mixup" in args.method or "base" in args.method):
+        return int(args.num_epochs * 0.4)
+    return args.num_epochs + 1
+
+
+def build_model(args) -> nn.Module:
+    """The three models of the hot path (train_model.py:296, 338, 360), head sized for
+    ``args.sig_len`` (the reference hard-codes T = 2500)."""
+    sig_len = getattr(args, "sig_len", 2500)
+    if args.dataset in SPECTROGRAM_DATASETS:
+        if args.model != "resnet9":
+            raise NotImplementedError(args.model)
+        return models2d.ResNet9(num_classes=args.num_classes)
+    if args.model == "Potes":
+        m = models.CNN_potes_TS(num_channels=args.num_channels, num_classes=args.num_classes,
+                                dataset=args.dataset, sig_len=None if sig_len == 2500 else sig_len)
+        # cnn2..cnn4 are never called (reference models.py:444-455): their grads stay None in
+        # the reference, so Adam and the clipper skip them; freezing them is equivalent and
+        # keeps them out of the DDP reducer
+        for name in ("cnn2", "cnn3", "cnn4"):
+            for p in getattr(m, name).parameters():
+                p.requires_grad_(False)
+        return m
+    if args.model == "resnet9":
+        return models.ResNet9(in_channels=args.num_channels, num_classes=args.num_classes,
+                              linear=models.resnet9_flat_features(sig_len))
+    raise NotImplementedError(f"model {args.model!r} is outside the PCGmix hot path")
+
+
+def make_optimizer(args, model: nn.Module):
+    """train_model.py:404-410."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    if args.op == "SGD":
+        opt = torch.optim.SGD(params, lr=args.lr_max, weight_decay=args.weight_decay)
+    elif args.op == "adam":
+        opt = torch.optim.Adam(params, lr=args.lr_max, weight_decay=args.weight_decay)
+    else:
+        raise ValueError(args.op)
+    sched = None
+    if args.use_sched:
+        sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=args.lr_max,
+                                                    total_steps=args.num_steps)
+    return opt, sched
+
+
+def wrap_distributed(model: nn.Module, device: torch.device) -> nn.Module:
+    """One process per GPU; gradients are averaged by an all-reduce (RCCL over xGMI when the
+    process group is 'nccl').  The whole model fits one bucket (<= 26 MB), so the single
+    all-reduce overlaps the tail of backward.  BatchNorm statistics stay per rank, as they are
+    per replica under the reference's DataParallel."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return model
+    ids = [device.index] if device.type == "cuda" else None
+    return nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=64,
+                                               gradient_as_bucket_view=True)
+
+
+def shard_batch(batch, rank: int, world: int):
+    """Give rank r the r-th contiguous slice of every per-sample field (drop_last semantics of
+    dataloader_physionet.py:227: the remainder is dropped)."""
+    n = len(batch[0]) // world
+    sl = slice(rank * n, (rank + 1) * n)
+    return tuple(b[sl] for b in batch)
+
+
+def train_step(args, model, batch, device, optimizer, scheduler, criterion, epoch, step_counter,
+               stats: Optional[dict] = None):
+    """One iteration of the reference's batch loop (train_model.py:498-582) without host syncs.
+    ``batch`` = (data, target, frames, wav, sig_qual, indices) as the reference's loaders yield
+    it (dataloader_physionet.py:151-172).  Returns the loss tensor (on device, detached)."""
+    data, target, frames, wav, _sig_qual, indices = batch
+    data = data.to(device, non_blocking=True)
+    target_ohe = F.one_hot(target, args.num_classes).to(device, non_blocking=True)
+    aug = augmentations2d if args.dataset in SPECTROGRAM_DATASETS else augmentations
+    data, target_ohe, _, _ = aug.augment(args, data, target_ohe, frames, wav, step_counter,
+                                         model, device, None,
+                                         host_labels=target.numpy() if not target.is_cuda else None)
+    out = model(data, depth=getattr(args, "depth", 0), pass_part="second")
+    args.depth = 0
+    loss = criterion(out, target_ohe, indices, epoch, "train")
+    loss.backward()
+    if args.grad_clip:
+        nn.utils.clip_grad_value_([p for p in model.parameters() if p.grad is not None],
+                                  clip_value=args.grad_clip)
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    if scheduler is not None:
+        scheduler.step()
+    step_counter.add()
+    if stats is not None:
+        with torch.no_grad():
+            stats["loss_sum"] += loss.detach()
+            stats["hits"] += (out.argmax(1) == target_ohe.argmax(1)).sum()
+            stats["seen"] += out.shape[0]
+    return loss.detach()
+
+
+def train_epoch(args, model, train_loader, device, optimizer, scheduler, criterion, epoch,
+                step_counter, variability_counter=None, EXPERIMENT_ARGS=None):
+    """Reference signature (train_model.py:490).  Returns (mean loss, accuracy, lr per step)."""
+    model.train()
+    torch.manual_seed(args.seed * 635410 + step_counter.count)      # :497 fixes this epoch's shuffle
+    stats = {"loss_sum": torch.zeros((), device=device), "hits": torch.zeros((), device=device,
+                                                                         dtype=torch.long), "seen": 0}
+    lrs, n_batches = [], 0
+    for batch in train_loader:
+        lrs.append(optimizer.param_groups[0]["lr"])
+        train_step(args, model, batch, device, optimizer, scheduler, criterion, epoch,
+                   step_counter, stats)
+        n_batches += 1
+        if not step_counter.count < args.num_steps:                  # :584-586
+            break
+    loss = float(stats["loss_sum"]) / max(1, n_batches)              # the only host syncs
+    acc = float(stats["hits"]) / max(1, stats["seen"])
+    return loss, acc, lrs
+
+
+@torch.no_grad()
+def test_data_accuracy(args, model, test_loader, device, criterion=None):
+    """Evaluation as train_model.py:591-670: per recording, average the softmax of its heart
+    cycles and take the argmax; accuracy / sensitivity / specificity over recordings.  The
+    per-recording mean is a segmented sum on the device (index_add), not a Python dict of
+    ``.item()`` values."""
+    model.eval()
+    rec_ids: dict = {}
+    rec_label: dict = {}
+    parts = []
+    loss_sum, n = 0.0, 0
+    for data, target, _frames, wav, _sq, _idx in test_loader:
+        data = data.to(device)
+        out = model(data)
+        prob = F.softmax(out, dim=1)
+        for w, t in zip(wav, target.tolist()):
+            rec_label.setdefault(rec_ids.setdefault(w, len(rec_ids)), t)   # first cycle's label
+        ids = torch.tensor([rec_ids[w] for w in wav], device=device)
+        parts.append((ids, prob))
+        if criterion is not None:
+            loss_sum += float(criterion(out, F.one_hot(target, args.num_classes).to(device),
+                                        None, None, "test")) * len(target)
+        n += len(target)
+    R = len(rec_ids)
+    acc_p = torch.zeros(R, args.num_classes, device=device)
+    acc_n = torch.zeros(R, device=device)
+    for ids, prob in parts:
+        acc_p.index_add_(0, ids, prob)
+        acc_n.index_add_(0, ids, torch.ones_like(ids, dtype=torch.float))
+    mean_p = (acc_p / acc_n[:, None]).cpu().numpy()
+    pred = mean_p.argmax(1)
+    lab = np.asarray([rec_label[i] for i in range(R)])
+    tp = int(((pred == 1) & (lab == 1)).sum()); tn = int(((pred == 0) & (lab == 0)).sum())
+    fp = int(((pred == 1) & (lab == 0)).sum()); fn = int(((pred == 0) & (lab == 1)).sum())
+    prec = tp / max(1, tp + fp)
+    rec = tp / max(1, tp + fn)
+    # ROC-AUC of the class-1 mean probability (Mann-Whitney U with average ranks for ties)
+    auc = None
+    if 0 < lab.sum() < R:
+        score = mean_p[:, 1]
+        order = np.argsort(score, kind="mergesort")
+        ranks = np.empty(R)
+        ranks[order] = np.arange(1, R + 1)
+        for v in np.unique(score):
+            tie = score == v
+            ranks[tie] = ranks[tie].mean()
+        n1 = int(lab.sum())
+        auc = float((ranks[lab == 1].sum() - n1 * (n1 + 1) / 2) / (n1 * (R - n1)))
+    return {"accuracy": 100.0 * (tp + tn) / max(1, R), "sensitivity": 100.0 * rec,
+            "specificity": 100.0 * tn / max(1, tn + fp), "precision": prec, "recall": rec,
+            "f1": 2 * prec * rec / max(1e-12, prec + rec), "rocauc": auc, "recordings": R,
+            "loss": loss_sum / max(1, n) if criterion is not None else None}
+
+
+class SyntheticCycleLoader:
+    """Stands in for physionet_dataloader(...).run('train') (dataloader_physionet.py:204-229):
+    yields the same 6-tuple (data, target, frames, wav, sig_qual, index) of CPU tensors, shuffled
+    with torch's global generator and ``drop_last=True``, from a synthetic pool."""
+
+    def __init__(self, pool, batch_size: int):
+        self.x, self.frames, self.labels, self.wav = pool
+        self.batch_size = batch_size
+        self.dataset = range(len(self.labels))
+
+    def __len__(self):
+        return len(self.labels) // self.batch_size
+
+    def __iter__(self):
+        perm = torch.randperm(len(self.labels))
+        for i in range(len(self)):
+            idx = perm[i * self.batch_size:(i + 1) * self.batch_size]
+            ii = idx.numpy()
+            yield (torch.from_numpy(self.x[ii]), torch.from_numpy(self.labels[ii]),
+                   torch.from_numpy(self.frames[ii]), tuple(self.wav[j] for j in ii),
+                   torch.ones(len(ii), dtype=torch.long), idx)

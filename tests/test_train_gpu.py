@@ -1,0 +1,59 @@
+"""Train step on the GPU: the HIP augmentation inside the loop, host-label fast path, DDP
+wrapper degenerate case."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+import pcgmix_amd  # noqa: F401
+from pcgmix_amd import augmentations, synthetic, train_model as tm
+from conftest import Args, StepCounter
+
+pytestmark = pytest.mark.gpu
+
+
+def make_args(**kw):
+    a = argparse.Namespace(dataset="PhysioNet", model="Potes", method="durmixmagwarp(0.2,4)",
+                           num_epochs=2, batch_size=32, op="adam", use_sched=True, lr_max=0.01,
+                           weight_decay=1e-4, grad_clip=0.1, seed=4, num_classes=2, num_channels=4,
+                           sig_len=2500, depth=0, num_steps=16, sample_rate=1000)
+    a.__dict__.update(kw)
+    return a
+
+
+def test_host_labels_path_is_identical(device):
+    x, frames, labels, wav = synthetic.make_batch(32, 4, 2500, seed=4)
+    data = torch.from_numpy(x).to(device)
+    tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)
+    a = Args("durmixmagwarp(0.2,4)")
+    y1, _, m1, _ = augmentations.augment(a, data, tgt, frames, wav, StepCounter(6), None, device, "")
+    y2, _, m2, _ = augmentations.augment(a, data, tgt, frames, wav, StepCounter(6), None, device, "",
+                                         host_labels=labels)
+    assert np.array_equal(m1, m2) and torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("model,method,shape", [("Potes", "durmixmagwarp(0.2,4)", (32, 4, 2500)),
+                                                ("resnet9", "durratiomixup+0.5", (16, 4, 2500)),
+                                                ("Potes", "durratiomixup", (32, 4, 5000))])
+def test_train_epoch_on_gpu(model, method, shape, device):
+    B, C, T = shape
+    args = make_args(model=model, method=method, batch_size=B, sig_len=T, num_steps=8,
+                     sample_rate=2000 if T == 5000 else 1000)
+    pool = synthetic.make_batch(4 * B, C, T, sample_rate=args.sample_rate, seed=6)
+    loader = tm.SyntheticCycleLoader(pool, B)
+    torch.manual_seed(0)
+    net = tm.build_model(args).to(device)
+    net = tm.wrap_distributed(net, device)           # no process group: returned unchanged
+    opt, sched = tm.make_optimizer(args, net)
+    crit = tm.SELCLoss(pool[2], 2, es=args.num_epochs + 1, device=device)
+    sc = tm.step_counter_class()
+    before = [p.detach().clone() for p in net.parameters() if p.requires_grad]
+    for epoch in range(2):
+        loss, acc, lrs = tm.train_epoch(args, net, loader, device, opt, sched, crit, epoch, sc)
+        assert np.isfinite(loss) and 0.0 <= acc <= 1.0 and len(lrs) == 4
+    assert sc.count == 8
+    after = [p.detach() for p in net.parameters() if p.requires_grad]
+    assert any(not torch.equal(a, b) for a, b in zip(before, after))
+    ev = tm.test_data_accuracy(args, net, tm.SyntheticCycleLoader(pool, B), device, crit)
+    assert ev["recordings"] == len(set(pool[3]))
