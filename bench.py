@@ -218,6 +218,22 @@ def train_steps_per_s(method, model_name, B, C, T, rate, device, steps, warmup, 
             "model": model_name, "method": method, "batch_per_gpu": B, "shape": [B, C, T]}
 
 
+def measured_traffic(method, B, C, T):
+    """HBM bytes per launch of the splice kernel from the committed rocprofv3 PMC passes
+    (profiles/r*_mix_kernel_summary.json; FETCH_SIZE x2 + WRITE_SIZE, see that file) — only when
+    it was collected on exactly this workload, else None."""
+    import glob
+    want = f"{method} ({B},{C},{T}) float32"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mix_kernel_summary.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload", "").startswith(want):
+            return d["hbm_bytes_per_launch"]["total"], os.path.basename(path)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,6 +306,7 @@ def main():
     pair_ms = kt.mean_ms()
     alg_bytes = 12.0 * C * T * B                     # read own + read partner + write, fp32
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic, traffic_src = measured_traffic(a.method, B, C, T)
     result = {
         "metric": "augmented PCG samples/s", "value": value, "unit": "samples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -300,7 +317,8 @@ def main():
                    "batch_per_gpu": B, "channels": C, "sig_len": T, "method": a.method,
                    "parallelism": f"dp{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": traffic_src,
                      "kernel": "pcgmix::mix_warp_kernel<4,false,2>", "kernel_ms": kern_ms,
                      "in_step_event_pair_ms": pair_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
