@@ -257,12 +257,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # one process per GPU; the modulo only matters for rehearsals with more ranks than GPUs
+    # (PCGMIX_DIST_BACKEND=gloo on a 1-GPU box) — the driver's runs have one GPU per rank
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("PCGMIX_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if dist is not None:

@@ -177,6 +177,31 @@ int pcgmix_logmel_f32(const float* x, const int32_t* frames, float* spec, int32_
                       float fmin, float fmax, float sr, float mean, float std, int W,
                       pcgmix_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Potes 1D-CNN convolutional branch, fused.                                         [device]
+ *
+ * Replaces, for the N = 4*B band rows of a batch, CNN_potes.cnn1 (models.py:359-381, 444-455):
+ *     Conv1d(1->8,k5,pad1) + ReLU + MaxPool1d(2) -> Conv1d(8->4,k5,pad1) + ReLU + MaxPool1d(2)
+ * (the Dropout(0.25) that follows is applied by the caller).  Weight layouts are torch's:
+ * w1 (8,1,5), b1 (8), w2 (4,8,5), b2 (4).
+ *
+ *   pcgmix_potes_out_len(T)        pooled output length P2 (1248 for T = 5000, 623 for 2500)
+ *   pcgmix_potes_stack_fwd_f32     x (N,T) -> h2 (N,4,P2)
+ *   pcgmix_potes_bwd_blocks(N,T)   G = number of partial rows the backward needs
+ *   pcgmix_potes_stack_bwd_f32     x, dL/dh2 (N,4,P2) -> grads[212] = [gw1(40) | gb1(8) |
+ *                                  gw2(160) | gb2(4)]; `partial` is caller-provided scratch of
+ *                                  G*212 floats.  The forward is recomputed tile by tile; the
+ *                                  gradient w.r.t. x is NOT produced (the input is data).
+ * All pointers device; float32.
+ */
+int pcgmix_potes_out_len(int T);
+int pcgmix_potes_bwd_blocks(int N, int T);
+int pcgmix_potes_stack_fwd_f32(const float* x, const float* w1, const float* b1, const float* w2,
+                               const float* b2, float* h2, int N, int T, pcgmix_stream_t stream);
+int pcgmix_potes_stack_bwd_f32(const float* x, const float* grad_h2, const float* w1,
+                               const float* b1, const float* w2, const float* b2, float* partial,
+                               float* grads, int N, int T, pcgmix_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,10 @@ SIGNATURES = {
                                         _ptr]),
     "pcgmix_logmel_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                    _c_float, _c_float, _c_float, _c_float, _c_float, _c_int, _ptr]),
+    "pcgmix_potes_out_len": (_c_int, [_c_int]),
+    "pcgmix_potes_bwd_blocks": (_c_int, [_c_int, _c_int]),
+    "pcgmix_potes_stack_fwd_f32": (_c_int, [_ptr] * 6 + [_c_int, _c_int, _ptr]),
+    "pcgmix_potes_stack_bwd_f32": (_c_int, [_ptr] * 8 + [_c_int, _c_int, _ptr]),
 }
 
 _lib = None

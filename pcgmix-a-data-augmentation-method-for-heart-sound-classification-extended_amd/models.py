@@ -10,9 +10,53 @@ full forward pass.  Convolutions run through MIOpen (MFMA paths for the ResNet9 
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import _lib
+
+
+class PotesStackFunction(torch.autograd.Function):
+    """conv(1->8,k5,p1)+ReLU+pool2 -> conv(8->4,k5,p1)+ReLU+pool2 on (N,T) rows as ONE HIP kernel
+    forward and one (+ a 212-block reduction) backward: ``pcgmix_potes_stack_{fwd,bwd}_f32``
+    (csrc/pcgmix_potes.hip).  The backward recomputes the forward per tile from the saved input,
+    so nothing but the input row is kept for it.  No gradient is produced for the input."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        N, T = x.shape
+        lib = _lib.load()
+        P2 = lib.pcgmix_potes_out_len(T)
+        w1c, b1c, w2c, b2c = (t.detach().contiguous() for t in (w1, b1, w2, b2))
+        h2 = torch.empty((N, 4, P2), dtype=torch.float32, device=x.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(lib.pcgmix_potes_stack_fwd_f32(x.data_ptr(), w1c.data_ptr(), b1c.data_ptr(),
+                                                  w2c.data_ptr(), b2c.data_ptr(), h2.data_ptr(),
+                                                  N, T, stream), "pcgmix_potes_stack_fwd_f32")
+        ctx.save_for_backward(x, w1c, b1c, w2c, b2c)
+        return h2
+
+    @staticmethod
+    def backward(ctx, grad_h2):
+        x, w1, b1, w2, b2 = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("the fused Potes stack does not produce input gradients")
+        N, T = x.shape
+        lib = _lib.load()
+        G = lib.pcgmix_potes_bwd_blocks(N, T)
+        g = grad_h2.contiguous()
+        partial = torch.empty((G, 212), dtype=torch.float32, device=x.device)
+        grads = torch.empty(212, dtype=torch.float32, device=x.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(lib.pcgmix_potes_stack_bwd_f32(x.data_ptr(), g.data_ptr(), w1.data_ptr(),
+                                                  b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                                  partial.data_ptr(), grads.data_ptr(), N, T,
+                                                  stream), "pcgmix_potes_stack_bwd_f32")
+        return (None, grads[0:40].view(8, 1, 5), grads[40:48], grads[48:208].view(4, 8, 5),
+                grads[208:212])
 
 
 def _potes_block(c_in: int, c_out: int, dropout: float = 0.0) -> nn.Sequential:
@@ -52,12 +96,28 @@ class CNN_potes(nn.Module):
         self.dimreduc = nn.Linear(linear, 20)
         self.dropout = nn.Dropout(0.5)
         self.linear = nn.Linear(20, c_out)
+        self.fused = True       # use the fused HIP conv stack on a HIP device (see _fused)
+
+    def _fused(self, x: torch.Tensor) -> bool:
+        """The hand-written HIP stack applies to the reference configuration (layers [8,4]) on a
+        HIP device when the input itself needs no gradient (saliency maps take the torch path)."""
+        c1, c2 = self.cnn1[0][0], self.cnn1[1][0]
+        return (self.fused and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad
+                and c1.out_channels == 8 and c2.out_channels == 4 and x.shape[-1] >= 14)
 
     def features(self, x: torch.Tensor) -> torch.Tensor:
         B, C, T = x.shape
         # the four bands share cnn1's weights: run them as one (4B,1,T) batch, then restore the
         # reference's concatenation order [band0 | band1 | band2 | band3] per sample
-        z = self.cnn1(x[:, :4, :].reshape(B * 4, 1, T))
+        rows = x[:, :4, :].reshape(B * 4, T)
+        if self._fused(x):
+            c1, c2 = self.cnn1[0][0], self.cnn1[1][0]
+            z = PotesStackFunction.apply(rows.contiguous(), c1.weight, c1.bias, c2.weight, c2.bias)
+            drop = self.cnn1[1][3] if len(self.cnn1[1]) > 3 else None
+            if drop is not None:
+                z = F.dropout(z, drop.p, self.training)
+        else:
+            z = self.cnn1(rows.unsqueeze(1))
         z = z.reshape(B, -1)
         z = F.relu(self.dimreduc(z))
         return self.dropout(z)

@@ -1,0 +1,80 @@
+"""Fused Potes conv stack (HIP) against the same stack through torch/MIOpen in float32
+(a floating-point kernel: the torch fp32 path is the reference here; tolerances stated)."""
+import numpy as np
+import pytest
+import torch
+
+import pcgmix_amd  # noqa: F401
+from pcgmix_amd import models
+
+pytestmark = pytest.mark.gpu
+
+
+def make(T, device, seed=0):
+    torch.manual_seed(seed)
+    m = models.CNN_potes_TS(4, 2, "PhysioNet", sig_len=None if T == 2500 else T).to(device)
+    return m
+
+
+@pytest.mark.parametrize("B,T", [(8, 2500), (4, 5000), (3, 1037), (2, 1030), (5, 526), (2, 14), (1, 23)])
+def test_forward_matches_torch(B, T, device):
+    m = make(T, device).eval()
+    x = torch.randn(B, 4, T, device=device)
+    m.fused = True
+    y_f = m(x)
+    m.fused = False
+    y_t = m(x)
+    assert torch.allclose(y_f, y_t, rtol=1e-4, atol=1e-5), float((y_f - y_t).abs().max())
+    # the stack itself, element-wise
+    c1, c2 = m.cnn1[0][0], m.cnn1[1][0]
+    h_f = models.PotesStackFunction.apply(x.reshape(B * 4, T), c1.weight, c1.bias, c2.weight, c2.bias)
+    h_t = m.cnn1(x.reshape(B * 4, 1, T))
+    assert h_f.shape == h_t.shape
+    assert torch.allclose(h_f, h_t, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,T", [(8, 2500), (4, 5000), (3, 1037), (2, 1030), (6, 526), (2, 270), (1, 23)])
+def test_weight_gradients_match_torch(B, T, device):
+    """dL/d{w1,b1,w2,b2} of a random linear functional of the stack output (dropout off)."""
+    m = make(T, device, seed=1).eval()
+    x = torch.randn(B, 4, T, device=device)
+    c1, c2 = m.cnn1[0][0], m.cnn1[1][0]
+    params = [c1.weight, c1.bias, c2.weight, c2.bias]
+    h_t = m.cnn1(x.reshape(B * 4, 1, T))
+    r = torch.randn_like(h_t)
+    g_t = torch.autograd.grad((h_t * r).sum(), params)
+    h_f = models.PotesStackFunction.apply(x.reshape(B * 4, T), *params)
+    g_f = torch.autograd.grad((h_f * r).sum(), params)
+    for a, b, name in zip(g_f, g_t, ("w1", "b1", "w2", "b2")):
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 2e-4 * scale, (name, float((a - b).abs().max()), scale)
+
+
+def test_training_step_equivalence(device):
+    """One Adam step with the fused stack == one with the torch stack (dropout disabled)."""
+    outs = []
+    for fused in (True, False):
+        m = make(2500, device, seed=2).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        m.fused = fused
+        opt = torch.optim.Adam([p for p in m.parameters()], lr=1e-2)
+        torch.manual_seed(5)
+        x = torch.randn(16, 4, 2500, device=device)
+        t = torch.nn.functional.one_hot(torch.randint(0, 2, (16,), device=device), 2).float()
+        loss = -(torch.log_softmax(m(x), 1) * t).sum(1).mean()
+        loss.backward()
+        opt.step()
+        outs.append((float(loss), [p.detach().clone() for p in m.cnn1.parameters()] +
+                     [m.dimreduc.weight.detach().clone()]))
+    assert abs(outs[0][0] - outs[1][0]) < 1e-5
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.allclose(a, b, rtol=1e-3, atol=2e-4)   # Adam normalises: sign/ratio sensitive
+
+
+def test_input_gradient_requests_take_the_torch_path(device):
+    m = make(2500, device).eval()
+    x = torch.randn(2, 4, 2500, device=device, requires_grad=True)
+    m(x).sum().backward()                         # saliency-style use: must not raise
+    assert x.grad is not None and torch.isfinite(x.grad).all()
