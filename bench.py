@@ -191,7 +191,8 @@ class TrainArgs:
         self.num_steps, self.sample_rate = steps, 2000
 
 
-def train_steps_per_s(method, model_name, B, C, T, rate, device, steps, warmup, barrier, rank):
+def train_steps_per_s(method, model_name, B, C, T, rate, device, steps, warmup, barrier, rank,
+                      use_graph=True):
     """Full training step (train_model.py:498-582): augment + forward + soft CE + backward +
     clip + Adam + OneCycleLR, batch resident in HBM, DDP gradient all-reduce when world > 1."""
     args = TrainArgs(method, model_name, B, C, T, steps + warmup + 1)
@@ -204,18 +205,26 @@ def train_steps_per_s(method, model_name, B, C, T, rate, device, steps, warmup, 
     opt, sched = tm.make_optimizer(args, model)
     crit = tm.SELCLoss(labels, 2, es=args.num_epochs + 1, device=device)
     sc = tm.step_counter_class()
+    import torch.distributed as dist
+    graphed = use_graph and not (dist.is_available() and dist.is_initialized())
+    if graphed:
+        g = tm.GraphedTrainStep(args, model, opt, sched, crit, device, B, C, T)
+        step = lambda: g.step(batch, 0, sc)                                  # noqa: E731
+    else:
+        step = lambda: tm.train_step(args, model, batch, device, opt, sched, crit, 0, sc)  # noqa: E731
     for _ in range(warmup):
-        tm.train_step(args, model, batch, device, opt, sched, crit, 0, sc)
+        step()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = tm.train_step(args, model, batch, device, opt, sched, crit, 0, sc)
+        loss = step()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     return {"steps_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "loss": float(loss),
-            "model": model_name, "method": method, "batch_per_gpu": B, "shape": [B, C, T]}
+            "model": model_name, "method": method, "batch_per_gpu": B, "shape": [B, C, T],
+            "hipgraph": bool(graphed)}
 
 
 def measured_traffic(method, B, C, T):
@@ -337,6 +346,11 @@ def main():
     if not a.no_train:
         train = train_steps_per_s(a.method, "Potes", B, C, T, rate, device, max(20, a.steps // 4),
                                   max(5, a.warmup // 2), barrier, rank)
+        if world == 1:
+            eager = train_steps_per_s(a.method, "Potes", B, C, T, rate, device,
+                                      max(20, a.steps // 4), max(5, a.warmup // 2), barrier, rank,
+                                      use_graph=False)
+            train["eager_steps_per_s"] = eager["steps_per_s"]
         if dist is not None:
             t = torch.tensor([train["ms_per_step"]], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

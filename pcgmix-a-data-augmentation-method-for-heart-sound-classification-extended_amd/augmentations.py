@@ -30,6 +30,16 @@ from .hostprep import MixPlan
 _OP_CACHE: dict = {}      # (device index, T, n_knots) -> device tensor with the spline operator
 
 
+def _raw_stream(device: torch.device) -> int:
+    """hipStream_t of torch's current stream on ``device`` (the cheap private getter when this
+    torch build has it, the public Stream object otherwise)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    try:
+        return torch._C._cuda_getCurrentRawStream(idx)
+    except AttributeError:      # pragma: no cover
+        return torch.cuda.current_stream(device).cuda_stream
+
+
 def _as_numpy_frames(frames) -> np.ndarray:
     if isinstance(frames, torch.Tensor):
         frames = frames.detach().cpu().numpy()
@@ -89,11 +99,11 @@ class _StagingRing:
             self.bufs[i] = buf
         return i, buf
 
-    def sent(self, i: int):
+    def sent(self, i: int, stream):
         ev = self.events[i]
         if ev is None:
             ev = self.events[i] = torch.cuda.Event()
-        ev.record()
+        ev.record(stream)
 
 
 _RINGS: dict = {}
@@ -121,7 +131,7 @@ def upload_plan(plan: MixPlan, frames: np.ndarray, device: torch.device):
         buf[n_int_pad * 4:nbytes].view(np.float64)[:] = plan.knots.reshape(-1)
     dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
     dev.copy_(pinned[:nbytes], non_blocking=True)
-    ring.sent(slot)
+    ring.sent(slot, torch.cuda.current_stream(device))
     offs = {"frames": 0, "mix": B * 5 * 4, "off": B * 6 * 4 if n_off else None,
             "knots": n_int_pad * 4 if n_kn else None}
     return dev, offs
@@ -131,7 +141,7 @@ def launch_mix(data: torch.Tensor, out: torch.Tensor, frames_ptr: int, mix_ptr: 
                off_ptr: Optional[int], lam: float, knots_ptr: Optional[int],
                op_ptr: Optional[int], n_knots: int, B: int, C: int, T: int) -> None:
     lib = _lib.load()
-    stream = torch.cuda.current_stream(data.device).cuda_stream
+    stream = _raw_stream(data.device)
     err = lib.pcgmix_mix_warp_f32(data.data_ptr(), out.data_ptr(), frames_ptr, mix_ptr, off_ptr,
                                   ctypes.c_float(lam), knots_ptr, op_ptr, n_knots, B, C, T,
                                   ctypes.c_void_p(stream))
@@ -139,8 +149,10 @@ def launch_mix(data: torch.Tensor, out: torch.Tensor, frames_ptr: int, mix_ptr: 
 
 
 def apply_plan(plan: MixPlan, data: torch.Tensor, frames: np.ndarray,
-               saliency_maps: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Run the device part of a fired plan; returns the new (B,C,T) tensor."""
+               saliency_maps: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Run the device part of a fired plan; returns the new (B,C,T) tensor (``out`` if given:
+    a static buffer a captured hipGraph reads from)."""
     B, C, T = data.shape
     device = data.device
     with torch.cuda.device(device):
@@ -162,7 +174,11 @@ def apply_plan(plan: MixPlan, data: torch.Tensor, frames: np.ndarray,
             op = spline_operator(device, T, plan.n_knots)
             keep.append(op)
             knots_ptr, op_ptr = base + offs["knots"], op.data_ptr()
-        out = torch.empty_like(data)
+        if out is None:
+            out = torch.empty_like(data)
+        elif out.shape != data.shape or out.dtype != data.dtype or not out.is_contiguous() \
+                or out.data_ptr() == data.data_ptr():
+            raise ValueError("out must be a distinct contiguous tensor shaped like data")
         launch_mix(data, out, frames_ptr, mix_ptr, off_ptr, float(plan.lam32), knots_ptr, op_ptr,
                    plan.n_knots, B, C, T)
         # the small buffers are only read by work already enqueued on this stream; torch's

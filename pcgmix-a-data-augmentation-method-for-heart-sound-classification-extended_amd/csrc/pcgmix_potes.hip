@@ -64,44 +64,71 @@ __device__ __forceinline__ void stage_x(float* xs, const float* __restrict__ xro
   }
 }
 
-// Layer 1 for pooled positions q = qlo + qq, qq in [0, nq): a1s[ci][qq] (0 outside [0,P1) —
-// that IS conv2's zero padding) and, if sel != nullptr, which conv output won the pool and
-// survived the ReLU: 0 none, 1 first (i = 2q), 2 second (i = 2q+1).
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void lds_load12(const float* p, float (&v)[12]) {  // p 16-byte aligned
+  const f4 a = *reinterpret_cast<const f4*>(p), b = *reinterpret_cast<const f4*>(p + 4),
+           c = *reinterpret_cast<const f4*>(p + 8);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+}
+__device__ __forceinline__ void lds_load8(const float* p, float (&v)[8]) {  // p 16-byte aligned
+  const f4 a = *reinterpret_cast<const f4*>(p), b = *reinterpret_cast<const f4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// Layer 1 (conv 1->8 k5 + ReLU + pool 2) for pooled positions q = qlo + qq, qq in [0, nq),
+// nq % 4 == 0.  Work item = (channel, 4 consecutive qq): 12 staged inputs feed 8 conv outputs.
+// a1s[ci*nq + qq] is 0 outside [0,P1) — that IS conv2's zero padding.  If sel != nullptr it gets
+// which conv output won the pool and survived the ReLU: 0 none, 1 first (i = 2q), 2 second.
 __device__ __forceinline__ void layer1(const PotesWeights& W, const float* xs, float* a1s,
                                        uint8_t* sel, int qlo, int nq, int P1) {
-  for (int idx = threadIdx.x; idx < kC1 * nq; idx += kPotThreads) {
-    const int ci = idx / nq, qq = idx - ci * nq;
-    const int q = qlo + qq;
-    float a = 0.f;
-    uint8_t s = 0;
-    if (q >= 0 && q < P1) {
-      float za = W.b1[ci], zb = W.b1[ci];
+  const int groups = nq / 4;
+  for (int item = threadIdx.x; item < kC1 * groups; item += kPotThreads) {
+    const int ci = item / groups, g = item - ci * groups;
+    float xw[12], w[kK];
+    lds_load12(xs + 8 * g, xw);
+#pragma unroll
+    for (int k = 0; k < kK; ++k) w[k] = W.w1[ci * kK + k];
+    const float bias = W.b1[ci];
+    f4 out;
+    uint32_t sels = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float za = bias, zb = bias;
 #pragma unroll
       for (int k = 0; k < kK; ++k) {
-        za = fmaf(W.w1[ci * kK + k], xs[2 * qq + k], za);
-        zb = fmaf(W.w1[ci * kK + k], xs[2 * qq + 1 + k], zb);
+        za = fmaf(w[k], xw[2 * u + k], za);
+        zb = fmaf(w[k], xw[2 * u + 1 + k], zb);
       }
+      const int q = qlo + 4 * g + u;
       const float ra = fmaxf(za, 0.f), rb = fmaxf(zb, 0.f);
-      // torch's max-pool keeps the FIRST maximum (strict '>' scan)
-      if (rb > ra) { a = rb; s = 2; } else { a = ra; s = ra > 0.f ? 1 : 0; }
+      float a = 0.f;
+      uint32_t sc = 0;
+      if (q >= 0 && q < P1) {
+        // torch's max-pool keeps the FIRST maximum (strict '>' scan)
+        if (rb > ra) { a = rb; sc = 2; } else { a = ra; sc = ra > 0.f ? 1 : 0; }
+      }
+      out[u] = a;
+      sels |= sc << (8 * u);
     }
-    a1s[idx] = a;
-    if (sel) sel[idx] = s;
+    *reinterpret_cast<f4*>(a1s + ci * nq + 4 * g) = out;
+    if (sel) *reinterpret_cast<uint32_t*>(sel + ci * nq + 4 * g) = sels;
   }
 }
 
 // ---------------------------------------------------------------------------------- forward
-constexpr int kFwdTP = 256;                     // pooled outputs per block
-constexpr int kFwdNQ = 2 * kFwdTP + 4;
-constexpr int kFwdNX = 4 * kFwdTP + 12;
+constexpr int kFwdTP = 256;                     // pooled outputs per block (4 per lane, wave = co)
+constexpr int kFwdNQ = 2 * kFwdTP + 4;          // 516
+constexpr int kFwdNX = 4 * kFwdTP + 12;         // 1036
 
 __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ h2, int N,
     int T) {
   __shared__ PotesWeights W;
-  __shared__ float xs[kFwdNX];
-  __shared__ float a1s[kC1 * kFwdNQ];
+  __shared__ __align__(16) float xs[kFwdNX];
+  __shared__ __align__(16) float a1s[kC1 * kFwdNQ];
   const PotesDims d = potes_dims(T);
   const int n = blockIdx.y, p0 = blockIdx.x * kFwdTP;
   const int qlo = 2 * p0 - 1, xlo = 2 * qlo - 1;
@@ -110,136 +137,255 @@ __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
   __syncthreads();
   layer1(W, xs, a1s, nullptr, qlo, kFwdNQ, d.P1);
   __syncthreads();
-  const int p = p0 + threadIdx.x;
-  if (p < d.P2) {
+  // conv 8->4 k5 + ReLU + pool 2: wave = output channel, lane = 4 consecutive pooled outputs
+  const int co = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float za[4], zb[4];
 #pragma unroll
-    for (int co = 0; co < kC2; ++co) {
-      float za = W.b2[co], zb = W.b2[co];
+  for (int u = 0; u < 4; ++u) za[u] = zb[u] = W.b2[co];
 #pragma unroll
-      for (int ci = 0; ci < kC1; ++ci)
+  for (int ci = 0; ci < kC1; ++ci) {
+    float aw[12], w[kK];
+    lds_load12(a1s + ci * kFwdNQ + 8 * lane, aw);
 #pragma unroll
-        for (int k = 0; k < kK; ++k) {
-          const float w = W.w2[(co * kC1 + ci) * kK + k];
-          za = fmaf(w, a1s[ci * kFwdNQ + 2 * threadIdx.x + k], za);
-          zb = fmaf(w, a1s[ci * kFwdNQ + 2 * threadIdx.x + 1 + k], zb);
-        }
-      h2[((size_t)n * kC2 + co) * d.P2 + p] = fmaxf(fmaxf(za, 0.f), fmaxf(zb, 0.f));
-    }
+    for (int k = 0; k < kK; ++k) w[k] = W.w2[(co * kC1 + ci) * kK + k];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < kK; ++k) {
+        za[u] = fmaf(w[k], aw[2 * u + k], za[u]);
+        zb[u] = fmaf(w[k], aw[2 * u + 1 + k], zb[u]);
+      }
+  }
+  const int p = p0 + 4 * lane;
+  float* dst = h2 + ((size_t)n * kC2 + co) * d.P2 + p;
+  f4 o;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) o[u] = fmaxf(fmaxf(za[u], 0.f), fmaxf(zb[u], 0.f));
+  if (p + 3 < d.P2 && (d.P2 & 3) == 0) {
+    *reinterpret_cast<f4*>(dst) = o;
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p + u < d.P2) dst[u] = o[u];
   }
 }
 
 // ---------------------------------------------------------------------------------- backward
-constexpr int kBwdTP = 128;                     // OWNED pooled outputs per work item
-constexpr int kBwdNP = kBwdTP + 3;              // extended: p0-2 .. p0+TP
-constexpr int kBwdNJ = 2 * kBwdTP + 6;          // conv2 outputs j: 2p0-4 .. 2p0+2TP+1
-constexpr int kBwdNQ = 2 * kBwdTP + 10;         // a1 positions:   2p0-5 .. 2p0+2TP+4
-constexpr int kBwdNX = 4 * kBwdTP + 24;         // x positions:    4p0-11 .. 4p0+4TP+12
-constexpr int kBwdNI = 4 * kBwdTP;              // OWNED conv1 outputs i: 4p0 .. 4p0+4TP-1
+// Work item = (row, tile).  A tile OWNS kBwdTP pooled outputs p0 .. p0+TP-1, i.e. conv2 outputs
+// j = 2p0+s (s < 2TP), layer-1 pooled positions q = 2p0+r (r < 2TP) and conv1 outputs
+// i = 4p0+ii (ii < 4TP); every position is owned by exactly one tile.  To get the complete
+// dL/da1 of its owned q it recomputes conv2 on the extended range p0-2 .. p0+TP (128 values).
+constexpr int kBwdTP = 125;
+constexpr int kBwdNP = 128;                     // extended pooled outputs pe = p0-2+pp
+constexpr int kBwdNJ = 2 * kBwdNP;              // 256 conv2 outputs, j = 2p0-4+jj
+constexpr int kBwdNQ = 260;                     // a1 positions q = 2p0-5+qq
+constexpr int kBwdNX = 524;                     // x positions 4p0-11+u
+constexpr int kBwdNS = 2 * kBwdTP;              // 250 owned j / owned q
+constexpr int kBwdNI = 4 * kBwdTP;              // 500 owned i
+constexpr int kBwdNIpad = 512;
+constexpr int kNAcc = 53;                       // private accumulators per lane (see below)
+
+__device__ __forceinline__ int potes_bwd_tiles(const PotesDims& d) {
+  // +2: the a1 positions 2*P2 .. 2*P2+2 still receive gradient from the last pooled outputs
+  return (d.P2 + 2 + kBwdTP - 1) / kBwdTP;
+}
 
 __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gh2, const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
     float* __restrict__ partial /* gridDim.x * 212 */, int N, int T) {
   __shared__ PotesWeights W;
-  __shared__ float xs[kBwdNX];
-  __shared__ float a1s[kC1 * kBwdNQ];
-  __shared__ uint8_t sel1[kC1 * kBwdNQ];
-  __shared__ float dz2s[kC2 * kBwdNJ];
-  __shared__ float dz1s[kC1 * kBwdNI];
-  __shared__ float red[4 * kNGrad];
+  __shared__ __align__(16) float xs[kBwdNX + 4];
+  __shared__ __align__(16) float a1s[kC1 * kBwdNQ];
+  __shared__ __align__(16) uint8_t sel1[kC1 * kBwdNQ];
+  __shared__ __align__(16) float dz2s[kC2 * (kBwdNJ + 12)];   // +12: read window of the last lanes
+  __shared__ __align__(16) float dz1s[kC1 * kBwdNIpad];
+  __shared__ float red[4 * kNAcc];
+  constexpr int kDz2Row = kBwdNJ + 12;
   const PotesDims d = potes_dims(T);
-  // +2: the a1 positions 2*P2 .. 2*P2+2 still receive gradient from the last pooled outputs
-  const int tiles = (d.P2 + 2 + kBwdTP - 1) / kBwdTP;
+  const int tiles = potes_bwd_tiles(d);
   const long long work = (long long)N * tiles;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   load_weights(&W, w1, b1, w2, b2);
+  for (int i = threadIdx.x; i < kC2 * kDz2Row; i += kPotThreads) dz2s[i] = 0.f;
 
-  // gradient entry e in [0,212) is owned, for the whole kernel, by lane (e & 63) slot (e >> 6)
-  // of EVERY wave; wave w sums the w-th quarter of each tile's positions.
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // Private accumulators, reduced across lanes once at the end of the kernel:
+  //   wave w owns output channel co = w of conv2 and input channels ci = 2w, 2w+1 of conv1
+  //   acc2[ci][k] = gw2[w][ci][k] (40), accb2 = gb2[w], acc1[c][k] = gw1[2w+c][k] (10),
+  //   accb1[c] = gb1[2w+c]
+  float acc2[kC1][kK], acc1[2][kK], accb1[2] = {0.f, 0.f}, accb2 = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < kC1; ++ci)
+#pragma unroll
+    for (int k = 0; k < kK; ++k) acc2[ci][k] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int k = 0; k < kK; ++k) acc1[c][k] = 0.f;
 
   for (long long item = blockIdx.x; item < work; item += gridDim.x) {
     const int n = (int)(item / tiles), p0 = (int)(item - (long long)n * tiles) * kBwdTP;
     const int qlo = 2 * p0 - 5, xlo = 2 * qlo - 1;
     __syncthreads();  // previous item's LDS fully consumed
-    stage_x(xs, x + (size_t)n * T, xlo, kBwdNX, T);
+    stage_x(xs, x + (size_t)n * T, xlo, kBwdNX + 4, T);
     __syncthreads();
     layer1(W, xs, a1s, sel1, qlo, kBwdNQ, d.P1);
     __syncthreads();
-    // conv2 + ReLU + pool on the extended range, straight to dz2 = dL/dz2
-    for (int idx = threadIdx.x; idx < kC2 * kBwdNP; idx += kPotThreads) {
-      const int co = idx / kBwdNP, pp = idx - co * kBwdNP;
-      const int pe = p0 - 2 + pp;
-      float da = 0.f, db = 0.f;
-      if (pe >= 0 && pe < d.P2) {
-        float za = W.b2[co], zb = W.b2[co];
+    {  // conv2 + ReLU + pool on the extended range -> dz2 = dL/dz2 (wave = co, 2 pooled per lane)
+      const int co = wave;
+      float aw[8], za[2], zb[2];
+      za[0] = za[1] = zb[0] = zb[1] = W.b2[co];
 #pragma unroll
-        for (int ci = 0; ci < kC1; ++ci)
+      for (int ci = 0; ci < kC1; ++ci) {
+        float w[kK];
+        lds_load8(a1s + ci * kBwdNQ + 4 * lane, aw);
+#pragma unroll
+        for (int k = 0; k < kK; ++k) w[k] = W.w2[(co * kC1 + ci) * kK + k];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int k = 0; k < kK; ++k) {
-            const float w = W.w2[(co * kC1 + ci) * kK + k];
-            za = fmaf(w, a1s[ci * kBwdNQ + 2 * pp + k], za);
-            zb = fmaf(w, a1s[ci * kBwdNQ + 2 * pp + 1 + k], zb);
+            za[u] = fmaf(w[k], aw[2 * u + k], za[u]);
+            zb[u] = fmaf(w[k], aw[2 * u + 1 + k], zb[u]);
           }
-        const float g = gh2[((size_t)n * kC2 + co) * d.P2 + pe];
-        const float ra = fmaxf(za, 0.f), rb = fmaxf(zb, 0.f);
-        if (rb > ra) db = g; else if (ra > 0.f) da = g;
       }
-      dz2s[co * kBwdNJ + 2 * pp] = da;
-      dz2s[co * kBwdNJ + 2 * pp + 1] = db;
+      f4 dz;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int pe = p0 - 2 + 2 * lane + u;
+        float da = 0.f, db = 0.f;
+        if (pe >= 0 && pe < d.P2) {
+          const float g = gh2[((size_t)n * kC2 + co) * d.P2 + pe];
+          const float ra = fmaxf(za[u], 0.f), rb = fmaxf(zb[u], 0.f);
+          if (rb > ra) db = g; else if (ra > 0.f) da = g;
+        }
+        dz[2 * u] = da;
+        dz[2 * u + 1] = db;
+      }
+      *reinterpret_cast<f4*>(dz2s + co * kDz2Row + 4 * lane) = dz;
     }
     __syncthreads();
-    // back through conv2 to the owned a1 positions q = 2p0 + r, then pool1/ReLU1 -> dz1
-    for (int idx = threadIdx.x; idx < kC1 * 2 * kBwdTP; idx += kPotThreads) {
-      const int ci = idx / (2 * kBwdTP), r = idx - ci * (2 * kBwdTP);
-      float da1 = 0.f;
+    {  // back through conv2 to the owned a1 positions q = 2p0+r, then pool1/ReLU1 -> dz1
+       // wave w -> channels 2w, 2w+1; lane -> r0 = 4*lane .. +3
+      const int r0 = 4 * lane;
 #pragma unroll
-      for (int co = 0; co < kC2; ++co)
+      for (int c = 0; c < 2; ++c) {
+        const int ci = 2 * wave + c;
+        float da1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < kK; ++k)
-          da1 = fmaf(dz2s[co * kBwdNJ + r + 5 - k], W.w2[(co * kC1 + ci) * kK + k], da1);
-      const uint8_t s = sel1[ci * kBwdNQ + r + 5];   // 0 for q outside [0,P1)
-      dz1s[ci * kBwdNI + 2 * r] = s == 1 ? da1 : 0.f;
-      dz1s[ci * kBwdNI + 2 * r + 1] = s == 2 ? da1 : 0.f;
+        for (int co = 0; co < kC2; ++co) {
+          float dw[12], w[kK];
+          lds_load12(dz2s + co * kDz2Row + r0, dw);   // dz2 index r+5-k, r = r0+u: r0+1 .. r0+8
+#pragma unroll
+          for (int k = 0; k < kK; ++k) w[k] = W.w2[(co * kC1 + ci) * kK + k];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < kK; ++k) da1[u] = fmaf(dw[u + 5 - k], w[k], da1[u]);
+        }
+        float out[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = r0 + u;
+          const uint8_t sc = r < kBwdNS ? sel1[ci * kBwdNQ + r + 5] : 0;   // 0 outside [0,P1) too
+          out[2 * u] = sc == 1 ? da1[u] : 0.f;
+          out[2 * u + 1] = sc == 2 ? da1[u] : 0.f;
+        }
+        f4* dst = reinterpret_cast<f4*>(dz1s + ci * kBwdNIpad + 8 * lane);
+        dst[0] = f4{out[0], out[1], out[2], out[3]};
+        dst[1] = f4{out[4], out[5], out[6], out[7]};
+      }
     }
     __syncthreads();
-    // the 212 reductions; each wave takes a quarter of the owned positions
-    const int i_lo = wave * (kBwdNI / 4), i_hi = i_lo + kBwdNI / 4;          // conv1 outputs
-    const int s_lo = wave * (2 * kBwdTP / 4), s_hi = s_lo + 2 * kBwdTP / 4;  // conv2 outputs
+    {  // gw2 / gb2: wave = co, lane -> owned s0 = 4*lane .. +3 (s < 250)
+      const int co = wave, s0 = 4 * lane;
+      const f4 dv = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + s0 + 4);
+      float dd[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
-    for (int slot = 0; slot < 4; ++slot) {
-      const int e = slot * 64 + lane;
-      if (e >= kNGrad) continue;
-      float a = 0.f;
-      if (e < kNW1) {                                  // gw1[ci][k] += dz1[ci][i] * x[i-1+k]
-        const int ci = e / kK, k = e - ci * kK;
-        for (int ii = i_lo; ii < i_hi; ++ii) a = fmaf(dz1s[ci * kBwdNI + ii], xs[ii + 10 + k], a);
-      } else if (e < kNW1 + kC1) {                     // gb1[ci]
-        const int ci = e - kNW1;
-        for (int ii = i_lo; ii < i_hi; ++ii) a += dz1s[ci * kBwdNI + ii];
-      } else if (e < kNW1 + kC1 + kNW2) {              // gw2[co][ci][k] += dz2[co][j] * a1[ci][j-1+k]
-        const int f = e - kNW1 - kC1;
-        const int co = f / (kC1 * kK), ci = (f / kK) % kC1, k = f % kK;
-        for (int s = s_lo; s < s_hi; ++s)
-          a = fmaf(dz2s[co * kBwdNJ + s + 4], a1s[ci * kBwdNQ + s + 4 + k], a);
-      } else {                                         // gb2[co]
-        const int co = e - kNW1 - kC1 - kNW2;
-        for (int s = s_lo; s < s_hi; ++s) a += dz2s[co * kBwdNJ + s + 4];
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u >= kBwdNS) dd[u] = 0.f;            // computed for the halo, owned by the next tile
+      accb2 += (dd[0] + dd[1]) + (dd[2] + dd[3]);
+      if (s0 < kBwdNS) {
+#pragma unroll
+        for (int ci = 0; ci < kC1; ++ci) {
+          float aw[8];
+          lds_load8(a1s + ci * kBwdNQ + s0 + 4, aw);   // a1 index s+4+k
+#pragma unroll
+          for (int k = 0; k < kK; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc2[ci][k] = fmaf(dd[u], aw[u + k], acc2[ci][k]);
+        }
       }
-      acc[slot] += a;
+    }
+    {  // gw1 / gb1: wave w -> channels 2w, 2w+1; lane -> owned ii0 = 8*lane .. +7 (ii < 500)
+      const int ii0 = 8 * lane;
+      if (ii0 < kBwdNI) {
+        float xw[12];                                  // x index ii+10+k: ii0+10 .. ii0+21
+#pragma unroll
+        for (int u = 0; u < 12; u += 2) {
+          const float2 v = *reinterpret_cast<const float2*>(xs + ii0 + 10 + u);
+          xw[u] = v.x;
+          xw[u + 1] = v.y;
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float dd[8];
+          lds_load8(dz1s + (2 * wave + c) * kBwdNIpad + ii0, dd);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (ii0 + u >= kBwdNI) dd[u] = 0.f;
+          accb1[c] += ((dd[0] + dd[1]) + (dd[2] + dd[3])) + ((dd[4] + dd[5]) + (dd[6] + dd[7]));
+#pragma unroll
+          for (int k = 0; k < kK; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc1[c][k] = fmaf(dd[u], xw[u + k], acc1[c][k]);
+        }
+      }
     }
   }
-  // combine the four waves' quarters, one partial vector per block
-  __syncthreads();
+
+  // ---- one cross-lane reduction per kernel, then one partial vector per block ----------------
+  float flat[kNAcc];
 #pragma unroll
-  for (int slot = 0; slot < 4; ++slot) {
-    const int e = slot * 64 + lane;
-    if (e < kNGrad) red[wave * kNGrad + e] = acc[slot];
+  for (int ci = 0; ci < kC1; ++ci)
+#pragma unroll
+    for (int k = 0; k < kK; ++k) flat[ci * kK + k] = acc2[ci][k];
+  flat[40] = accb2;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int k = 0; k < kK; ++k) flat[41 + c * kK + k] = acc1[c][k];
+    flat[51 + c] = accb1[c];
+  }
+#pragma unroll
+  for (int e = 0; e < kNAcc; ++e) {
+    float v = flat[e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    flat[e] = v;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < kNGrad; e += kPotThreads)
-    partial[(size_t)blockIdx.x * kNGrad + e] =
-        (red[e] + red[kNGrad + e]) + (red[2 * kNGrad + e] + red[3 * kNGrad + e]);
+  if (lane == 0)
+#pragma unroll
+    for (int e = 0; e < kNAcc; ++e) red[wave * kNAcc + e] = flat[e];
+  __syncthreads();
+  for (int e = threadIdx.x; e < kNGrad; e += kPotThreads) {
+    float v;
+    if (e < kNW1) {                       // gw1[ci][k]
+      const int ci = e / kK, k = e - ci * kK;
+      v = red[(ci >> 1) * kNAcc + 41 + (ci & 1) * kK + k];
+    } else if (e < kNW1 + kC1) {          // gb1[ci]
+      const int ci = e - kNW1;
+      v = red[(ci >> 1) * kNAcc + 51 + (ci & 1)];
+    } else if (e < kNW1 + kC1 + kNW2) {   // gw2[co][ci][k]
+      const int f = e - kNW1 - kC1;
+      const int co = f / (kC1 * kK), rest = f - co * (kC1 * kK);
+      v = red[co * kNAcc + rest];
+    } else {                              // gb2[co]
+      v = red[(e - kNW1 - kC1 - kNW2) * kNAcc + 40];
+    }
+    partial[(size_t)blockIdx.x * kNGrad + e] = v;
+  }
 }
 
 // Sum the per-block partial vectors in a fixed order: grads[e] = sum_g partial[g][e].
@@ -268,8 +414,8 @@ extern "C" int pcgmix_potes_out_len(int T) {
 extern "C" int pcgmix_potes_bwd_blocks(int N, int T) {
   if (N <= 0 || T < 14) return 0;
   const pcgmix::PotesDims d = pcgmix::potes_dims(T);
-  const long long work = (long long)N * ((d.P2 + 2 + pcgmix::kBwdTP - 1) / pcgmix::kBwdTP);
-  return (int)(work < 1024 ? work : 1024);  // 4 persistent blocks per CU
+  const long long work = (long long)N * ((d.P2 + 2 + pcgmix::kBwdTP - 1) / pcgmix::kBwdTP);  // = tiles
+  return (int)(work < 512 ? work : 512);  // 2 persistent blocks per CU (230 VGPRs: 2 waves per SIMD)
 }
 
 extern "C" int pcgmix_potes_stack_fwd_f32(const float* x, const float* w1, const float* b1,

@@ -16,6 +16,7 @@ waveform data is touched here.
 """
 from __future__ import annotations
 
+import functools
 import random
 from dataclasses import dataclass, field
 from typing import Optional, Sequence
@@ -63,6 +64,7 @@ class MixPlan:
     mix_all: bool = False                      # '(mixAll)': targets are blended too
 
 
+@functools.lru_cache(maxsize=256)
 def select_method(method: str, is2d: bool) -> Optional[str]:
     """Which of our branches the reference's if-chain would reach, or None for passthrough.
 
@@ -83,18 +85,21 @@ def select_method(method: str, is2d: bool) -> Optional[str]:
     return hit
 
 
+@functools.lru_cache(maxsize=256)
 def parse_probability(method: str) -> float:
     """Text after the last '+' (augmentations.py:865-868)."""
     parts = method.split("+")
     return float(parts[-1]) if len(parts) > 1 else 1.0
 
 
+@functools.lru_cache(maxsize=256)
 def parse_alpha(method: str, name: str) -> float:
     """'(alpha=a)' immediately in front of the method name (augmentations.py:897-899)."""
     parts = method.split("(alpha=")
     return float(parts[1].split(")" + name)[0]) if len(parts) > 1 else 1.0
 
 
+@functools.lru_cache(maxsize=256)
 def parse_magwarp(method: str):
     """'durmixmagwarp(sigma,knot)' (augmentations.py:919-923); defaults 0.2, 4."""
     sigma, knot = 0.2, 4
@@ -169,10 +174,12 @@ def validate_frames(frames: np.ndarray, sig_len: int) -> None:
     past the padded length; refuse such input up front."""
     if frames.ndim != 2 or frames.shape[1] != 5:
         raise ValueError(f"frames must be (B, 5), got {frames.shape}")
-    if (np.diff(frames, axis=1) < 0).any() or (frames[:, 0] < 0).any():
+    if frames.size == 0:
+        return
+    if (frames[:, 1:] < frames[:, :-1]).any() or int(frames.min()) < 0:
         raise ValueError("frames must be non-decreasing and non-negative")
-    if int(frames[:, 4].max(initial=0)) > sig_len:
-        raise ValueError(f"heart cycle ends at {int(frames[:, 4].max())} > signal length {sig_len}")
+    if int(frames.max()) > sig_len:
+        raise ValueError(f"heart cycle ends at {int(frames.max())} > signal length {sig_len}")
 
 
 def make_plan(method: str, labels, frames: np.ndarray, wav: Sequence[str], step: int,

@@ -57,3 +57,35 @@ def test_train_epoch_on_gpu(model, method, shape, device):
     assert any(not torch.equal(a, b) for a, b in zip(before, after))
     ev = tm.test_data_accuracy(args, net, tm.SyntheticCycleLoader(pool, B), device, crit)
     assert ev["recordings"] == len(set(pool[3]))
+
+
+def test_graphed_step_matches_eager(device):
+    """hipGraph replay of fwd+loss+bwd+clip with eager augment/Adam == the eager train_step
+    (dropout off so both see the same network function)."""
+    results = []
+    B, C, T = 32, 4, 2500
+    pool = synthetic.make_batch(B, C, T, seed=9)
+    batch = (torch.from_numpy(pool[0]), torch.from_numpy(pool[2]), torch.from_numpy(pool[1]), pool[3],
+             torch.ones(B, dtype=torch.long), torch.arange(B))
+    for graphed in (False, True):
+        args = make_args(method="durmixmagwarp(0.2,4)+0.7", batch_size=B, num_steps=12)
+        torch.manual_seed(0)
+        net = tm.build_model(args).to(device)
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        net.train()
+        opt, sched = tm.make_optimizer(args, net)
+        crit = tm.SELCLoss(pool[2], 2, es=args.num_epochs + 1, device=device)
+        sc = tm.step_counter_class()
+        if graphed:
+            g = tm.GraphedTrainStep(args, net, opt, sched, crit, device, B, C, T)
+            losses = [float(g.step(batch, 0, sc)) for _ in range(6)]
+        else:
+            losses = [float(tm.train_step(args, net, batch, device, opt, sched, crit, 0, sc))
+                      for _ in range(6)]
+        results.append((losses, [p.detach().clone() for p in net.parameters() if p.requires_grad]))
+        assert sc.count == 6
+    assert np.allclose(results[0][0], results[1][0], rtol=1e-4, atol=1e-5), results
+    for a, b in zip(results[0][1], results[1][1]):
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-4)
