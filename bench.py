@@ -227,6 +227,92 @@ def train_steps_per_s(method, model_name, B, C, T, rate, device, steps, warmup, 
             "hipgraph": bool(graphed)}
 
 
+def potes_kernel_times(device, B=256, T=5000, iters=100):
+    """Fused Potes conv stack alone: forward and weight-gradient backward, us per launch, and
+    the HBM-roofline fraction for their algorithmic bytes (4*T + 16*P2 per band row, each)."""
+    from pcgmix_amd import models
+    N = 4 * B
+    m = models.CNN_potes_TS(4, 2, "PhysioNet", sig_len=T).to(device)
+    c1, c2 = m.cnn1[0][0], m.cnn1[1][0]
+    params = [c1.weight, c1.bias, c2.weight, c2.bias]
+    x = torch.randn(N, T, device=device)
+    out = {}
+    h = models.PotesStackFunction.apply(x, *params)
+    g = torch.randn_like(h)
+
+    def timeit(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+    with torch.no_grad():
+        out["fwd_us"] = timeit(lambda: models.PotesStackFunction.apply(x, *params))
+
+    def bwd():
+        hh = models.PotesStackFunction.apply(x, *params)
+        torch.autograd.grad((hh * g).sum(), params)
+    out["fwd_bwd_us"] = timeit(bwd)
+    nbytes = N * (4 * T + 16 * h.shape[-1])
+    out["alg_bytes_each"] = nbytes
+    out["fwd_GBs"] = nbytes / out["fwd_us"] / 1e3
+    return out
+
+
+def secondary_kernel_times(device, B=256, iters=50):
+    """The other kernels of the path at bs=256, us per launch and fraction of the HBM roofline for
+    their algorithmic bytes: log-mel 4T+4*128*128, saliency post 4CT+4T,
+    displacement scan 8T, 2D splice 12*F*W per sample."""
+    from pcgmix_amd import augmentations2d, frontend, saliency
+    out = {}
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3
+
+    def entry(us, nbytes):
+        return {"us": us, "GBs": nbytes / us / 1e3, "frac_of_8TBs": nbytes / us / 1e3 / HBM_PEAK_GBS}
+
+    T, C = 5000, 4
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=2000, seed=0)
+    data = torch.from_numpy(x).to(device)
+    fr = torch.from_numpy(frames.astype(np.int32)).to(device)
+    x1 = data[:, 0, :].contiguous()
+    out["logmel_256x5000"] = entry(timeit(lambda: frontend.logmel(x1, frames)), B * (4 * T + 4 * 128 * 128))
+    grad = torch.randn_like(data)
+    out["saliency_post_256x4x5000"] = entry(timeit(lambda: saliency.saliency_post(grad, fr.data_ptr())),
+                                            B * (4 * C * T + 4 * T))
+    sal = saliency.saliency_post(grad, fr.data_ptr())
+    mix = torch.from_numpy(np.random.RandomState(0).permutation(B).astype(np.int32)).to(device)
+    for mode, name in ((0, "env"), (1, "sum")):
+        out[f"salopt_disp_{name}_256x5000"] = entry(
+            timeit(lambda: saliency.optimal_displacements(sal, fr.data_ptr(), mix.data_ptr(), 0.37, mode, B, T)),
+            B * 8 * T)
+    spec, fs = frontend.logmel(x1, frames)
+    tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)
+    sc = StepCounter()
+    a2 = Args("durratiomixup")
+
+    def mix2d():
+        augmentations2d.augment(a2, spec, tgt, fs, wav, sc, None, device, "", host_labels=labels)
+        sc.add()
+    out["augment2d_256x1x128x128"] = entry(timeit(mix2d), B * 12 * 128 * 128)
+    return out
+
+
 def measured_traffic(method, B, C, T):
     """HBM bytes per launch of the splice kernel from the committed rocprofv3 PMC passes
     (profiles/r*_mix_kernel_summary.json; FETCH_SIZE x2 + WRITE_SIZE, see that file) — only when
@@ -286,6 +372,9 @@ def main():
 
     B, C, T, rate = a.batch, a.channels, a.sig_len, 2000
     if a.kernels_only:
+        print("potes:", potes_kernel_times(device), flush=True)
+        for k, v in secondary_kernel_times(device).items():
+            print(f"{k:32s} {v['us']:9.1f} us  {v['GBs']:8.1f} GB/s", flush=True)
         for m, b, c, t in (("durratiomixup", 256, 1, 5000), ("durratiomixup", 256, 4, 5000),
                            ("durmixmagwarp(0.2,4)", 256, 1, 5000), ("durmixmagwarp(0.2,4)", 256, 4, 5000),
                            ("durratiomixup", 4096, 4, 5000), ("durmixmagwarp(0.2,4)", 4096, 4, 5000),
@@ -381,6 +470,8 @@ def main():
             ):
                 dte, _ = run_augment_steps(m, dd, tt, ff, ww, device, a.steps, a.warmup, barrier)
                 extra[tag] = {"samples_per_s": 256 * a.steps / dte, "ms_per_step": 1e3 * dte / a.steps}
+            extra["potes_stack"] = potes_kernel_times(device)
+            extra["secondary_kernels"] = secondary_kernel_times(device)
             if not a.no_train:
                 extra["train_resnet9_1d_magwarp"] = train_steps_per_s(
                     "durmixmagwarp(0.2,4)", "resnet9", 256, 4, 5000, rate, device, 10, 3, barrier, rank)

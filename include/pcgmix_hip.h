@@ -158,24 +158,31 @@ int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames, const int32_
                            pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * Log-mel front end.                                                              [device]
+ * Log-mel front end.                                                    [host tables + device]
  *
  * Replaces the offline librosa pipeline of databuilder.ipynb cell 6:19-23, 81-101, 127-142
  * (melspectrogram -> power_to_db(ref=max) -> (x-mean)/std -> crop to the cycle -> zero-pad
- * to W columns) per heart cycle, on device.  librosa 0.9.2 semantics restated (centered
- * frames with reflect padding, periodic Hann of n_fft, power 2, Slaney mel scale and
+ * to W columns) per heart cycle, on device.  librosa 0.9.2 semantics restated (centred frames
+ * with reflect padding, periodic Hann of n_fft, float64 transform, power 2, Slaney mel scale and
  * normalisation, amin 1e-10, top_db 80); parity with librosa itself is unpinned.
+ *
+ * pcgmix_logmel_tables builds, on the host, everything that does not depend on the data: the
+ * windowed DFT matrix in matrix-core operand order, the mel filter bank and each filter's
+ * non-zero span (pcgmix_logmel_tables_size bytes).  The caller copies that blob to the device
+ * once and passes it to every pcgmix_logmel_f32 call with the same (n_fft, n_mels).
  *
  *   x           device, (B, T) one channel per row
  *   frames      device, int32 (B, 5) waveform boundaries; columns >= round(f4 * n_frames / T)
  *               are zero-filled after normalisation
+ *   tables      device, the blob above
  *   spec        device, (B, n_mels, W) out
  *   frames_out  device, int32 (B, 5) out or NULL: boundaries in spectrogram columns
  */
-int pcgmix_logmel_f32(const float* x, const int32_t* frames, float* spec, int32_t* frames_out,
-                      int B, int T, int n_fft, int hop, int n_mels,
-                      float fmin, float fmax, float sr, float mean, float std, int W,
-                      pcgmix_stream_t stream);
+long long pcgmix_logmel_tables_size(int n_fft, int n_mels);
+int pcgmix_logmel_tables(int n_fft, int n_mels, float fmin, float fmax, float sr, void* out /* host */);
+int pcgmix_logmel_f32(const float* x, const int32_t* frames, const void* tables, float* spec,
+                      int32_t* frames_out, int B, int T, int n_fft, int hop, int n_mels,
+                      float mean, float std, int W, pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Potes 1D-CNN convolutional branch, fused.                                         [device]

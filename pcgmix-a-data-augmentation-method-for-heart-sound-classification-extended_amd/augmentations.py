@@ -109,6 +109,21 @@ class _StagingRing:
 _RINGS: dict = {}
 
 
+def upload_array(arr: np.ndarray, device: torch.device) -> torch.Tensor:
+    """Async H2D copy of a small host array through the pinned staging ring (never synchronises
+    the stream, unlike ``torch.from_numpy(a).to(device)`` from pageable memory).  Must be called
+    with ``device`` current.  Returns a device tensor of arr's dtype and shape."""
+    arr = np.ascontiguousarray(arr)
+    nbytes = arr.nbytes
+    ring = _RINGS.setdefault(device.index, _StagingRing())
+    slot, pinned = ring.stage(max(nbytes, 1))
+    pinned.numpy()[:nbytes] = arr.reshape(-1).view(np.uint8)
+    dev = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+    dev.copy_(pinned[:max(nbytes, 1)], non_blocking=True)
+    ring.sent(slot, torch.cuda.current_stream(device))
+    return dev[:nbytes].view(torch.from_numpy(arr[:0].reshape(-1)).dtype).view(arr.shape)
+
+
 def upload_plan(plan: MixPlan, frames: np.ndarray, device: torch.device):
     """One async H2D copy with every small per-step array: int32 frames (B,5) | mix (B) |
     offsets (B,4, optional) | float64 knots (optional).  Returns (device buffer, byte offsets).

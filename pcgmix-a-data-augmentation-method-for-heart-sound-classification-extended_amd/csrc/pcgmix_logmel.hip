@@ -8,12 +8,20 @@
 // amin = 1e-10 and top_db = 80.  One difference is inherent to doing this per batch item: `ref`
 // is the maximum over the item's own spectrogram, not over the whole recording.
 //
-// One block per sample.  LDS holds the reflect-padded row, the DFT twiddles, the mel filter
-// bank and the whole (n_mels x W) dB image, so the input is read from HBM once and the output is
-// written once, in full 512-byte rows: 4*T + 4*n_mels*W algorithmic bytes per sample.
+// The STFT is a GEMM,  S[(re|im, bin)][frame] = sum_k (win[k] tw(bin k)) x[frame*hop + k],
+// M = 2*bins, N = frames, K = n_fft, and librosa evaluates it in float64 — so it runs on the f64
+// matrix cores (v_mfma_f64_16x16x4_f64).  Everything that does not depend on the data (the
+// windowed twiddle matrix already in MFMA A-fragment order, the mel filter bank, each filter's
+// non-zero span) is a constant table built once on the host (pcgmix_logmel_tables) and read
+// through L2.  One block per sample; LDS holds the reflect-padded row, the power spectrogram and
+// the whole dB image, so HBM sees the input once and the output once:
+// 4*T + 4*n_mels*W algorithmic bytes per sample.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+
+#include <cmath>
+#include <vector>
 
 #include "pcgmix_kernels.h"
 
@@ -21,133 +29,140 @@ namespace pcgmix {
 
 constexpr int kMelThreads = 256;
 constexpr int kMelWaves = kMelThreads / 64;
+constexpr int kNGroup = 5;  // 16-frame tiles accumulated together by one wave (5 x v4f64 = 40 regs)
 
-// librosa.hz_to_mel / mel_to_hz, htk=False (Slaney): linear below 1 kHz, log above.
-__device__ __forceinline__ double hz_to_mel(double f) {
-  const double f_sp = 200.0 / 3, min_log_hz = 1000.0;
-  const double min_log_mel = (min_log_hz - 0.0) / f_sp, logstep = log(6.4) / 27.0;
-  return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : (f - 0.0) / f_sp;
-}
-__device__ __forceinline__ double mel_to_hz(double m) {
-  const double f_sp = 200.0 / 3, min_log_hz = 1000.0;
-  const double min_log_mel = (min_log_hz - 0.0) / f_sp, logstep = log(6.4) / 27.0;
-  return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : 0.0 + f_sp * m;
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ---- constant tables (host-built blob) ---------------------------------------------------------
+//   [0]                 double afrag[m_tiles][ksteps][64]   A operand, one double per lane:
+//                       lane l -> row r = l & 15, k = 4*ks + (l >> 4);
+//                       row r = (component (r>>2)&1 : 0 re, 1 im ; bin 8*mt + (r&3) + 4*(r>>3))
+//                       value = win[k] * cos(2 pi bin k / n_fft)  or  -win[k] * sin(...),
+//                       0 for padded bins / k >= n_fft
+//   [off_wts]           float  wts[n_mels][n_bins]           librosa.filters.mel, slaney, float32
+//   [off_krange]        int32  krange[n_mels][2]             first / last non-zero bin
+struct MelTables {
+  int m_tiles, ksteps, n_bins;
+  size_t off_wts, off_krange, total;
+};
+__host__ __device__ inline MelTables mel_tables(int n_fft, int n_mels) {
+  MelTables t;
+  t.n_bins = n_fft / 2 + 1;
+  t.m_tiles = (t.n_bins + 7) / 8;
+  t.ksteps = (n_fft + 3) / 4;
+  size_t o = (size_t)t.m_tiles * t.ksteps * 64 * sizeof(double);
+  t.off_wts = o;
+  o += (size_t)n_mels * t.n_bins * sizeof(float);
+  o = (o + 7) & ~(size_t)7;
+  t.off_krange = o;
+  o += (size_t)n_mels * 2 * sizeof(int32_t);
+  t.total = (o + 15) & ~(size_t)15;
+  return t;
 }
 
 struct MelLayout {  // byte offsets into dynamic LDS
-  int xrow, tw, win, xw, melf, wts, pw, img, total;
+  int xrow, ps, img, total;
+  int nfp, xr;
 };
-
-__host__ __device__ inline MelLayout mel_layout(int T, int n_fft, int n_mels, int W) {
-  const int n_bins = n_fft / 2 + 1;
+__host__ __device__ inline MelLayout mel_layout(int T, int n_fft, int hop, int n_mels, int W) {
+  const MelTables tb = mel_tables(n_fft, n_mels);
+  const int n_frames = 1 + T / hop;
   MelLayout L;
+  L.nfp = ((n_frames + 16 * kNGroup - 1) / (16 * kNGroup)) * (16 * kNGroup);  // frames, padded
+  L.xr = (L.nfp - 1) * hop + 4 * tb.ksteps;  // padded-row samples the GEMM may touch
+  if (L.xr < T + n_fft) L.xr = T + n_fft;
+  L.xr = (L.xr + 3) & ~3;
   int o = 0;
-  L.tw = o;   o += 2 * n_fft * 8;                 // cos, sin of 2*pi*j/n_fft      (double)
-  L.win = o;  o += n_fft * 8;                     // periodic Hann                 (double)
-  L.xw = o;   o += kMelWaves * n_fft * 8;         // windowed frame, one per wave  (double)
-  L.melf = o; o += (n_mels + 2) * 8;              // mel band edges in Hz          (double)
-  L.xrow = o; o += (T + n_fft) * 4;               // reflect-padded waveform       (float)
-  L.wts = o;  o += n_mels * n_bins * 4;           // filter bank                   (float)
-  L.pw = o;   o += kMelWaves * n_bins * 4;        // power spectrum, one per wave  (float)
-  L.img = o;  o += n_mels * W * 4;                // dB image                      (float)
+  L.xrow = o; o += L.xr * 4;                    // reflect-padded waveform, zero beyond (float)
+  L.ps = o;   o += tb.m_tiles * 8 * L.nfp * 4;  // power spectrogram [bin][frame]        (float)
+  L.img = o;  o += n_mels * W * 4;              // dB image                              (float)
   L.total = o;
   return L;
 }
 
 __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
-    const float* __restrict__ x, const int32_t* __restrict__ frames, float* __restrict__ spec,
-    int32_t* __restrict__ frames_out, int B, int T, int n_fft, int hop, int n_mels, float f_lo,
-    float f_hi, float sr, float mean, float stdv, int W) {
+    const float* __restrict__ x, const int32_t* __restrict__ frames,
+    const unsigned char* __restrict__ tables, float* __restrict__ spec,
+    int32_t* __restrict__ frames_out, int B, int T, int n_fft, int hop, int n_mels, float mean,
+    float stdv, int W) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ float red[kMelWaves];
-  const MelLayout L = mel_layout(T, n_fft, n_mels, W);
-  double* tw = reinterpret_cast<double*>(smem + L.tw);
-  double* win = reinterpret_cast<double*>(smem + L.win);
-  double* xw_all = reinterpret_cast<double*>(smem + L.xw);
-  double* melf = reinterpret_cast<double*>(smem + L.melf);
+  const MelTables tb = mel_tables(n_fft, n_mels);
+  const MelLayout L = mel_layout(T, n_fft, hop, n_mels, W);
+  const double* afrag = reinterpret_cast<const double*>(tables);
+  const float* wts = reinterpret_cast<const float*>(tables + tb.off_wts);
+  const int32_t* krange = reinterpret_cast<const int32_t*>(tables + tb.off_krange);
   float* xrow = reinterpret_cast<float*>(smem + L.xrow);
-  float* wts = reinterpret_cast<float*>(smem + L.wts);
-  float* pw_all = reinterpret_cast<float*>(smem + L.pw);
+  float* ps = reinterpret_cast<float*>(smem + L.ps);
   float* img = reinterpret_cast<float*>(smem + L.img);
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_bins = n_fft / 2 + 1, pad = n_fft / 2;
+  const int n_bins = tb.n_bins, pad = n_fft / 2;
   const int n_frames = 1 + T / hop;  // centred: 1 + (T + 2*pad - n_fft) / hop
 
-  // ---- tables ---------------------------------------------------------------------------------
-  for (int j = tid; j < n_fft; j += kMelThreads) {
-    double s, c;
-    sincospi(2.0 * (double)j / (double)n_fft, &s, &c);
-    tw[2 * j] = c;
-    tw[2 * j + 1] = s;
-    win[j] = 0.5 - 0.5 * c;  // scipy.signal.get_window('hann', n_fft, fftbins=True)
+  // reflect-padded row (numpy.pad mode='reflect': the edge sample is not repeated), zero beyond
+  for (int i = tid; i < L.xr; i += kMelThreads) {
+    float v = 0.f;
+    if (i < T + n_fft) {
+      int s = i - pad;
+      if (s < 0) s = -s;
+      if (s >= T) s = 2 * (T - 1) - s;
+      s = s < 0 ? 0 : (s >= T ? T - 1 : s);
+      v = x[(size_t)b * T + s];
+    }
+    xrow[i] = v;
   }
-  for (int i = tid; i < n_mels + 2; i += kMelThreads) {
-    // librosa.mel_frequencies: linspace in mel between hz_to_mel(fmin) and hz_to_mel(fmax)
-    const double m0 = hz_to_mel((double)f_lo), m1 = hz_to_mel((double)f_hi);
-    const double step = (m1 - m0) / (double)(n_mels + 1);
-    const double m = (i == n_mels + 1) ? m1 : m0 + (double)i * step;
-    melf[i] = mel_to_hz(m);
-  }
-  // reflect-padded row (numpy.pad mode='reflect': the edge sample is not repeated)
-  for (int i = tid; i < T + n_fft; i += kMelThreads) {
-    int s = i - pad;
-    if (s < 0) s = -s;
-    if (s >= T) s = 2 * (T - 1) - s;
-    s = s < 0 ? 0 : (s >= T ? T - 1 : s);
-    xrow[i] = x[(size_t)b * T + s];
-  }
-  __syncthreads();
-  // librosa.filters.mel(norm='slaney', dtype=float32)
-  const double fft_step = 1.0 / ((double)n_fft * (1.0 / (double)sr));  // np.fft.rfftfreq
-  for (int i = tid; i < n_mels * n_bins; i += kMelThreads) {
-    const int m = i / n_bins, k = i - m * n_bins;
-    const double f = (double)k * fft_step;
-    const double lower = -(melf[m] - f) / (melf[m + 1] - melf[m]);
-    const double upper = (melf[m + 2] - f) / (melf[m + 2] - melf[m + 1]);
-    const float w = (float)fmax(0.0, fmin(lower, upper));
-    const double enorm = 2.0 / (melf[m + 2] - melf[m]);
-    wts[i] = (float)((double)w * enorm);
-  }
-  for (int i = tid; i < n_mels * W; i += kMelThreads) img[i] = 0.f;
   __syncthreads();
 
-  // ---- one wave per STFT frame ----------------------------------------------------------------
-  double* xw = xw_all + wave * n_fft;
-  float* pw = pw_all + wave * n_bins;
-  float vmax = -INFINITY;  // max over the item of 10*log10(max(amin, S))
-  for (int t0 = 0; t0 < n_frames; t0 += kMelWaves) {  // uniform trip count: barriers inside
-    const int t = t0 + wave;
-    const bool active = t < n_frames;
-    if (active)
-      for (int n = lane; n < n_fft; n += 64) xw[n] = win[n] * (double)xrow[t * hop + n];
-    __syncthreads();
-    if (active)
-      for (int k = lane; k < n_bins; k += 64) {
-        double re = 0.0, im = 0.0;
-        int idx = 0;
-        for (int n = 0; n < n_fft; ++n) {
-          const double v = xw[n];
-          re = fma(v, tw[2 * idx], re);
-          im = fma(-v, tw[2 * idx + 1], im);
-          idx += k;
-          idx = idx >= n_fft ? idx - n_fft : idx;
-        }
-        const float fr = (float)re, fi = (float)im;  // complex64, as librosa stores the STFT
-        const float mag = hypotf(fr, fi);            // np.abs(complex64)
-        pw[k] = mag * mag;                           // ** 2
+  // ---- STFT power on the f64 matrix cores -----------------------------------------------------
+  // C layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4*reg, col = lane&15, so lane
+  // (g = lane>>4, col) ends up with reg0/1 = re/im of bin 8mt+g and reg2/3 = re/im of bin 8mt+g+4
+  // of frame col: |.|^2 needs no cross-lane traffic.
+  const int n_groups = L.nfp / (16 * kNGroup);
+  const int r = lane & 15, kq = lane >> 4;
+  for (int unit = wave; unit < tb.m_tiles * n_groups; unit += kMelWaves) {
+    const int mt = unit / n_groups, ng = unit - mt * n_groups;
+    d4 acc[kNGroup];
+#pragma unroll
+    for (int i = 0; i < kNGroup; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    const double* ap = afrag + (size_t)mt * tb.ksteps * 64 + lane;  // coalesced 512 B per k-step
+    const float* xb = xrow + (16 * kNGroup * ng + r) * hop + kq;    // B[k][n] = x[n*hop + k]
+    double a_next = ap[0];
+    for (int ks = 0; ks < tb.ksteps; ++ks) {
+      const double a = a_next;
+      if (ks + 1 < tb.ksteps) a_next = ap[(size_t)(ks + 1) * 64];
+      double bv[kNGroup];
+#pragma unroll
+      for (int i = 0; i < kNGroup; ++i) bv[i] = (double)xb[(16 * i) * hop + 4 * ks];
+#pragma unroll
+      for (int i = 0; i < kNGroup; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[i], acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < kNGroup; ++i) {
+      const int fcol = 16 * (kNGroup * ng + i) + r;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float fr = (float)acc[i][2 * h], fi = (float)acc[i][2 * h + 1];  // complex64
+        const float mag = hypotf(fr, fi);                                       // np.abs
+        ps[(8 * mt + kq + 4 * h) * L.nfp + fcol] = mag * mag;                   // ** 2
       }
-    __syncthreads();
-    if (active)
-      for (int m = lane; m < n_mels; m += 64) {
-        float acc = 0.f;
-        for (int k = 0; k < n_bins; ++k) acc = fmaf(wts[m * n_bins + k], pw[k], acc);
-        const float db = 10.0f * log10f(fmaxf(1e-10f, acc));  // power_to_db, amin = 1e-10
-        vmax = fmaxf(vmax, db);
-        if (t < W) img[m * W + t] = db;
-      }
+    }
   }
-  // item maximum (ref = np.max): wave shuffle, then across the block's waves
+  __syncthreads();
+
+  // ---- mel projection, dB, item maximum --------------------------------------------------------
+  float vmax = -INFINITY;  // max over the item of 10*log10(max(amin, S)), all n_frames columns
+  for (int i = tid; i < n_mels * L.nfp; i += kMelThreads) {
+    const int m = i / L.nfp, t = i - m * L.nfp;
+    if (t >= n_frames) continue;
+    float accm = 0.f;
+    const int klo = krange[2 * m], khi = krange[2 * m + 1];
+    for (int k = klo; k <= khi; ++k) accm = fmaf(wts[m * n_bins + k], ps[k * L.nfp + t], accm);
+    const float db = 10.0f * log10f(fmaxf(1e-10f, accm));  // power_to_db, amin = 1e-10
+    vmax = fmaxf(vmax, db);
+    if (t < W) img[m * W + t] = db;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
   if (lane == 0) red[wave] = vmax;
@@ -163,6 +178,7 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
     const double v = (double)((long long)f4 * n_frames) / (double)T;
     const int c4 = (int)rint(v);
     col_end = c4 < 0 ? 0 : (c4 > W ? W : c4);
+    if (col_end > n_frames) col_end = n_frames;
     if (frames_out && tid < 5) {
       const double vv = (double)((long long)frames[b * 5 + tid] * n_frames) / (double)T;
       frames_out[b * 5 + tid] = (int)rint(vv);
@@ -170,30 +186,105 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   }
   // log_spec = db - ref_db; its maximum is (ref_db - ref_db) = 0, so top_db clips at -80
   const float floor_db = (ref_db - ref_db) - 80.0f;
-  for (int i = tid; i < n_mels * W; i += kMelThreads) {
+  float* out = spec + (size_t)b * n_mels * W;
+  for (int i = tid; i < n_mels * W; i += kMelThreads) {  // coalesced rows of the image
     const int t = i % W;
     float v = 0.f;  // zero padding is applied AFTER normalisation (cell 6:99, 141-142)
     if (t < col_end) {
       v = fmaxf(img[i] - ref_db, floor_db);
       v = (v - mean) / stdv;
     }
-    spec[(size_t)b * n_mels * W + i] = v;
+    out[i] = v;
   }
+}
+
+// librosa.hz_to_mel / mel_to_hz, htk=False (Slaney): linear below 1 kHz, log above.
+static double hz_to_mel(double f) {
+  const double f_sp = 200.0 / 3, min_log_hz = 1000.0;
+  const double min_log_mel = (min_log_hz - 0.0) / f_sp, logstep = std::log(6.4) / 27.0;
+  return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : (f - 0.0) / f_sp;
+}
+static double mel_to_hz(double m) {
+  const double f_sp = 200.0 / 3, min_log_hz = 1000.0;
+  const double min_log_mel = (min_log_hz - 0.0) / f_sp, logstep = std::log(6.4) / 27.0;
+  return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : 0.0 + f_sp * m;
 }
 
 }  // namespace pcgmix
 
-extern "C" int pcgmix_logmel_f32(const float* x, const int32_t* frames, float* spec,
-                                 int32_t* frames_out, int B, int T, int n_fft, int hop,
-                                 int n_mels, float fmin, float fmax, float sr, float mean,
-                                 float std, int W, pcgmix_stream_t stream) {
+extern "C" long long pcgmix_logmel_tables_size(int n_fft, int n_mels) {
+  if (n_fft < 2 || (n_fft & 1) || n_mels < 1) return 0;
+  return (long long)pcgmix::mel_tables(n_fft, n_mels).total;
+}
+
+extern "C" int pcgmix_logmel_tables(int n_fft, int n_mels, float fmin, float fmax, float sr,
+                                    void* out) {
   using namespace pcgmix;
-  if (!x || !frames || !spec) return hipErrorInvalidValue;
+  if (!out || n_fft < 2 || (n_fft & 1) || n_mels < 1 || !(fmax > fmin) || !(sr > 0))
+    return hipErrorInvalidValue;
+  const MelTables tb = mel_tables(n_fft, n_mels);
+  unsigned char* base = static_cast<unsigned char*>(out);
+  // periodic Hann (scipy.signal.get_window('hann', n_fft, fftbins=True)) and twiddles
+  std::vector<double> win(n_fft), cs(n_fft), sn(n_fft);
+  for (int j = 0; j < n_fft; ++j) {
+    const double ang = 2.0 * M_PI * (double)j / (double)n_fft;
+    cs[j] = std::cos(ang);
+    sn[j] = std::sin(ang);
+    win[j] = 0.5 - 0.5 * cs[j];
+  }
+  double* afrag = reinterpret_cast<double*>(base);
+  for (int mt = 0; mt < tb.m_tiles; ++mt)
+    for (int ks = 0; ks < tb.ksteps; ++ks)
+      for (int l = 0; l < 64; ++l) {
+        const int r = l & 15, k = 4 * ks + (l >> 4);
+        const int bin = 8 * mt + (r & 3) + 4 * (r >> 3), comp = (r >> 2) & 1;
+        double v = 0.0;
+        if (bin < tb.n_bins && k < n_fft) {
+          const int idx = (int)(((long long)bin * k) % n_fft);
+          v = comp ? -win[k] * sn[idx] : win[k] * cs[idx];
+        }
+        afrag[((size_t)mt * tb.ksteps + ks) * 64 + l] = v;
+      }
+  // librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax, htk=False, norm='slaney', dtype=float32)
+  std::vector<double> melf(n_mels + 2);
+  const double m0 = hz_to_mel((double)fmin), m1 = hz_to_mel((double)fmax);
+  const double step = (m1 - m0) / (double)(n_mels + 1);  // numpy.linspace
+  for (int i = 0; i < n_mels + 2; ++i) melf[i] = mel_to_hz(i == n_mels + 1 ? m1 : m0 + i * step);
+  const double fft_step = 1.0 / ((double)n_fft * (1.0 / (double)sr));  // np.fft.rfftfreq
+  float* wts = reinterpret_cast<float*>(base + tb.off_wts);
+  int32_t* krange = reinterpret_cast<int32_t*>(base + tb.off_krange);
+  for (int m = 0; m < n_mels; ++m) {
+    int lo = tb.n_bins, hi = -1;
+    const double enorm = 2.0 / (melf[m + 2] - melf[m]);
+    for (int k = 0; k < tb.n_bins; ++k) {
+      const double f = (double)k * fft_step;
+      const double lower = -(melf[m] - f) / (melf[m + 1] - melf[m]);
+      const double upper = (melf[m + 2] - f) / (melf[m + 2] - melf[m + 1]);
+      const float w = (float)std::fmax(0.0, std::fmin(lower, upper));  // float32 weights array
+      const float wn = (float)((double)w * enorm);                     // weights *= enorm
+      wts[(size_t)m * tb.n_bins + k] = wn;
+      if (wn != 0.f) {
+        lo = k < lo ? k : lo;
+        hi = k;
+      }
+    }
+    krange[2 * m] = lo;
+    krange[2 * m + 1] = hi;
+  }
+  return hipSuccess;
+}
+
+extern "C" int pcgmix_logmel_f32(const float* x, const int32_t* frames, const void* tables,
+                                 float* spec, int32_t* frames_out, int B, int T, int n_fft,
+                                 int hop, int n_mels, float mean, float std, int W,
+                                 pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!x || !frames || !tables || !spec) return hipErrorInvalidValue;
   if (B < 0 || T < 2 || n_fft < 2 || (n_fft & 1) || hop < 1 || n_mels < 1 || W < 1 ||
-      !(fmax > fmin) || !(sr > 0) || !(std != 0.f) || n_fft / 2 >= T)
+      !(std != 0.f) || n_fft / 2 >= T)
     return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
-  const MelLayout L = mel_layout(T, n_fft, n_mels, W);
+  const MelLayout L = mel_layout(T, n_fft, hop, n_mels, W);
   if (L.total > 158 * 1024) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
@@ -203,7 +294,8 @@ extern "C" int pcgmix_logmel_f32(const float* x, const int32_t* frames, float* s
     attr_set = true;
   }
   hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)B), dim3(kMelThreads), (size_t)L.total,
-                     reinterpret_cast<hipStream_t>(stream), x, frames, spec, frames_out, B, T,
-                     n_fft, hop, n_mels, fmin, fmax, sr, mean, std, W);
+                     reinterpret_cast<hipStream_t>(stream), x, frames,
+                     static_cast<const unsigned char*>(tables), spec, frames_out, B, T, n_fft, hop,
+                     n_mels, mean, std, W);
   return (int)hipGetLastError();
 }

@@ -223,11 +223,40 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
 #pragma unroll
     for (int k = 0; k < kK; ++k) acc1[c][k] = 0.f;
 
+  // Software prefetch: the global loads of item k+1 (its x window and this lane's two output
+  // gradients) are issued while item k is being processed, so that the ~2 us HBM/L2 latency is
+  // not paid twice per item with only two resident blocks per CU.
+  constexpr int kXPer = (kBwdNX + 4 + kPotThreads - 1) / kPotThreads;   // 3
+  float xr[kXPer], gr[2];
+  auto prefetch = [&](long long it) {
+    const int n = (int)(it / tiles), p0 = (int)(it - (long long)n * tiles) * kBwdTP;
+    const int xlo = 2 * (2 * p0 - 5) - 1;
+    const float* xrow = x + (size_t)n * T;
+#pragma unroll
+    for (int j = 0; j < kXPer; ++j) {
+      const int u = threadIdx.x + j * kPotThreads, g = xlo + u;
+      xr[j] = (u < kBwdNX + 4 && g >= 0 && g < T) ? xrow[g] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pe = p0 - 2 + 2 * lane + u;
+      gr[u] = (pe >= 0 && pe < d.P2) ? gh2[((size_t)n * kC2 + wave) * d.P2 + pe] : 0.f;
+    }
+  };
+  if ((long long)blockIdx.x < work) prefetch(blockIdx.x);
+
   for (long long item = blockIdx.x; item < work; item += gridDim.x) {
     const int n = (int)(item / tiles), p0 = (int)(item - (long long)n * tiles) * kBwdTP;
-    const int qlo = 2 * p0 - 5, xlo = 2 * qlo - 1;
+    const int qlo = 2 * p0 - 5;
+    (void)n;
     __syncthreads();  // previous item's LDS fully consumed
-    stage_x(xs, x + (size_t)n * T, xlo, kBwdNX + 4, T);
+#pragma unroll
+    for (int j = 0; j < kXPer; ++j) {
+      const int u = threadIdx.x + j * kPotThreads;
+      if (u < kBwdNX + 4) xs[u] = xr[j];
+    }
+    const float g_cur[2] = {gr[0], gr[1]};
+    if (item + gridDim.x < work) prefetch(item + gridDim.x);
     __syncthreads();
     layer1(W, xs, a1s, sel1, qlo, kBwdNQ, d.P1);
     __syncthreads();
@@ -255,7 +284,7 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
         const int pe = p0 - 2 + 2 * lane + u;
         float da = 0.f, db = 0.f;
         if (pe >= 0 && pe < d.P2) {
-          const float g = gh2[((size_t)n * kC2 + co) * d.P2 + pe];
+          const float g = g_cur[u];
           const float ra = fmaxf(za[u], 0.f), rb = fmaxf(zb[u], 0.f);
           if (rb > ra) db = g; else if (ra > 0.f) da = g;
         }
@@ -415,7 +444,7 @@ extern "C" int pcgmix_potes_bwd_blocks(int N, int T) {
   if (N <= 0 || T < 14) return 0;
   const pcgmix::PotesDims d = pcgmix::potes_dims(T);
   const long long work = (long long)N * ((d.P2 + 2 + pcgmix::kBwdTP - 1) / pcgmix::kBwdTP);  // = tiles
-  return (int)(work < 512 ? work : 512);  // 2 persistent blocks per CU (230 VGPRs: 2 waves per SIMD)
+  return (int)(work < 512 ? work : 512);  // 2 persistent blocks per CU (236 VGPRs: 2 waves per SIMD)
 }
 
 extern "C" int pcgmix_potes_stack_fwd_f32(const float* x, const float* w1, const float* b1,

@@ -116,50 +116,53 @@ __device__ __forceinline__ float pw_leaf(F elem, int start, int n) {
   return res;
 }
 
+// The split tree is walked without a memory stack: a node is (depth, path bits) and its range is
+// recomputed from the root (<= kPwDepth steps, negligible next to a 128-element leaf); the left
+// sums waiting for their right sibling live in a register array accessed by compare-select, so
+// nothing goes to scratch.  kPwDepth = 8 covers n <= 128 * 2^8 = 32768 (T is capped at 19000).
+constexpr int kPwDepth = 8;
+
+__device__ __forceinline__ int pw_split(int n) {
+  int n2 = n / 2;
+  return n2 - (n2 % 8);
+}
+
 template <class F>
-__device__ float pw_sum(F elem, int n) {
+__device__ __forceinline__ float pw_sum(F elem, int n) {
   if (n <= 128) return pw_leaf(elem, 0, n);
-  // explicit post-order walk of the split tree (depth <= log2(n/64) < 32)
-  int st_start[32], st_n[32];
-  float st_left[32];
-  unsigned have_left = 0;  // bit sp: the node at depth sp already holds its left sum
-  int sp = 0;
-  st_start[0] = 0;
-  st_n[0] = n;
-  float ret = 0.f;
-  bool returning = false;
-  while (sp >= 0) {
-    if (!returning) {
-      const int cn = st_n[sp];
-      if (cn <= 128) {
-        ret = pw_leaf(elem, st_start[sp], cn);
-        returning = true;
-        --sp;
-      } else {  // descend into the left child
-        int n2 = cn / 2;
-        n2 -= n2 % 8;
-        have_left &= ~(1u << sp);
-        st_start[sp + 1] = st_start[sp];
-        st_n[sp + 1] = n2;
-        ++sp;
+  float left[kPwDepth];
+#pragma unroll
+  for (int l = 0; l < kPwDepth; ++l) left[l] = 0.f;
+  int depth = 0;
+  unsigned path = 0;  // bit l: at depth l+1 we are in the RIGHT child
+  for (;;) {
+    int start = 0, cn = n;  // range of node (depth, path)
+    for (int l = 0; l < depth; ++l) {
+      const int n2 = pw_split(cn);
+      if (path & (1u << l)) { start += n2; cn -= n2; } else { cn = n2; }
+    }
+    if (cn > 128 && depth < kPwDepth) {  // descend left
+      path &= ~(1u << depth);
+      ++depth;
+      continue;
+    }
+    float v = pw_leaf(elem, start, cn);
+    for (;;) {  // climb
+      if (depth == 0) return v;
+      const int lvl = depth - 1;
+      if (!(path & (1u << lvl))) {  // left child done: park it, go to the right sibling
+#pragma unroll
+        for (int l = 0; l < kPwDepth; ++l) left[l] = (l == lvl) ? v : left[l];
+        path |= 1u << lvl;
+        break;
       }
-    } else {
-      if (!(have_left & (1u << sp))) {  // left done -> right child
-        st_left[sp] = ret;
-        have_left |= 1u << sp;
-        int n2 = st_n[sp] / 2;
-        n2 -= n2 % 8;
-        st_start[sp + 1] = st_start[sp] + n2;
-        st_n[sp + 1] = st_n[sp] - n2;
-        ++sp;
-        returning = false;
-      } else {  // both done
-        ret = __fadd_rn(st_left[sp], ret);
-        --sp;
-      }
+      float lv = 0.f;  // right child done: combine with the parked left sum
+#pragma unroll
+      for (int l = 0; l < kPwDepth; ++l) lv = (l == lvl) ? left[l] : lv;
+      v = __fadd_rn(lv, v);
+      depth = lvl;
     }
   }
-  return ret;
 }
 
 // One block per (state k, sample b); candidates d are strided over the lanes.

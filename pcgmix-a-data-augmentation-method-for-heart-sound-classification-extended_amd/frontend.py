@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .augmentations import _raw_stream, upload_array
 
 SPEC_LEN_S = 2.2                         # databuilder.ipynb cell 6:19
 SPEC_FRAMES = 128                        # cell 6:22
@@ -37,6 +38,25 @@ def spec_frames(frames: np.ndarray, sig_len: int, hop: int) -> np.ndarray:
     return np.rint(v).astype(np.int64)
 
 
+_TABLES: dict = {}     # (device index, n_fft, n_mels, fmin, fmax, sr) -> device blob
+
+
+def logmel_tables(device: torch.device, n_fft: int, n_mels: int, sample_rate: float) -> torch.Tensor:
+    """Constant tables of the transform (windowed DFT matrix in MFMA operand order, Slaney filter
+    bank, filter spans), built on the host by ``pcgmix_logmel_tables`` and kept on ``device``."""
+    key = (device.index, n_fft, n_mels, FMIN, FMAX, float(sample_rate))
+    blob = _TABLES.get(key)
+    if blob is None:
+        lib = _lib.load()
+        host = np.zeros(lib.pcgmix_logmel_tables_size(n_fft, n_mels), dtype=np.uint8)
+        _lib.check(lib.pcgmix_logmel_tables(n_fft, n_mels, ctypes.c_float(FMIN), ctypes.c_float(FMAX),
+                                            ctypes.c_float(sample_rate), host.ctypes.data),
+                   "pcgmix_logmel_tables")
+        blob = torch.from_numpy(host).to(device)
+        _TABLES[key] = blob
+    return blob
+
+
 def logmel(x: torch.Tensor, frames, sample_rate: int = 2000, n_mels: int = SPEC_FRAMES,
            width: int = SPEC_FRAMES, mean: float = TRAIN_MEAN, std: float = TRAIN_STD):
     """x: float32 device tensor (B, T) or (B, 1, T); frames: (B,5) host boundaries.
@@ -52,12 +72,12 @@ def logmel(x: torch.Tensor, frames, sample_rate: int = 2000, n_mels: int = SPEC_
     n_fft, hop = stft_params(sample_rate)
     lib = _lib.load()
     with torch.cuda.device(x.device):
-        fr = torch.from_numpy(np.ascontiguousarray(frames_np, dtype=np.int32)).to(x.device)
+        tables = logmel_tables(x.device, n_fft, n_mels, sample_rate)
+        fr = upload_array(frames_np.astype(np.int32), x.device)
         spec = torch.empty((B, 1, n_mels, width), dtype=torch.float32, device=x.device)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(lib.pcgmix_logmel_f32(x.data_ptr(), fr.data_ptr(), spec.data_ptr(), None, B, T,
-                                         n_fft, hop, n_mels, ctypes.c_float(FMIN),
-                                         ctypes.c_float(FMAX), ctypes.c_float(sample_rate),
+        stream = _raw_stream(x.device)
+        _lib.check(lib.pcgmix_logmel_f32(x.data_ptr(), fr.data_ptr(), tables.data_ptr(),
+                                         spec.data_ptr(), None, B, T, n_fft, hop, n_mels,
                                          ctypes.c_float(mean), ctypes.c_float(std), width,
                                          ctypes.c_void_p(stream)), "pcgmix_logmel_f32")
     return spec, spec_frames(frames_np, T, hop)

@@ -128,7 +128,8 @@ def get_saliency_maps(args, device, data, target_ohe, frames, dim=1, gauss_k_n=1
     model = model_sal or _INJECTED or _baseline_model(args, data.device, dim)
     frames_np = frames.detach().cpu().numpy() if isinstance(frames, torch.Tensor) else np.asarray(frames)
     with torch.cuda.device(data.device):
-        fr = torch.from_numpy(np.ascontiguousarray(frames_np, dtype=np.int32)).to(data.device)
+        from .augmentations import upload_array
+        fr = upload_array(frames_np.astype(np.int32), data.device)
         grad = input_gradient(model, data, target_ohe)
         return saliency_post(grad, fr.data_ptr(), gauss_k_n)
 
