@@ -313,6 +313,68 @@ def secondary_kernel_times(device, B=256, iters=50):
     return out
 
 
+def cfg3_salopt(device, steps=30, warmup=5, B=256, C=4, T=5000):
+    """BASELINE.json configs[2]: (saloptenv)durmixmagwarp(0.2,4) — saliency from a frozen copy of
+    the 1D-CNN (one fwd+bwd through torch), then the three HIP kernels (saliency post-processing,
+    displacement search, splice+warp) with no host round trip in between."""
+    from pcgmix_amd import models, saliency
+    method = "(saloptenv)durmixmagwarp(0.2,4)"
+    _, data, tgt, frames, labels, wav = make_device_batch(B, C, T, 2000, 7, device)
+    torch.manual_seed(4)
+    saliency.set_saliency_model(models.CNN_potes_TS(4, 2, "PhysioNet", sig_len=T).to(device))
+    try:
+        dt, _ = run_augment_steps(method, data, tgt, frames, wav, device, steps, warmup, lambda: None)
+    finally:
+        saliency.set_saliency_model(None)
+    return {"method": method, "shape": [B, C, T], "samples_per_s": B * steps / dt,
+            "ms_per_step": 1e3 * dt / steps, "saliency_model": "CNN_potes (frozen copy)"}
+
+
+def cfg4_spectrogram(device, steps=8, warmup=2, B=256, T=5000):
+    """BASELINE.json configs[3]: waveform (256,1,5000) -> HIP log-mel (256,1,128,128) -> 2D
+    durratiomixup on the spectrogram columns -> ResNet9-2D train step (MIOpen convolutions)."""
+    from pcgmix_amd import augmentations2d, frontend
+    x, frames, labels, wav = synthetic.make_batch(B, 1, T, sample_rate=2000, seed=3)
+    wave = torch.from_numpy(x).to(device)
+    args = TrainArgs("durratiomixup", "resnet9", B, 1, T, steps + warmup + 1)
+    args.dataset = "PhysioNet(spec128)"
+    torch.manual_seed(4)
+    model = tm.build_model(args).to(device).train()
+    opt, sched = tm.make_optimizer(args, model)
+    crit = tm.SELCLoss(labels, 2, es=args.num_epochs + 1, device=device)
+    sc = tm.step_counter_class()
+    target = torch.from_numpy(labels)
+
+    def step():
+        spec, fspec = frontend.logmel(wave, frames)
+        batch = (spec, target, torch.from_numpy(fspec), wav, None, torch.arange(B))
+        return tm.train_step(args, model, batch, device, opt, sched, crit, 0, sc)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the front end + 2D splice alone
+    a2, sc2 = Args("durratiomixup"), StepCounter()
+    tgt = torch.nn.functional.one_hot(target, 2).to(device)
+    for _ in range(3):
+        spec, fspec = frontend.logmel(wave, frames)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(50):
+        spec, fspec = frontend.logmel(wave, frames)
+        augmentations2d.augment(a2, spec, tgt, fspec, wav, sc2, None, device, "", host_labels=labels)
+        sc2.add()
+    torch.cuda.synchronize()
+    dfe = (time.perf_counter() - t1) / 50
+    return {"steps_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "loss": float(loss),
+            "model": "ResNet9-2D", "shape": [B, 1, 128, 128],
+            "frontend_plus_mix_ms": 1e3 * dfe, "frontend_plus_mix_samples_per_s": B / dfe}
+
+
 def measured_traffic(method, B, C, T):
     """HBM bytes per launch of the splice kernel from the committed rocprofv3 PMC passes
     (profiles/r*_mix_kernel_summary.json; FETCH_SIZE x2 + WRITE_SIZE, see that file) — only when
@@ -472,7 +534,9 @@ def main():
                 extra[tag] = {"samples_per_s": 256 * a.steps / dte, "ms_per_step": 1e3 * dte / a.steps}
             extra["potes_stack"] = potes_kernel_times(device)
             extra["secondary_kernels"] = secondary_kernel_times(device)
+            extra["cfg3_salopt"] = cfg3_salopt(device)
             if not a.no_train:
+                extra["cfg4_spectrogram"] = cfg4_spectrogram(device)
                 extra["train_resnet9_1d_magwarp"] = train_steps_per_s(
                     "durmixmagwarp(0.2,4)", "resnet9", 256, 4, 5000, rate, device, 10, 3, barrier, rank)
         result["extra"] = extra

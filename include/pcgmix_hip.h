@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 1
+#define PCGMIX_ABI_VERSION 2
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -93,6 +93,7 @@ int64_t pcgmix_py_randint0(uint64_t seed, int64_t hi);
  *   magnitude_warp + its D2H/H2D round trip   augmentations.py:674-683, 924-928
  *   augmentations2d.mixup_keepdur_multidim_tensors  augmentations2d.py:206-221 (call with
  *                                             C = F rows, T = W columns of the spectrogram)
+ *   the 2D mask loops                         augmentations2d.py:320-323, 355-358, 393 (zero_rect)
  *
  * For sample b with partner m = mix_idx[b], heart state k = 0..3:
  *     len1 = frames[b][k+1]-frames[b][k],  len2 = frames[m][k+1]-frames[m][k],  n = min(len1,len2)
@@ -113,11 +114,16 @@ int64_t pcgmix_py_randint0(uint64_t seed, int64_t hi);
  *   off         device, int32 (B, 4) >= 0, or NULL
  *   knots       device, float64 (B, n_knots, C) exactly as numpy.random.normal fills it, or NULL
  *   spline_op   device, float64 (pcgmix_spline_operator_size(n_knots)); required iff knots
+ *   zero_rect   device, int32 (B, 4) = [row0, row1, col0, col1) per sample, or NULL: outputs with
+ *               row0 <= c < row1 and col0 <= t < col1 are written as 0 — the masks that
+ *               durmixcutout / durmixtimemask / durmixfreqmask apply after the 2D splice
+ *               (augmentations2d.py:309-323, 348-358, 384-394)
  */
 int pcgmix_mix_warp_f32(const float* x, float* y,
                         const int32_t* frames, const int32_t* mix_idx, const int32_t* off,
                         float lam,
                         const double* knots, const double* spline_op, int n_knots,
+                        const int32_t* zero_rect,
                         int B, int C, int T, pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

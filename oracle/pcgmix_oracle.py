@@ -30,6 +30,7 @@ import torch
 from scipy.interpolate import CubicSpline
 
 PCGMIX_METHODS = ("durmixmagwarp", "durratiomixup")
+PCGMIX_METHODS_2D = ("durmixcutout", "durmixtimemask", "durmixfreqmask", "durratiomixup")
 
 
 # --------------------------------------------------------------------------- parsing
@@ -251,7 +252,8 @@ def augment(method: str, x: np.ndarray, labels: np.ndarray, frames: np.ndarray, 
     res = dict(y=x, target=target, mix=np.zeros(0, np.int64), fired=False, lam=float("nan"),
                knots=np.zeros(0), disp=None)
     is2d = x.ndim == 4
-    names = ("durratiomixup",) if is2d else PCGMIX_METHODS        # no magwarp in 2D (:269-281)
+    # 2D dispatch order: augmentations2d.py:286 (cutout), :325 (timemask), :361 (freqmask), :397
+    names = PCGMIX_METHODS_2D if is2d else PCGMIX_METHODS
     name = next((m for m in names if m in method), None)           # dispatch order :864,:931
     if name is None or not gate_fires(method, step):
         return res
@@ -279,6 +281,8 @@ def augment(method: str, x: np.ndarray, labels: np.ndarray, frames: np.ndarray, 
         target = (t * lt + t[mix] * (1 - lt)).numpy()
     knots = np.zeros(0)
     y = y.numpy()
+    if is2d and name != "durratiomixup":
+        y = mask_2d(y, frames, method, name, step)
     if name == "durmixmagwarp":                                       # :919-928
         sigma, knot = parse_magwarp(method)
         y, knots = magnitude_warp(np.transpose(y, (0, 2, 1)), sigma, knot, return_knots=True)
@@ -286,6 +290,45 @@ def augment(method: str, x: np.ndarray, labels: np.ndarray, frames: np.ndarray, 
     res.update(y=y, target=target, mix=mix, fired=True, lam=lam64, knots=knots,
                disp=disp if "(salopt" in method else None)
     return res
+
+
+def mask_2d(y: np.ndarray, frames: np.ndarray, method: str, name: str, step: int) -> np.ndarray:
+    """Zeroed rectangle after the 2D splice: durmixcutout / durmixtimemask / durmixfreqmask,
+    augmentations2d.py:309-323, 348-358, 384-394.  Region sizes come from
+    Random(step+131071).uniform, positions from Random(step+13119).uniform; the time span is a
+    fraction of each sample's own cycle length, the frequency span is the same for the batch."""
+    F = y.shape[2]
+
+    def clamp01(v):
+        return min(max(v, 0), 1)
+    t_max = f_max = 0.2
+    key = name[len("durmix"):] + "("
+    if len(method.split(key)) > 1:
+        if name == "durmixcutout":
+            t_max = clamp01(float(method.split(key)[1].split(",")[0]))
+            f_max = clamp01(float(method.split(",")[1].split(")")[0]))
+        else:
+            t_max = f_max = clamp01(float(method.split(key)[1].split(")")[0]))
+    y = y.copy()
+    if name in ("durmixcutout", "durmixtimemask"):
+        gap = random.Random(step + 131071).uniform(0, t_max)
+        frac1 = random.Random(step + 13119).uniform(0, 1 - gap)
+        frac2 = frac1 + gap
+    if name in ("durmixcutout", "durmixfreqmask"):
+        fgap = random.Random(step + 131071).uniform(0, f_max)
+        h1 = int(F * random.Random(step + 13119).uniform(0, 1 - fgap))
+        h2 = min(F, h1 + int(fgap * F))
+    for i in range(y.shape[0]):
+        beat = frames[i][-1]
+        if name == "durmixfreqmask":
+            y[i, :, h1:h2, :] = 0
+        else:
+            c0, c1 = int(frac1 * beat), int(frac2 * beat)
+            if name == "durmixtimemask":
+                y[i, :, :, c0:c1] = 0
+            else:
+                y[i, :, h1:h2, c0:c1] = 0
+    return y
 
 
 # --------------------------------------------------------------------------- loss

@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -28,7 +28,7 @@ SIGNATURES = {
     "pcgmix_py_uniform01": (ctypes.c_double, [ctypes.c_uint64]),
     "pcgmix_py_randint0": (ctypes.c_int64, [ctypes.c_uint64, ctypes.c_int64]),
     "pcgmix_mix_warp_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _ptr, _ptr, _c_int,
-                                     _c_int, _c_int, _c_int, _ptr]),
+                                     _ptr, _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_saliency_post_f32": (_c_int, [_ptr, _ptr, _ptr, _c_int, ctypes.c_double, _c_int, _c_int,
                                           _c_int, _ptr]),
     "pcgmix_salopt_disp_f32": (_c_int, [_ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _c_int, _c_int,

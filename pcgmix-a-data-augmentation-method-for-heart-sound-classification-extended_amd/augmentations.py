@@ -126,11 +126,12 @@ def upload_array(arr: np.ndarray, device: torch.device) -> torch.Tensor:
 
 def upload_plan(plan: MixPlan, frames: np.ndarray, device: torch.device):
     """One async H2D copy with every small per-step array: int32 frames (B,5) | mix (B) |
-    offsets (B,4, optional) | float64 knots (optional).  Returns (device buffer, byte offsets).
+    offsets (B,4, optional) | zero rectangles (B,4, optional) | float64 knots (optional).  Returns (device buffer, byte offsets).
     Must be called with ``device`` current."""
     B = frames.shape[0]
     n_off = B * 4 if plan.rand_off is not None else 0
-    n_int = B * 5 + B + n_off
+    n_rect = B * 4 if plan.zero_rect is not None else 0
+    n_int = B * 5 + B + n_off + n_rect
     n_int_pad = (n_int + 1) & ~1                      # keep the float64 block 8-byte aligned
     n_kn = plan.knots.size if plan.knots is not None else 0
     nbytes = n_int_pad * 4 + n_kn * 8
@@ -142,24 +143,28 @@ def upload_plan(plan: MixPlan, frames: np.ndarray, device: torch.device):
     ints[B * 5:B * 6] = plan.mix
     if n_off:
         ints[B * 6:B * 6 + n_off] = plan.rand_off.reshape(-1)
+    if n_rect:
+        ints[B * 6 + n_off:B * 6 + n_off + n_rect] = plan.zero_rect.reshape(-1)
     if n_kn:
         buf[n_int_pad * 4:nbytes].view(np.float64)[:] = plan.knots.reshape(-1)
     dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
     dev.copy_(pinned[:nbytes], non_blocking=True)
     ring.sent(slot, torch.cuda.current_stream(device))
     offs = {"frames": 0, "mix": B * 5 * 4, "off": B * 6 * 4 if n_off else None,
+            "rect": (B * 6 + n_off) * 4 if n_rect else None,
             "knots": n_int_pad * 4 if n_kn else None}
     return dev, offs
 
 
 def launch_mix(data: torch.Tensor, out: torch.Tensor, frames_ptr: int, mix_ptr: int,
                off_ptr: Optional[int], lam: float, knots_ptr: Optional[int],
-               op_ptr: Optional[int], n_knots: int, B: int, C: int, T: int) -> None:
+               op_ptr: Optional[int], n_knots: int, B: int, C: int, T: int,
+               rect_ptr: Optional[int] = None) -> None:
     lib = _lib.load()
     stream = _raw_stream(data.device)
     err = lib.pcgmix_mix_warp_f32(data.data_ptr(), out.data_ptr(), frames_ptr, mix_ptr, off_ptr,
-                                  ctypes.c_float(lam), knots_ptr, op_ptr, n_knots, B, C, T,
-                                  ctypes.c_void_p(stream))
+                                  ctypes.c_float(lam), knots_ptr, op_ptr, n_knots, rect_ptr,
+                                  B, C, T, ctypes.c_void_p(stream))
     _lib.check(err, "pcgmix_mix_warp_f32")
 
 
@@ -170,6 +175,8 @@ def apply_plan(plan: MixPlan, data: torch.Tensor, frames: np.ndarray,
     a static buffer a captured hipGraph reads from)."""
     B, C, T = data.shape
     device = data.device
+    if B == 0:                        # nothing to launch (and an empty tensor has no storage)
+        return torch.empty_like(data) if out is None else out
     with torch.cuda.device(device):
         dev, offs = upload_plan(plan, frames, device)
         base = dev.data_ptr()
@@ -194,8 +201,9 @@ def apply_plan(plan: MixPlan, data: torch.Tensor, frames: np.ndarray,
         elif out.shape != data.shape or out.dtype != data.dtype or not out.is_contiguous() \
                 or out.data_ptr() == data.data_ptr():
             raise ValueError("out must be a distinct contiguous tensor shaped like data")
+        rect_ptr = base + offs["rect"] if offs["rect"] is not None else None
         launch_mix(data, out, frames_ptr, mix_ptr, off_ptr, float(plan.lam32), knots_ptr, op_ptr,
-                   plan.n_knots, B, C, T)
+                   plan.n_knots, B, C, T, rect_ptr)
         # the small buffers are only read by work already enqueued on this stream; torch's
         # caching allocator reuses them in stream order, so dropping the references is safe
         del keep

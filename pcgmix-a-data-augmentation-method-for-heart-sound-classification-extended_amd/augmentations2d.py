@@ -1,6 +1,10 @@
 """Drop-in replacement for the PCGmix branch of the reference's ``augmentations2d.augment``
 (augmentations2d.py:267, ``durratiomixup`` branch :397-427; called from train_model.py:505).
 
+Also the mask variants ``durmixcutout(t,f)``, ``durmixtimemask(t)``, ``durmixfreqmask(f)``
+(augmentations2d.py:286-395): the same splice followed by a zeroed rectangle, fused into the same
+kernel launch as one extra predicate.
+
 Spectrogram batches are (B, 1, F, W); the four heart states are ranges of the last (time)
 axis and ``frames`` holds their boundaries in spectrogram columns.  The splice is the 1D one
 applied to every frequency row, so the same kernel runs with C = F rows and T = W columns
@@ -25,7 +29,7 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
     B, Cc, F, W = data.shape
     frames_np = _as_numpy_frames(frames)
     labels = (lambda: labels_from_ohe(target_ohe)) if host_labels is None else host_labels
-    plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, Cc * F, is2d=True)
+    plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, Cc * F, is2d=True, n_cols=W)
     if not plan.fired:
         return data, target_ohe, [], None
     hostprep.validate_frames(frames_np, W)

@@ -138,8 +138,8 @@ template <int VEC, bool WARP, int U>
 __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
     const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ frames,
     const int32_t* __restrict__ mix_idx, const int32_t* __restrict__ off, float lam, float oml,
-    const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots, int B,
-    int C, int T, int epb) {
+    const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots,
+    const int32_t* __restrict__ zero_rect, int B, int C, int T, int epb) {
   extern __shared__ __align__(16) double lds[];  // spline records per channel, then thresholds
 
   const int b = blockIdx.z * kBatchPerGridZ + blockIdx.y;
@@ -147,6 +147,14 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
   int m = mix_idx[b];
   m = (m < 0 || m >= B) ? b : m;  // memory safety; validated on the host as well
   const StateMap sm = make_state_map(frames, off, b, m, T);
+  // optional zeroed rectangle (rows = index along C, columns = index along T), block-uniform
+  int zr0 = 0, zr1 = 0, zc0 = 0, zc1 = 0;
+  if (zero_rect) {
+    zr0 = zero_rect[b * 4 + 0];
+    zr1 = zero_rect[b * 4 + 1];
+    zc0 = zero_rect[b * 4 + 2];
+    zc1 = zero_rect[b * 4 + 3];
+  }
 
   const int plane = C * T;
   const int chunk0 = blockIdx.x * epb;
@@ -241,6 +249,11 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
         out[e] = (mask & (1 << e)) ? blend(o[e], v, lam, oml) : o[e];
       }
       if (WARP) spline_apply<4>(out, lds + (size_t)(c - c_lo) * rec_per_ch, thr, n_knots, t0);
+      if (c >= zr0 && c < zr1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (t0 + e >= zc0 && t0 + e < zc1) out[e] = 0.f;
+      }
       float4_a v;
       v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
       const int i = chunk0 + (q * kThreads + (int)threadIdx.x) * 4;
@@ -255,6 +268,7 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
       float out[1] = {x[own_base + i]};
       if (hit) out[0] = blend(out[0], x[par_base + (size_t)c * T + t0 + d], lam, oml);
       if (WARP) spline_apply<1>(out, lds + (size_t)(c - c_lo) * rec_per_ch, thr, n_knots, t0);
+      if (c >= zr0 && c < zr1 && t0 >= zc0 && t0 < zc1) out[0] = 0.f;
       y[own_base + i] = out[0];
     }
   }
@@ -265,7 +279,8 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
 extern "C" int pcgmix_mix_warp_f32(const float* x, float* y, const int32_t* frames,
                                    const int32_t* mix_idx, const int32_t* off, float lam,
                                    const double* knots, const double* spline_op, int n_knots,
-                                   int B, int C, int T, pcgmix_stream_t stream) {
+                                   const int32_t* zero_rect, int B, int C, int T,
+                                   pcgmix_stream_t stream) {
   using namespace pcgmix;
   if (!x || !y || !frames || !mix_idx || x == y) return hipErrorInvalidValue;
   if (B < 0 || C <= 0 || T <= 0) return hipErrorInvalidValue;
@@ -303,7 +318,7 @@ extern "C" int pcgmix_mix_warp_f32(const float* x, float* y, const int32_t* fram
   dim3 grid(chunks, gy, gz), block(kThreads);
 #define PCGMIX_LAUNCH(V, W, UU)                                                              \
   hipLaunchKernelGGL((mix_warp_kernel<V, W, UU>), grid, block, lds, s, x, y, frames, mix_idx, \
-                     off, lam, oml, knots, spline_op, n_knots, B, C, T, epb)
+                     off, lam, oml, knots, spline_op, n_knots, zero_rect, B, C, T, epb)
 #define PCGMIX_LAUNCH_U(W)                                \
   do {                                                    \
     if (U == 4) PCGMIX_LAUNCH(4, W, 4);                   \

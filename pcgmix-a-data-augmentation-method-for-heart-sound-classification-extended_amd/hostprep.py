@@ -27,7 +27,8 @@ from . import _lib
 
 # Methods this package implements, in the reference's dispatch order (augmentations.py:864, 931).
 PCGMIX_METHODS_1D = ("durmixmagwarp", "durratiomixup")
-PCGMIX_METHODS_2D = ("durratiomixup",)            # augmentations2d.py:397 (no magwarp in 2D)
+# 2D dispatch order: augmentations2d.py:286 (cutout), :325 (timemask), :361 (freqmask), :397
+PCGMIX_METHODS_2D = ("durmixcutout", "durmixtimemask", "durmixfreqmask", "durratiomixup")
 
 # Every name the reference dispatcher knows (augmentations.py:700-729, augmentations2d.py:269-281).
 # A method string that names one of these but none of ours is refused loudly instead of being
@@ -44,7 +45,7 @@ _REFERENCE_METHODS_2D = (
     "durratiomixup", "durmixfreqmask", "durmixtimemask", "durmixcutout")
 # Branches the reference tests BEFORE ours (augmentations.py:731-862; augmentations2d.py:286-395)
 _EARLIER_1D = ("durmixrespscale", "respiratoryscale", "timemask")
-_EARLIER_2D = ("durmixcutout", "durmixfreqmask", "durmixtimemask")
+_EARLIER_2D = ()
 _UNSUPPORTED_SELECTORS = ("(sameCVD)", "(closestbins=", "(closestknn=")
 
 
@@ -62,6 +63,7 @@ class MixPlan:
     knots: Optional[np.ndarray] = None         # float64 (B, n_knots, C) as numpy drew them
     n_knots: int = 0
     mix_all: bool = False                      # '(mixAll)': targets are blended too
+    zero_rect: Optional[np.ndarray] = None     # int32 (B,4) [row0,row1,col0,col1): 2D mask variants
 
 
 @functools.lru_cache(maxsize=256)
@@ -169,6 +171,44 @@ def rand_offsets(frames: np.ndarray, mix: np.ndarray, step: int) -> np.ndarray:
     return vals[inv].reshape(gap.shape)
 
 
+def mask_rectangles(method: str, name: str, frames: np.ndarray, step: int, n_rows: int,
+                    n_cols: int) -> np.ndarray:
+    """Zeroed rectangle per sample for durmixcutout / durmixtimemask / durmixfreqmask
+    (augmentations2d.py:309-323, 348-358, 384-394): region sizes from
+    ``Random(step+131071).uniform``, positions from ``Random(step+13119).uniform``; the time span
+    is a fraction of each sample's own cycle length (``int(frac * f[-1])``), the frequency span is
+    one row range for the whole batch.  Rows count along the flattened (channel, frequency) axis
+    of the kernel call; the reference's images have one channel."""
+    def clamp01(v):
+        return min(max(v, 0), 1)
+    t_max = f_max = 0.2
+    key = name[len("durmix"):] + "("
+    parts = method.split(key)
+    if len(parts) > 1:
+        if name == "durmixcutout":
+            t_max = clamp01(float(parts[1].split(",")[0]))
+            f_max = clamp01(float(method.split(",")[1].split(")")[0]))
+        else:
+            t_max = f_max = clamp01(float(parts[1].split(")")[0]))
+    B = frames.shape[0]
+    rect = np.zeros((B, 4), dtype=np.int32)
+    rect[:, 1] = n_rows
+    rect[:, 3] = n_cols
+    if name in ("durmixcutout", "durmixtimemask"):
+        gap = random.Random(step + 131071).uniform(0, t_max)
+        frac1 = random.Random(step + 13119).uniform(0, 1 - gap)
+        frac2 = frac1 + gap
+        beat = frames[:, 4].astype(np.float64)
+        rect[:, 2] = (frac1 * beat).astype(np.int64)          # int() truncation
+        rect[:, 3] = (frac2 * beat).astype(np.int64)
+    if name in ("durmixcutout", "durmixfreqmask"):
+        fgap = random.Random(step + 131071).uniform(0, f_max)
+        h1 = int(n_rows * random.Random(step + 13119).uniform(0, 1 - fgap))
+        rect[:, 0] = h1
+        rect[:, 1] = min(n_rows, h1 + int(fgap * n_rows))
+    return rect
+
+
 def validate_frames(frames: np.ndarray, sig_len: int) -> None:
     """The reference silently mis-slices (and usually raises a shape error) when a cycle runs
     past the padded length; refuse such input up front."""
@@ -183,7 +223,7 @@ def validate_frames(frames: np.ndarray, sig_len: int) -> None:
 
 
 def make_plan(method: str, labels, frames: np.ndarray, wav: Sequence[str], step: int,
-              batch: int, channels: int, is2d: bool = False) -> MixPlan:
+              batch: int, channels: int, is2d: bool = False, n_cols: int = 0) -> MixPlan:
     """Everything random/integer for one step, in the reference's RNG order.
 
     ``labels`` may be an array or a zero-argument callable returning one: they are needed only
@@ -206,6 +246,8 @@ def make_plan(method: str, labels, frames: np.ndarray, wav: Sequence[str], step:
     else:
         plan.lam64 = 1.0
     plan.lam32 = np.float32(plan.lam64)                                     # augmentations.py:903
+    if is2d and name != "durratiomixup":
+        plan.zero_rect = mask_rectangles(method, name, frames, step, channels, n_cols)
     if not is2d:
         if "(rand)" in method and "(salopt" not in method:
             plan.rand_off = rand_offsets(frames, plan.mix, step)

@@ -213,6 +213,18 @@ def main():
     x2d[np.broadcast_to(np.arange(128)[None, None, None, :] >= f2d[:, 4][:, None, None, None], x2d.shape)] = 0
     for j, (method, step) in enumerate([("durratiomixup", 0), ("durratiomixup+0.5", 3), ("durratiomixup", 11)]):
         save(f"mix2d_8x1x128x128_{j}", run_case(ref, ref.augmentations2d, x2d, f2d, lb, wb, method, step, tmp))
+    # mask variants fused after the 2D splice (small images keep fixtures small)
+    rs = np.random.RandomState(22)
+    xm2 = rs.standard_normal((6, 1, 32, 32)).astype(np.float32)
+    fm2 = np.array([[0, 3, 9, 12, 25], [0, 4, 11, 15, 30], [0, 2, 8, 10, 20], [0, 5, 12, 16, 32],
+                    [0, 3, 10, 13, 27], [0, 4, 9, 12, 22]], dtype=np.int64)
+    lm2 = np.array([0, 1, 0, 1, 0, 0], dtype=np.int64)
+    wm2 = tuple("abcdef")
+    for j, (method, step) in enumerate([("durmixcutout", 1), ("durmixcutout(0.5,0.6)", 2),
+                                        ("durmixcutout(0.9,0.9)+0.9", 5), ("durmixtimemask", 3),
+                                        ("durmixtimemask(0.7)", 4), ("durmixfreqmask", 6),
+                                        ("durmixfreqmask(0.8)", 7), ("durmixfreqmask(0.8)+0.5", 8)]):
+        save(f"mask2d_6x1x32x32_{j}", run_case(ref, ref.augmentations2d, xm2, fm2, lm2, wm2, method, step, tmp))
 
     # ---------------- models: seed-initialised forward logits + soft-target CE ----------------
     out = {}

@@ -14,14 +14,16 @@ from conftest import ROOT, golden_files, load_golden
 CASES = golden_files("mix1d_") + golden_files("salopt_")
 
 
-@pytest.mark.parametrize("path", CASES + golden_files("mix2d_"), ids=lambda p: p.split("/")[-1][:-4])
+@pytest.mark.parametrize("path", CASES + golden_files("mix2d_") + golden_files("mask2d_"),
+                         ids=lambda p: p.split("/")[-1][:-4])
 def test_plan_matches_reference(path):
     g = load_golden(path)
     is2d = g["x"].ndim == 4
     B = g["x"].shape[0]
     C = 1 if is2d else g["x"].shape[1]
+    C = g["x"].shape[1] * g["x"].shape[2] if is2d else C
     plan = hostprep.make_plan(g["method"], g["labels"], g["frames"], g["wav"], g["step"], B, C,
-                              is2d=is2d)
+                              is2d=is2d, n_cols=g["x"].shape[-1])
     assert plan.fired == bool(g["fired"])
     if not plan.fired:
         return
@@ -89,8 +91,9 @@ def test_unknown_method_is_passthrough_and_foreign_method_is_refused():
     with pytest.raises(NotImplementedError):
         hostprep.select_method("(sameCVD)durratiomixup", False)
     assert hostprep.select_method("durmixmagwarp(0.2,4)", True) is None   # unknown to the 2D dispatcher
+    assert hostprep.select_method("durmixcutout(0.2,0.3)", True) == "durmixcutout"
     with pytest.raises(NotImplementedError):
-        hostprep.select_method("durmixcutout", True)
+        hostprep.select_method("cutout", True)
 
 
 def test_validate_frames():
@@ -149,3 +152,32 @@ def test_spline_operator_rejects_bad_arguments():
     buf = np.empty(64)
     assert lib.pcgmix_spline_operator_f64(100, 1, buf.ctypes.data) != 0
     assert lib.pcgmix_spline_operator_f64(1, 4, buf.ctypes.data) != 0
+
+
+def test_plan_edge_batches():
+    one = hostprep.make_plan("durmixmagwarp(0.2,4)", np.array([1]), np.array([[0, 5, 9, 12, 20]]),
+                             ("a",), 3, 1, 2)
+    assert one.fired and one.mix.tolist() == [0] and one.knots.shape == (1, 6, 2)
+    empty = hostprep.make_plan("durratiomixup", np.zeros(0, np.int64), np.zeros((0, 5), np.int64),
+                               (), 3, 0, 1)
+    assert empty.fired and empty.mix.shape == (0,)
+    with pytest.raises(ValueError):
+        hostprep.make_plan("durratiomixup", np.zeros(3, np.int64), np.zeros((2, 5), np.int64),
+                           ("a", "b"), 0, 2, 1)
+
+
+def test_mask_rectangles_match_reference_zero_pattern():
+    """The rectangles derived on the host cover exactly the elements the reference zeroed
+    (goldens mask2d_*: inputs are dense noise, so zeros in y are the mask)."""
+    for path in golden_files("mask2d_"):
+        g = load_golden(path)
+        if not g["fired"]:
+            continue
+        B, _, F, W = g["x"].shape
+        plan = hostprep.make_plan(g["method"], g["labels"], g["frames"], g["wav"], g["step"], B, F,
+                                  is2d=True, n_cols=W)
+        r = plan.zero_rect
+        rows, cols = np.arange(F)[None, :, None], np.arange(W)[None, None, :]
+        mask = ((rows >= r[:, 0, None, None]) & (rows < r[:, 1, None, None])
+                & (cols >= r[:, 2, None, None]) & (cols < r[:, 3, None, None]))
+        assert np.array_equal(mask, g["y"][:, 0] == 0), path

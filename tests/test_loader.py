@@ -1,0 +1,95 @@
+"""Dataset selection against the reference's own output, the dataset container round trip, and
+the resident loader's batch order against a real torch DataLoader."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import pcgmix_amd  # noqa: F401
+from pcgmix_amd import dataloader_physionet as dl
+from conftest import GOLDEN
+
+sys.path.insert(0, GOLDEN)
+from make_golden_loader import CONFIGS, synthetic_dataset  # noqa: E402  (data generator only)
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "loader_selection.npz"))
+
+
+@pytest.mark.parametrize("i", range(len(CONFIGS)))
+@pytest.mark.parametrize("ch", [1, 4])
+def test_selection_matches_reference(i, ch, golden):
+    cfg = CONFIGS[i]
+    ds = synthetic_dataset()
+    d = dl.physionet_dataset(arguments=argparse.Namespace(**cfg), dataset=ds, dataset_name="PhysioNet",
+                             seed_data=cfg["seed_data"], num_classes=2, n_fraction=cfg["n_fraction"],
+                             mode="train", transform=None, sample_rate=1000, num_channels=ch,
+                             seed=cfg["seed"], train_balance=cfg["train_balance"], method="base",
+                             valid=cfg["valid"])
+    k = f"cfg{i}_ch{ch}"
+    assert np.array_equal(d.train_wav, golden[k + "_train_wav"])           # same cycles, same order
+    assert np.array_equal(d.train_label, golden[k + "_train_label"])
+    assert np.array_equal(d.train_frames, golden[k + "_train_frames"])
+    assert list(d.train_data.shape) == golden[k + "_train_data_shape"].tolist()
+    assert np.allclose(d.train_data.reshape(len(d.train_data), -1).sum(1), golden[k + "_train_data_sum"])
+    if cfg["valid"]:
+        assert np.array_equal(d.test_wav, golden[k + "_valid_wav"])
+        assert np.array_equal(d.test_label, golden[k + "_valid_label"])
+
+
+def test_test_split_and_bad_fold(golden):
+    ds = synthetic_dataset()
+    t = dl.physionet_dataset(argparse.Namespace(), ds, "PhysioNet", 1, 2, 1.0, "test", None, 1000, 4,
+                             4, True, "base", False)
+    assert np.array_equal(t.test_wav, golden["test_wav"])
+    assert list(t.test_data.shape) == golden["test_data_shape"].tolist()
+    with pytest.raises(Exception):
+        dl.physionet_dataset(argparse.Namespace(), ds, "PhysioNet", 1, 2, 1.0, "train", None, 1000, 4,
+                             7, True, "base", True)
+
+
+def test_container_round_trip(tmp_path):
+    ds = synthetic_dataset(seed=3, n_rec=6)
+    path = str(tmp_path / "set.dat")
+    dl.dict2file(ds, path)
+    back = dl.file2dict(path)
+    assert back["train"]["wav"] == ds["train"]["wav"]
+    assert np.array_equal(back["test"]["data"]["25-400"][2], ds["test"]["data"]["25-400"][2])
+
+
+def test_resident_loader_order_equals_torch_dataloader():
+    """Same global seed -> the same shuffled batches as DataLoader(shuffle=True, drop_last=True)."""
+    from torch.utils.data import DataLoader, TensorDataset
+    n, bs = 103, 8
+    x = np.arange(n * 2 * 5, dtype=np.float32).reshape(n, 2, 5)
+    lab = np.arange(n) % 2
+    fr = np.tile(np.array([0, 1, 2, 3, 4]), (n, 1))
+    loader = dl.ResidentLoader(x, lab, fr, [f"w{i}" for i in range(n)], np.ones(n), bs, True, True)
+    ref = DataLoader(TensorDataset(torch.arange(n)), batch_size=bs, shuffle=True, drop_last=True)
+    for epoch in range(3):
+        torch.manual_seed(4 * 635410 + epoch * 12)          # train_model.py:497
+        want = [b[0].tolist() for b in ref]
+        torch.manual_seed(4 * 635410 + epoch * 12)
+        got = [b[5].tolist() for b in loader]
+        assert got == want and len(got) == n // bs
+    batch = next(iter(loader))
+    assert batch[0].shape == (bs, 2, 5) and batch[2].shape == (bs, 5) and len(batch[3]) == bs
+    assert torch.equal(batch[0], torch.from_numpy(x)[batch[5]])
+
+
+def test_dataloader_run_interface():
+    ds = synthetic_dataset()
+    a = argparse.Namespace(dataset="PhysioNet", seed_data=1100001, n_fraction=1.0, batch_size=16,
+                           num_classes=2, sample_rate=1000, num_channels=4, seed=4,
+                           train_balance=True, method="durratiomixup", valid=False)
+    loader, labels = dl.physionet_dataloader(a, ds).run("train", 4)
+    assert len(labels) == len(loader.dataset) and len(loader) == len(labels) // 16
+    data, target, frames, wav, qual, idx = next(iter(loader))
+    assert data.shape[1:] == (4, 48) and data.dtype == torch.float32 and frames.dtype == torch.int64
+    test = dl.physionet_dataloader(a, ds).run("test", None)
+    assert sum(len(b[1]) for b in test) == len(test.dataset)

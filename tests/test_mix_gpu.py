@@ -27,7 +27,7 @@ def run(mod, g, device, method=None, x=None):
     return data, tgt, out
 
 
-@pytest.mark.parametrize("path", golden_files("mix1d_") + golden_files("mix2d_"),
+@pytest.mark.parametrize("path", golden_files("mix1d_") + golden_files("mix2d_") + golden_files("mask2d_"),
                          ids=lambda p: p.split("/")[-1][:-4])
 def test_augment_matches_reference_goldens(path, device):
     g = load_golden(path)
@@ -125,3 +125,61 @@ def test_rejects_bad_inputs(device):
     with pytest.raises(ValueError):
         augmentations.augment(a, torch.from_numpy(x).to(device), tgt, bad, wav, StepCounter(0),
                               None, device, "")
+
+
+# ------------------------------------------------------------------ edge cases
+def _aug(method, x, frames, labels, wav, step, device):
+    g = dict(x=x, labels=labels, frames=frames, wav=wav, step=step, method=method)
+    _, _, (y, _, mix, _) = run(augmentations, g, device)
+    return y.cpu().numpy(), mix
+
+
+@pytest.mark.parametrize("method", ["durratiomixup", "durmixmagwarp(0.2,4)"])
+def test_degenerate_frames(method, device):
+    """Zero-length states, a cycle that fills the whole row, an empty cycle, batch of one."""
+    T = 512
+    rs = np.random.RandomState(0)
+    frames = np.array([[0, 0, 100, 100, 300],        # S1 and S2 empty
+                       [0, 50, 50, 200, 512],        # systole empty, cycle ends exactly at T
+                       [0, 0, 0, 0, 0],              # empty cycle
+                       [0, 120, 260, 330, 500],
+                       [0, 1, 2, 3, 4]], dtype=np.int64)
+    B = frames.shape[0]
+    x = rs.standard_normal((B, 3, T)).astype(np.float32)
+    labels = np.zeros(B, dtype=np.int64)
+    wav = tuple("abcde")
+    for step in (0, 3):
+        ref = O.augment(method, x, labels, frames, wav, step)
+        y, mix = _aug(method, x, frames, labels, wav, step, device)
+        assert np.array_equal(mix, ref["mix"])
+        assert np.abs(y - ref["y"]).max() <= (WAVE_TOL if "magwarp" in method else 0.0)
+    # batch of one: the only partner is the sample itself
+    ref = O.augment(method, x[:1], labels[:1], frames[3:4], wav[:1], 2)
+    y, mix = _aug(method, x[:1].copy(), frames[3:4], labels[:1], wav[:1], 2, device)
+    assert mix.tolist() == [0] and np.abs(y - ref["y"]).max() <= (WAVE_TOL if "magwarp" in method else 0.0)
+
+
+def test_empty_batch(device):
+    x = np.zeros((0, 2, 64), dtype=np.float32)
+    y, mix = _aug("durratiomixup", x, np.zeros((0, 5), np.int64), np.zeros(0, np.int64), (), 1, device)
+    assert y.shape == (0, 2, 64) and len(mix) == 0
+
+
+def test_batch_beyond_grid_y_limit(device):
+    """B > 32768 takes the gridDim.z split of the sample index."""
+    B, C, T = 40000, 1, 64
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, seed=8, rate_scale=0.04)
+    ref = O.augment("durratiomixup", x, labels, frames, wav, 4)
+    y, mix = _aug("durratiomixup", x, frames, labels, wav, 4, device)
+    assert np.array_equal(mix, ref["mix"]) and np.array_equal(y, ref["y"])
+
+
+def test_two_streams_and_second_device_free(device):
+    """Launches follow torch's CURRENT stream: results on a side stream are identical."""
+    x, frames, labels, wav = synthetic.make_batch(16, 2, 2500, seed=12)
+    y0, _ = _aug("durmixmagwarp(0.2,4)", x, frames, labels, wav, 9, device)
+    s = torch.cuda.Stream(device)
+    with torch.cuda.stream(s):
+        y1, _ = _aug("durmixmagwarp(0.2,4)", x, frames, labels, wav, 9, device)
+    s.synchronize()
+    assert np.array_equal(y0, y1)

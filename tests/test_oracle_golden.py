@@ -6,7 +6,8 @@ import pytest
 from conftest import golden_files, load_golden
 from oracle import pcgmix_oracle as O
 
-CASES = golden_files("mix1d_") + golden_files("mix2d_") + golden_files("salopt_")
+CASES = (golden_files("mix1d_") + golden_files("mix2d_") + golden_files("mask2d_")
+         + golden_files("salopt_"))
 
 
 def test_golden_inventory():
