@@ -116,7 +116,7 @@ class _Null:
         return False
 
 
-def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200):
+def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200, per_launch=False):
     """The fused kernel alone, launched back to back from one prepared plan (no host prologue
     between launches): the figure to compare with rocprofv3's per-kernel average."""
     if B * C * T > 64_000_000:          # saturating batches: random payload made on device
@@ -147,7 +147,22 @@ def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200):
         launch()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    interval = e0.elapsed_time(e1) / iters
+    if not per_launch:
+        return interval
+    # per-launch duration: an event pair around every launch while the queue stays full, so the
+    # pair brackets the kernel itself (start -> end, what rocprofv3 --kernel-trace reports);
+    # consecutive kernels of one stream overlap their ramp-up/drain, so this is slightly longer
+    # than the launch-to-launch interval above
+    pairs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        launch()
+        b.record()
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in pairs])), interval
 
 
 def cpu_baseline(method, B, C, T, rate, budget_s=12.0):
@@ -465,11 +480,12 @@ def main():
         dt = float(t.item())
     value = world * B * a.steps / dt
 
-    # Kernel time for the roofline: HIP events on the launch stream around R back-to-back
-    # launches of the same kernel on this workload (the figure rocprofv3's per-kernel average
-    # agrees with).  An event PAIR around each single launch inside the steps is also recorded;
-    # it carries ~7 us of event/launch overhead and is reported as in_step_event_pair_ms.
-    kern_ms = kernel_back_to_back_ms(a.method, B, C, T, rate, device)
+    # Kernel time for the roofline: HIP event pairs on the launch stream around each of 200
+    # launches of the same kernel on this workload, issued back to back so the GPU never waits
+    # for the host (the figure rocprofv3's per-kernel average agrees with).  Also reported: the
+    # launch-to-launch interval of that loop, and the event pairs recorded around the launches
+    # inside the timed steps (which include GPU idle time while Python prepares the launch).
+    kern_ms, interval_ms = kernel_back_to_back_ms(a.method, B, C, T, rate, device, per_launch=True)
     pair_ms = kt.mean_ms()
     alg_bytes = 12.0 * C * T * B                     # read own + read partner + write, fp32
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -487,9 +503,10 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,
                      "kernel": "pcgmix::mix_warp_kernel<4,false,2>", "kernel_ms": kern_ms,
-                     "in_step_event_pair_ms": pair_ms,
+                     "launch_interval_ms": interval_ms, "in_step_event_pair_ms": pair_ms,
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "timing": "HIP events on the launch stream over 200 back-to-back launches"},
+                     "timing": "median of HIP event pairs around each of 200 launches issued "
+                               "back to back on the launch stream (queue kept full)"},
     }
 
     # train step/s (second half of BASELINE.json's metric): 1D-CNN, bs 256 per GPU, DDP if N>1
