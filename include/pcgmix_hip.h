@@ -203,14 +203,19 @@ int pcgmix_logmel_f32(const float* x, const int32_t* frames, const void* tables,
  *   pcgmix_potes_bwd_blocks(N,T)   G = number of partial rows the backward needs
  *   pcgmix_potes_stack_bwd_f32     x, dL/dh2 (N,4,P2) -> grads[212] = [gw1(40) | gb1(8) |
  *                                  gw2(160) | gb2(4)]; `partial` is caller-provided scratch of
- *                                  G*212 floats.  The forward is recomputed tile by tile; the
- *                                  gradient w.r.t. x is NOT produced (the input is data).
+ *                                  G*212 floats.  The forward is recomputed tile by tile.
+ *   pcgmix_potes_stack_input_grad_f32   x, dL/dh2 -> dL/dx (N,T): what saliency.py:52-61 needs
+ *                                  (the class score differentiated w.r.t. the input); also
+ *                                  recomputes the forward, keeps nothing from it.
  * All pointers device; float32.
  */
 int pcgmix_potes_out_len(int T);
 int pcgmix_potes_bwd_blocks(int N, int T);
 int pcgmix_potes_stack_fwd_f32(const float* x, const float* w1, const float* b1, const float* w2,
                                const float* b2, float* h2, int N, int T, pcgmix_stream_t stream);
+int pcgmix_potes_stack_input_grad_f32(const float* x, const float* grad_h2, const float* w1,
+                                      const float* b1, const float* w2, const float* b2,
+                                      float* grad_x, int N, int T, pcgmix_stream_t stream);
 int pcgmix_potes_stack_bwd_f32(const float* x, const float* grad_h2, const float* w1,
                                const float* b1, const float* w2, const float* b2, float* partial,
                                float* grads, int N, int T, pcgmix_stream_t stream);

@@ -417,6 +417,130 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------- input gradient
+// dL/dx for saliency maps (saliency.py:52-61 differentiates the class score w.r.t. the INPUT).
+// Tile g owns the input positions u = 4*p0 + v, v < 4*TP (p0 = g*TP, TP = 124).  dL/dx[u] needs
+// dz1 at i = u-3 .. u+1, hence dL/da1 at q = 2p0-2 .. 2p0+2TP, hence dz2 at j = 2p0-5 .. 2p0+2TP+1,
+// i.e. the pooled outputs p0-3 .. p0+TP (128 values): the same extended sizes as the weight-gradient
+// kernel with every origin shifted by one pooled position.
+constexpr int kInTP = 124;
+constexpr int kInNR = 2 * kInTP + 3;            // 251 a1 positions with a complete gradient
+constexpr int kInNU = 4 * kInTP;                // 496 owned inputs
+
+__global__ __launch_bounds__(kPotThreads) void potes_input_grad_kernel(
+    const float* __restrict__ x, const float* __restrict__ gh2, const float* __restrict__ w1,
+    const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    float* __restrict__ gx, int N, int T) {
+  __shared__ PotesWeights W;
+  __shared__ __align__(16) float xs[kBwdNX + 4];
+  __shared__ __align__(16) float a1s[kC1 * kBwdNQ];
+  __shared__ __align__(16) uint8_t sel1[kC1 * kBwdNQ];
+  constexpr int kDz2Row = kBwdNJ + 12;
+  __shared__ __align__(16) float dz2s[kC2 * kDz2Row];
+  __shared__ __align__(16) float dz1s[kC1 * kBwdNIpad];
+  const PotesDims d = potes_dims(T);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y, p0 = blockIdx.x * kInTP;
+  const int qlo = 2 * p0 - 7, xlo = 2 * qlo - 1;      // a1 origin, x origin (4p0 - 15)
+  load_weights(&W, w1, b1, w2, b2);
+  for (int i = threadIdx.x; i < kC2 * kDz2Row; i += kPotThreads) dz2s[i] = 0.f;
+  stage_x(xs, x + (size_t)n * T, xlo, kBwdNX + 4, T);
+  __syncthreads();
+  layer1(W, xs, a1s, sel1, qlo, kBwdNQ, d.P1);
+  __syncthreads();
+  {  // conv2 + ReLU + pool on pe = p0-3+pp, pp < 128 -> dz2 (wave = co, 2 pooled per lane)
+    const int co = wave;
+    float aw[8], za[2], zb[2];
+    za[0] = za[1] = zb[0] = zb[1] = W.b2[co];
+#pragma unroll
+    for (int ci = 0; ci < kC1; ++ci) {
+      float w[kK];
+      lds_load8(a1s + ci * kBwdNQ + 4 * lane, aw);
+#pragma unroll
+      for (int k = 0; k < kK; ++k) w[k] = W.w2[(co * kC1 + ci) * kK + k];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 0; k < kK; ++k) {
+          za[u] = fmaf(w[k], aw[2 * u + k], za[u]);
+          zb[u] = fmaf(w[k], aw[2 * u + 1 + k], zb[u]);
+        }
+    }
+    f4 dz;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pe = p0 - 3 + 2 * lane + u;
+      float da = 0.f, db = 0.f;
+      if (pe >= 0 && pe < d.P2) {
+        const float g = gh2[((size_t)n * kC2 + co) * d.P2 + pe];
+        const float ra = fmaxf(za[u], 0.f), rb = fmaxf(zb[u], 0.f);
+        if (rb > ra) db = g; else if (ra > 0.f) da = g;
+      }
+      dz[2 * u] = da;
+      dz[2 * u + 1] = db;
+    }
+    *reinterpret_cast<f4*>(dz2s + co * kDz2Row + 4 * lane) = dz;
+  }
+  __syncthreads();
+  {  // dL/da1 at q = 2p0-2+r (r < 251), through pool1/ReLU1 -> dz1 at i = 4p0-4+2r(+1)
+    const int r0 = 4 * lane;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ci = 2 * wave + c;
+      float da1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int co = 0; co < kC2; ++co) {
+        float dw[12], w[kK];
+        lds_load12(dz2s + co * kDz2Row + r0, dw);   // dz2 index r+5-k
+#pragma unroll
+        for (int k = 0; k < kK; ++k) w[k] = W.w2[(co * kC1 + ci) * kK + k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < kK; ++k) da1[u] = fmaf(dw[u + 5 - k], w[k], da1[u]);
+      }
+      float out[8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = r0 + u;
+        const uint8_t sc = r < kInNR ? sel1[ci * kBwdNQ + r + 5] : 0;
+        out[2 * u] = sc == 1 ? da1[u] : 0.f;
+        out[2 * u + 1] = sc == 2 ? da1[u] : 0.f;
+      }
+      f4* dst = reinterpret_cast<f4*>(dz1s + ci * kBwdNIpad + 8 * lane);
+      dst[0] = f4{out[0], out[1], out[2], out[3]};
+      dst[1] = f4{out[4], out[5], out[6], out[7]};
+    }
+  }
+  __syncthreads();
+  {  // transposed conv1: dx[u] = sum_ci sum_k dz1[ci][u+1-k] * w1[ci][k]; dz1 index v+5-k
+    const int v0 = 2 * threadIdx.x;
+    if (v0 < kInNU) {
+      float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < kC1; ++ci) {
+        float dw[6], w[kK];
+#pragma unroll
+        for (int j = 0; j < 6; j += 2) {             // dz1 index v0+1 .. v0+6 (8-byte aligned + 1)
+          dw[j] = dz1s[ci * kBwdNIpad + v0 + 1 + j];
+          dw[j + 1] = dz1s[ci * kBwdNIpad + v0 + 2 + j];
+        }
+#pragma unroll
+        for (int k = 0; k < kK; ++k) w[k] = W.w1[ci * kK + k];
+#pragma unroll
+        for (int k = 0; k < kK; ++k) {
+          acc0 = fmaf(dw[4 - k], w[k], acc0);        // v0+5-k   -> offset 4-k from v0+1
+          acc1 = fmaf(dw[5 - k], w[k], acc1);        // v0+1+5-k
+        }
+      }
+      const int u = 4 * p0 + v0;
+      float* dst = gx + (size_t)n * T + u;
+      if (u < T) dst[0] = acc0;
+      if (u + 1 < T) dst[1] = acc1;
+    }
+  }
+}
+
 // Sum the per-block partial vectors in a fixed order: grads[e] = sum_g partial[g][e].
 __global__ __launch_bounds__(kPotThreads) void potes_reduce_kernel(const float* __restrict__ partial,
                                                                    float* __restrict__ grads,
@@ -458,6 +582,20 @@ extern "C" int pcgmix_potes_stack_fwd_f32(const float* x, const float* w1, const
   dim3 grid((unsigned)((d.P2 + kFwdTP - 1) / kFwdTP), (unsigned)N), block(kPotThreads);
   hipLaunchKernelGGL(potes_fwd_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), x, w1,
                      b1, w2, b2, h2, N, T);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pcgmix_potes_stack_input_grad_f32(const float* x, const float* grad_h2,
+                                                 const float* w1, const float* b1, const float* w2,
+                                                 const float* b2, float* grad_x, int N, int T,
+                                                 pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!x || !grad_h2 || !w1 || !b1 || !w2 || !b2 || !grad_x || N < 0 || N > 65535 || T < 14)
+    return hipErrorInvalidValue;
+  if (N == 0) return hipSuccess;
+  dim3 grid((unsigned)((T + kInNU - 1) / kInNU), (unsigned)N), block(kPotThreads);
+  hipLaunchKernelGGL(potes_input_grad_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream),
+                     x, grad_h2, w1, b1, w2, b2, grad_x, N, T);
   return (int)hipGetLastError();
 }
 

@@ -23,7 +23,8 @@ class PotesStackFunction(torch.autograd.Function):
     """conv(1->8,k5,p1)+ReLU+pool2 -> conv(8->4,k5,p1)+ReLU+pool2 on (N,T) rows as ONE HIP kernel
     forward and one (+ a 212-block reduction) backward: ``pcgmix_potes_stack_{fwd,bwd}_f32``
     (csrc/pcgmix_potes.hip).  The backward recomputes the forward per tile from the saved input,
-    so nothing but the input row is kept for it.  No gradient is produced for the input."""
+    so nothing but the input row is kept for it.  The input gradient (saliency maps) has its own
+    kernel, ``pcgmix_potes_stack_input_grad_f32``, run only when the input requires it."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
@@ -42,21 +43,27 @@ class PotesStackFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_h2):
         x, w1, b1, w2, b2 = ctx.saved_tensors
-        if ctx.needs_input_grad[0]:
-            raise RuntimeError("the fused Potes stack does not produce input gradients")
         N, T = x.shape
         lib = _lib.load()
-        G = lib.pcgmix_potes_bwd_blocks(N, T)
         g = grad_h2.contiguous()
-        partial = torch.empty((G, 212), dtype=torch.float32, device=x.device)
-        grads = torch.empty(212, dtype=torch.float32, device=x.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        _lib.check(lib.pcgmix_potes_stack_bwd_f32(x.data_ptr(), g.data_ptr(), w1.data_ptr(),
-                                                  b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                                                  partial.data_ptr(), grads.data_ptr(), N, T,
-                                                  stream), "pcgmix_potes_stack_bwd_f32")
-        return (None, grads[0:40].view(8, 1, 5), grads[40:48], grads[48:208].view(4, 8, 5),
-                grads[208:212])
+        gx = gw1 = gb1 = gw2 = gb2 = None
+        if ctx.needs_input_grad[0]:                    # saliency: d score / d input
+            gx = torch.empty_like(x)
+            _lib.check(lib.pcgmix_potes_stack_input_grad_f32(
+                x.data_ptr(), g.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                b2.data_ptr(), gx.data_ptr(), N, T, stream), "pcgmix_potes_stack_input_grad_f32")
+        if any(ctx.needs_input_grad[1:]):
+            G = lib.pcgmix_potes_bwd_blocks(N, T)
+            partial = torch.empty((G, 212), dtype=torch.float32, device=x.device)
+            grads = torch.empty(212, dtype=torch.float32, device=x.device)
+            _lib.check(lib.pcgmix_potes_stack_bwd_f32(x.data_ptr(), g.data_ptr(), w1.data_ptr(),
+                                                      b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                                      partial.data_ptr(), grads.data_ptr(), N, T,
+                                                      stream), "pcgmix_potes_stack_bwd_f32")
+            gw1, gb1 = grads[0:40].view(8, 1, 5), grads[40:48]
+            gw2, gb2 = grads[48:208].view(4, 8, 5), grads[208:212]
+        return gx, gw1, gb1, gw2, gb2
 
 
 def _potes_block(c_in: int, c_out: int, dropout: float = 0.0) -> nn.Sequential:
@@ -100,9 +107,9 @@ class CNN_potes(nn.Module):
 
     def _fused(self, x: torch.Tensor) -> bool:
         """The hand-written HIP stack applies to the reference configuration (layers [8,4]) on a
-        HIP device when the input itself needs no gradient (saliency maps take the torch path)."""
+        HIP device."""
         c1, c2 = self.cnn1[0][0], self.cnn1[1][0]
-        return (self.fused and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad
+        return (self.fused and x.is_cuda and x.dtype == torch.float32
                 and c1.out_channels == 8 and c2.out_channels == 4 and x.shape[-1] >= 14)
 
     def features(self, x: torch.Tensor) -> torch.Tensor:

@@ -73,8 +73,27 @@ def test_training_step_equivalence(device):
         assert torch.allclose(a, b, rtol=1e-3, atol=2e-4)   # Adam normalises: sign/ratio sensitive
 
 
-def test_input_gradient_requests_take_the_torch_path(device):
-    m = make(2500, device).eval()
-    x = torch.randn(2, 4, 2500, device=device, requires_grad=True)
-    m(x).sum().backward()                         # saliency-style use: must not raise
-    assert x.grad is not None and torch.isfinite(x.grad).all()
+@pytest.mark.parametrize("B,T", [(8, 2500), (4, 5000), (3, 1037), (2, 1030), (6, 526), (2, 270), (1, 23), (2, 14)])
+def test_input_gradient_matches_torch(B, T, device):
+    """dL/dx through the fused stack == through the torch stack (saliency maps differentiate the
+    class score with respect to the input, saliency.py:52-61)."""
+    m = make(T, device, seed=3).eval()
+    c1, c2 = m.cnn1[0][0], m.cnn1[1][0]
+    params = [c1.weight, c1.bias, c2.weight, c2.bias]
+    x1 = torch.randn(B * 4, T, device=device, requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    h_t = m.cnn1(x1.unsqueeze(1))
+    r = torch.randn_like(h_t)
+    (g_t,) = torch.autograd.grad((h_t * r).sum(), x1)
+    h_f = models.PotesStackFunction.apply(x2, *params)
+    (g_f,) = torch.autograd.grad((h_f * r).sum(), x2)
+    scale = float(g_t.abs().max()) + 1e-6
+    assert float((g_f - g_t).abs().max()) <= 1e-4 * scale
+    # whole model, saliency style
+    xa = torch.randn(B, 4, T, device=device, requires_grad=True)
+    xb = xa.detach().clone().requires_grad_(True)
+    m.fused = True
+    m(xa)[:, 0].sum().backward()
+    m.fused = False
+    m(xb)[:, 0].sum().backward()
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-5 * float(xb.grad.abs().max()) + 1e-9)
