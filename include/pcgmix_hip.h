@@ -82,6 +82,15 @@ double pcgmix_py_uniform01(uint64_t seed);
 /* random.Random(seed).randint(0, hi) — the '(rand)' placement offset (augmentations.py:307). */
 int64_t pcgmix_py_randint0(uint64_t seed, int64_t hi);
 
+/* Validate `frames` (int64 (B,5), as the reference's loader yields them) against the signal
+ * length and pack the per-step index block read by pcgmix_mix_warp_f32 into `out` (host, e.g.
+ * pinned staging): int32 frames[B][5] | mix[B] | rand_off[B][4] (if given) | rect[B][4] (if
+ * given).  Returns 0, or 1 = boundaries negative / decreasing, 2 = cycle longer than T (the
+ * reference mis-slices silently there, augmentations.py:294-304), 3 = partner index out of
+ * range.                                                                            [host] */
+int pcgmix_pack_plan_i32(const int64_t* frames, const int64_t* mix, const int32_t* rand_off,
+                         const int32_t* rect, int B, int T, int32_t* out);
+
 /* ------------------------------------------------------------------------------------------
  * Fused segment-aware splice (+ optional magnitude warp).                        [device]
  *

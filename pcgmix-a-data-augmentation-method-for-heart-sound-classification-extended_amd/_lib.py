@@ -27,6 +27,7 @@ SIGNATURES = {
     "pcgmix_partner_permutation_i64": (_c_int, [_ptr, _c_int, _c_int, ctypes.c_uint64, _ptr]),
     "pcgmix_py_uniform01": (ctypes.c_double, [ctypes.c_uint64]),
     "pcgmix_py_randint0": (ctypes.c_int64, [ctypes.c_uint64, ctypes.c_int64]),
+    "pcgmix_pack_plan_i32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),
     "pcgmix_mix_warp_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _ptr, _ptr, _c_int,
                                      _ptr, _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_saliency_post_f32": (_c_int, [_ptr, _ptr, _ptr, _c_int, ctypes.c_double, _c_int, _c_int,

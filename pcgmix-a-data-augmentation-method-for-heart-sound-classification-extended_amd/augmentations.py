@@ -124,10 +124,17 @@ def upload_array(arr: np.ndarray, device: torch.device) -> torch.Tensor:
     return dev[:nbytes].view(torch.from_numpy(arr[:0].reshape(-1)).dtype).view(arr.shape)
 
 
-def upload_plan(plan: MixPlan, frames: np.ndarray, device: torch.device):
-    """One async H2D copy with every small per-step array: int32 frames (B,5) | mix (B) |
-    offsets (B,4, optional) | zero rectangles (B,4, optional) | float64 knots (optional).  Returns (device buffer, byte offsets).
-    Must be called with ``device`` current."""
+_PACK_ERRORS = {1: "frames must be non-decreasing and non-negative",
+                2: "heart cycle ends beyond the signal length",
+                3: "partner index out of range"}
+
+
+def upload_plan(plan: MixPlan, frames: np.ndarray, device: torch.device, sig_len: int = 2**31 - 1):
+    """Validate the boundaries and send every small per-step array in ONE async H2D copy:
+    int32 frames (B,5) | mix (B) | offsets (B,4, optional) | zero rectangles (B,4, optional) |
+    float64 knots (optional).  Packing + validation run in the library
+    (pcgmix_pack_plan_i32) straight into pinned staging.  Returns (device buffer, byte offsets).
+    Must be called with ``device`` current.  Raises ValueError on malformed frames."""
     B = frames.shape[0]
     n_off = B * 4 if plan.rand_off is not None else 0
     n_rect = B * 4 if plan.zero_rect is not None else 0
@@ -137,16 +144,15 @@ def upload_plan(plan: MixPlan, frames: np.ndarray, device: torch.device):
     nbytes = n_int_pad * 4 + n_kn * 8
     ring = _RINGS.setdefault(device.index, _StagingRing())
     slot, pinned = ring.stage(nbytes)
-    buf = pinned.numpy()
-    ints = buf[:n_int_pad * 4].view(np.int32)
-    ints[:B * 5] = frames.reshape(-1)
-    ints[B * 5:B * 6] = plan.mix
-    if n_off:
-        ints[B * 6:B * 6 + n_off] = plan.rand_off.reshape(-1)
-    if n_rect:
-        ints[B * 6 + n_off:B * 6 + n_off + n_rect] = plan.zero_rect.reshape(-1)
+    lib = _lib.load()
+    err = lib.pcgmix_pack_plan_i32(
+        frames.ctypes.data, plan.mix.ctypes.data,
+        plan.rand_off.ctypes.data if n_off else None,
+        plan.zero_rect.ctypes.data if n_rect else None, B, int(sig_len), pinned.data_ptr())
+    if err:
+        raise ValueError(_PACK_ERRORS.get(err, f"pcgmix_pack_plan_i32 error {err}"))
     if n_kn:
-        buf[n_int_pad * 4:nbytes].view(np.float64)[:] = plan.knots.reshape(-1)
+        pinned.numpy()[n_int_pad * 4:nbytes].view(np.float64)[:] = plan.knots.reshape(-1)
     dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
     dev.copy_(pinned[:nbytes], non_blocking=True)
     ring.sent(slot, torch.cuda.current_stream(device))
@@ -178,7 +184,7 @@ def apply_plan(plan: MixPlan, data: torch.Tensor, frames: np.ndarray,
     if B == 0:                        # nothing to launch (and an empty tensor has no storage)
         return torch.empty_like(data) if out is None else out
     with torch.cuda.device(device):
-        dev, offs = upload_plan(plan, frames, device)
+        dev, offs = upload_plan(plan, frames, device, T)
         base = dev.data_ptr()
         frames_ptr, mix_ptr = base + offs["frames"], base + offs["mix"]
         off_ptr = base + offs["off"] if offs["off"] is not None else None
@@ -246,7 +252,6 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
     plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, C, is2d=False)
     if not plan.fired:
         return data, target_ohe, [], None
-    hostprep.validate_frames(frames_np, T)
     sal = None
     if plan.salopt_mode is not None:
         from . import saliency as _sal

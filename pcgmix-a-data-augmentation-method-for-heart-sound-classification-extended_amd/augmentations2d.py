@@ -32,6 +32,5 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
     plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, Cc * F, is2d=True, n_cols=W)
     if not plan.fired:
         return data, target_ohe, [], None
-    hostprep.validate_frames(frames_np, W)
     out = apply_plan(plan, data.view(B, Cc * F, W), frames_np).view(B, Cc, F, W)
     return out, target_ohe, plan.mix, None

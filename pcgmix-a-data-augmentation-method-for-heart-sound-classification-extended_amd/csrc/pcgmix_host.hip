@@ -241,3 +241,33 @@ extern "C" int pcgmix_partner_permutation_i64(const int32_t* group_id, int B, in
   }
   return hipSuccess;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Validate the boundaries and pack the per-step index block the kernels read:
+//   int32 frames[B][5] | int32 mix[B] | int32 rand_off[B][4] (optional) | int32 rect[B][4] (optional)
+// Returns 0, or 1 frames not monotone / negative, 2 cycle end beyond T, 3 partner out of range.
+extern "C" int pcgmix_pack_plan_i32(const int64_t* frames, const int64_t* mix,
+                                    const int32_t* rand_off, const int32_t* rect, int B, int T,
+                                    int32_t* out) {
+  if (!frames || !mix || !out || B < 0) return hipErrorInvalidValue;
+  int32_t* f = out;
+  int32_t* m = out + (size_t)B * 5;
+  for (int b = 0; b < B; ++b) {
+    const int64_t* r = frames + (size_t)b * 5;
+    if (r[0] < 0) return 1;
+    for (int k = 0; k < 4; ++k)
+      if (r[k + 1] < r[k]) return 1;
+    if (r[4] > T) return 2;
+    for (int k = 0; k < 5; ++k) f[b * 5 + k] = (int32_t)r[k];
+    if (mix[b] < 0 || mix[b] >= B) return 3;
+    m[b] = (int32_t)mix[b];
+  }
+  int32_t* o = m + B;
+  if (rand_off) {
+    for (int i = 0; i < B * 4; ++i) o[i] = rand_off[i];
+    o += (size_t)B * 4;
+  }
+  if (rect)
+    for (int i = 0; i < B * 4; ++i) o[i] = rect[i];
+  return 0;
+}

@@ -113,8 +113,9 @@ def parse_magwarp(method: str):
 
 
 def gate_fires(method: str, step: int) -> bool:
-    """Fresh ``Random(step)``; the method runs iff u < p (augmentations.py:869-872)."""
-    return random.Random(step).uniform(0, 1) < parse_probability(method)
+    """Fresh ``Random(step)``; the method runs iff u < p (augmentations.py:869-872).  The draw is
+    the library's bit-exact restatement of ``random.Random(step).uniform(0, 1)``."""
+    return _lib.load().pcgmix_py_uniform01(int(step)) < parse_probability(method)
 
 
 def shuffle_within_groups(keys, step: int) -> np.ndarray:

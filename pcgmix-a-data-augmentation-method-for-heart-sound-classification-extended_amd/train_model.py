@@ -235,7 +235,6 @@ class GraphedTrainStep:
             raise NotImplementedError("saliency-guided steps are not captured; use train_step")
         t_ohe = F.one_hot(target, args.num_classes).to(self.device, non_blocking=True)
         if plan.fired:
-            hostprep.validate_frames(frames_np, T)
             augmentations.apply_plan(plan, data, frames_np, out=self.x)
             if plan.mix_all:
                 t_ohe = augmentations.blend_targets(t_ohe, plan)
