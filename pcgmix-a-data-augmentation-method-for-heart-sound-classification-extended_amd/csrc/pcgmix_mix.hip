@@ -161,17 +161,18 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
   const size_t own_base = (size_t)b * plane;
   const size_t par_base = (size_t)m * plane;
 
-  int c_lo = 0;
+  // Spline records for the channels this chunk touches (coef = op * knots[b,:,c]) are built in
+  // LDS AFTER the lane's data loads have been issued, so their dependent-load latency overlaps
+  // with the HBM latency of the batch data instead of preceding it.
   const int rec_per_ch = (n_knots - 1) * kRec;
-  const int* thr = nullptr;
-  if (WARP) {
-    // Coefficient records for the channels this chunk touches: coef = op * knots[b,:,c].
-    c_lo = chunk0 / T;
+  const int c_lo = WARP ? chunk0 / T : 0;
+  const int* thr = WARP ? reinterpret_cast<const int*>(lds + (size_t)(epb / T + 2) * rec_per_ch)
+                        : nullptr;
+  auto build_records = [&]() {
     int last = chunk0 + epb - 1;
     if (last > plane - 1) last = plane - 1;
     const int nch = last / T - c_lo + 1;
     int* thr_w = reinterpret_cast<int*>(lds + (size_t)(epb / T + 2) * rec_per_ch);
-    thr = thr_w;
     for (int i = threadIdx.x; i < n_knots; i += kThreads) thr_w[i] = (int)ceil(spline_op[i]);
     const int total = nch * rec_per_ch;
     for (int i = threadIdx.x; i < total; i += kThreads) {
@@ -189,9 +190,13 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
       lds[i] = acc;
     }
     __syncthreads();
-  }
+  };
 
+  // With U = 4 the extra live registers of "loads first" cost a wave of occupancy (129 VGPRs), so
+  // the fattest variant builds its records up front.
+  constexpr bool kRecordsFirst = U >= 4;
   if constexpr (VEC == 4) {
+    if (WARP && kRecordsFirst) build_records();
     // Two phases so that all U own-row and partner-row loads of a lane are in flight together.
     // Phase 1 is branch-free: the partner quad is fetched with ONE unaligned 16-byte load at
     // the shift of the first blended element (clamped into the row); elements of the quad that
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
       cs[q] = c;
       masks[q] = mask;
     }
+    if (WARP && !kRecordsFirst) build_records();
 #pragma unroll
     for (int q = 0; q < U; ++q) {
       const int mask = masks[q];
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
       *reinterpret_cast<float4_a*>(y + own_base + i) = v;
     }
   } else {
+    if (WARP) build_records();
     for (int i = chunk0 + threadIdx.x; i < chunk0 + epb && i < plane; i += kThreads) {
       const int c = i / T;
       const int t0 = i - c * T;

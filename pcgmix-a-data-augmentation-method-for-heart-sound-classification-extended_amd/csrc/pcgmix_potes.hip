@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
       const int co = wave;
       float aw[8], za[2], zb[2];
       za[0] = za[1] = zb[0] = zb[1] = W.b2[co];
-#pragma unroll
+#pragma unroll 2
       for (int ci = 0; ci < kC1; ++ci) {
         float w[kK];
         lds_load8(a1s + ci * kBwdNQ + 4 * lane, aw);
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
       for (int c = 0; c < 2; ++c) {
         const int ci = 2 * wave + c;
         float da1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
         for (int co = 0; co < kC2; ++co) {
           float dw[12], w[kK];
           lds_load12(dz2s + co * kDz2Row + r0, dw);   // dz2 index r+5-k, r = r0+u: r0+1 .. r0+8
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
       accb2 += (dd[0] + dd[1]) + (dd[2] + dd[3]);
       if (s0 < kBwdNS) {
 #pragma unroll
-        for (int ci = 0; ci < kC1; ++ci) {
+        for (int ci = 0; ci < kC1; ++ci) {   // acc2 is indexed statically: keep fully unrolled
           float aw[8];
           lds_load8(a1s + ci * kBwdNQ + s0 + 4, aw);   // a1 index s+4+k
 #pragma unroll
@@ -568,7 +568,7 @@ extern "C" int pcgmix_potes_bwd_blocks(int N, int T) {
   if (N <= 0 || T < 14) return 0;
   const pcgmix::PotesDims d = pcgmix::potes_dims(T);
   const long long work = (long long)N * ((d.P2 + 2 + pcgmix::kBwdTP - 1) / pcgmix::kBwdTP);  // = tiles
-  return (int)(work < 512 ? work : 512);  // 2 persistent blocks per CU (236 VGPRs: 2 waves per SIMD)
+  return (int)(work < 768 ? work : 768);  // 3 persistent blocks per CU (146 VGPRs: 3 waves per SIMD)
 }
 
 extern "C" int pcgmix_potes_stack_fwd_f32(const float* x, const float* w1, const float* b1,
