@@ -328,6 +328,104 @@ def test_data_accuracy(args, model, test_loader, device, criterion=None):
             "loss": loss_sum / max(1, n) if criterion is not None else None}
 
 
+def train_model(args, dataset, device, use_graph: bool = True, log=print):
+    """The reference's run driver (train_model.py:197-488) reduced to the hot path: seeds (:216-223),
+    loaders (:244-248), model (:293-386), criterion/optimiser/scheduler (:390-410), the epoch loop
+    (:428-478) with evaluation at the reference's 11 "plot epochs", and ``model.pth`` written with the
+    reference's DataParallel key prefix (:481-482) so that saliency-guided runs of either code
+    base can load it (saliency.py:50).  Plots, the pickle of the performance dict and the model
+    zoo are out of scope.  Returns the performance dict.
+
+    ``dataset`` is the dictionary ``dataloader_physionet.file2dict`` returns; it is selected by
+    ``physionet_dataloader`` and kept resident on ``device``.  On one GPU the step runs as a
+    captured hipGraph (``use_graph``); under torch.distributed each rank trains on its shard of
+    every batch with DDP gradient averaging."""
+    import random
+    import time as _time
+
+    import torch.distributed as dist
+    from . import dataloader_physionet as dlp
+    from . import saliency as _sal
+
+    if args.dataset != "PhysioNet":
+        raise NotImplementedError("train_model drives the PhysioNet time-series path")
+    seed_fix = 4                                                   # :217
+    args.seed_fix = seed_fix
+    torch.manual_seed(seed_fix)
+    random.seed(seed_fix)
+    np.random.seed(seed_fix)
+    args.device = device
+    if not hasattr(args, "classical_space"):
+        args.classical_space = False
+    loaders = dlp.physionet_dataloader(args, dataset)
+    train_loader, train_labels = loaders.run("train", seed_fix)
+    test_loader = loaders.run("valid" if args.valid else "test", None)
+    args.sig_len = int(train_loader.data.shape[-1])
+    torch.manual_seed(seed_fix)                                    # :293 initial weights
+    model = build_model(args).to(device)
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank, world = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
+    model = wrap_distributed(model, device)
+    args.num_steps = args.num_epochs * (len(train_loader.dataset) // args.batch_size)   # :390
+    criterion = SELCLoss(train_labels, args.num_classes, es=selc_turning_point(args), device=device)
+    optimizer, scheduler = make_optimizer(args, model)
+    step_counter = step_counter_class()
+    graphed = None
+    if use_graph and not distributed and device.type == "cuda" and "(salopt" not in args.method \
+            and args.num_epochs <= criterion.es:
+        graphed = GraphedTrainStep(args, model, optimizer, scheduler, criterion, device,
+                                   args.batch_size, args.num_channels, args.sig_len)
+    perf = {k: [] for k in ("epochs", "steps", "train_loss", "train_accuracy", "test_accuracy",
+                            "test_loss", "test_sensitivity", "test_specificity", "test_f1",
+                            "test_rocauc", "times")}
+    plot_epochs = set(np.linspace(1, args.num_epochs, 11).astype("int").tolist())       # :424
+    args.depth = 0
+    t_sum = 0.0
+    for epoch in range(1, args.num_epochs + 1):
+        t0 = _time.time()
+        model.train()
+        torch.manual_seed(args.seed * 635410 + step_counter.count)                      # :497
+        stats = {"loss_sum": torch.zeros((), device=device),
+                 "hits": torch.zeros((), device=device, dtype=torch.long), "seen": 0}
+        n_batches = 0
+        for batch in train_loader:
+            if distributed:
+                batch = shard_batch(batch, rank, world)
+            if graphed is not None:
+                graphed.step(batch, epoch, step_counter, stats)
+            else:
+                train_step(args, model, batch, device, optimizer, scheduler, criterion, epoch,
+                           step_counter, stats)
+            n_batches += 1
+            if not step_counter.count < args.num_steps:
+                break
+        t_sum += _time.time() - t0
+        if epoch in plot_epochs:
+            ev = test_data_accuracy(args, model, test_loader, device, criterion)
+            perf["epochs"].append(epoch)
+            perf["steps"].append(step_counter.count)
+            perf["train_loss"].append(float(stats["loss_sum"]) / max(1, n_batches))
+            perf["train_accuracy"].append(100.0 * float(stats["hits"]) / max(1, stats["seen"]))
+            for k_out, k_in in (("test_accuracy", "accuracy"), ("test_loss", "loss"),
+                                ("test_sensitivity", "sensitivity"), ("test_specificity", "specificity"),
+                                ("test_f1", "f1"), ("test_rocauc", "rocauc")):
+                perf[k_out].append(ev[k_in])
+            perf["times"].append(t_sum)
+            if rank == 0 and log is not None:
+                log(f"epoch {epoch:3d} step {step_counter.count:6d} train loss "
+                    f"{perf['train_loss'][-1]:.4f} acc {perf['train_accuracy'][-1]:.1f}%  "
+                    f"test acc {ev['accuracy']:.1f}%")
+    out_dir = getattr(args, "EXPERIMENTS", None)
+    if out_dir and rank == 0:
+        exp = _sal.experiment_dir(args)
+        os.makedirs(exp, exist_ok=True)
+        inner = model.module if hasattr(model, "module") else model
+        torch.save({"module." + k: v for k, v in inner.state_dict().items()},
+                   os.path.join(exp, "model.pth"))
+    perf["model"] = model
+    return perf
+
+
 class SyntheticCycleLoader:
     """Stands in for physionet_dataloader(...).run('train') (dataloader_physionet.py:204-229):
     yields the same 6-tuple (data, target, frames, wav, sig_qual, index) of CPU tensors, shuffled
