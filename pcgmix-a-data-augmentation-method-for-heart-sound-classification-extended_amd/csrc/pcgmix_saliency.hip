@@ -17,7 +17,8 @@
 
 namespace pcgmix {
 
-constexpr int kSalThreads = 256;
+constexpr int kSalThreads = 256;   // saliency_post: one block per row
+constexpr int kDispThreads = 1024; // displacement scan: all candidates of a (sample, state) at once
 constexpr int kMaxTaps = 255;
 
 struct Taps {
@@ -168,13 +169,13 @@ __device__ __forceinline__ float pw_sum(F elem, int n) {
 // One block per (state k, sample b); candidates d are strided over the lanes.
 // LDS: lng[nL] (the longer state's saliency), sht[nS] (the shorter one's).
 template <int MODE>  // 0: envelope (max), 1: lambda-weighted sum
-__global__ __launch_bounds__(kSalThreads) void salopt_disp_kernel(
+__global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
     const float* __restrict__ sal, const int32_t* __restrict__ frames,
     const int32_t* __restrict__ mix_idx, float lam, float oml, int32_t* __restrict__ disp, int B,
     int T) {
   extern __shared__ __align__(16) float smem[];
-  __shared__ float best_v[kSalThreads / 64];
-  __shared__ int best_d[kSalThreads / 64];
+  __shared__ float best_v[kDispThreads / 64];
+  __shared__ int best_d[kDispThreads / 64];
   const int k = blockIdx.x, b = blockIdx.y;
   int m = mix_idx[b];
   m = (m < 0 || m >= B) ? b : m;
@@ -195,13 +196,13 @@ __global__ __launch_bounds__(kSalThreads) void salopt_disp_kernel(
   const float* gs = sal + (size_t)(own_longer ? m : b) * T + (own_longer ? a2 : a1);
   float* lng = smem;
   float* sht = smem + nL;
-  for (int i = threadIdx.x; i < nL; i += kSalThreads) lng[i] = gl[i];
-  for (int i = threadIdx.x; i < nS; i += kSalThreads) sht[i] = gs[i];
+  for (int i = threadIdx.x; i < nL; i += kDispThreads) lng[i] = gl[i];
+  for (int i = threadIdx.x; i < nS; i += kDispThreads) sht[i] = gs[i];
   __syncthreads();
 
   float bv = -INFINITY;
   int bd = 0x7fffffff;
-  for (int d = threadIdx.x; d <= nL - nS; d += kSalThreads) {
+  for (int d = threadIdx.x; d <= nL - nS; d += kDispThreads) {
     auto mid = [&](int i) -> float {
       const float l = lng[d + i], s = sht[i];
       if (MODE == 0) return fmaxf(l, s);
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(kSalThreads) void salopt_disp_kernel(
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int i = 1; i < kSalThreads / 64; ++i)
+    for (int i = 1; i < kDispThreads / 64; ++i)
       if (best_v[i] > bv || (best_v[i] == bv && best_d[i] < bd)) {
         bv = best_v[i];
         bd = best_d[i];
@@ -299,7 +300,7 @@ extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
     attr_set = true;
   }
   const float oml = 1.0f - lam;
-  dim3 grid(4, (unsigned)B), block(kSalThreads);
+  dim3 grid(4, (unsigned)B), block(kDispThreads);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (mode == 0)
     hipLaunchKernelGGL(salopt_disp_kernel<0>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
