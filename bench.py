@@ -471,9 +471,10 @@ def main():
         run_augment_steps(a.method, data, tgt, frames, wav, device, a.steps, 0, barrier)
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumtime").print_stats(25)
-    kt = KernelTimer()
-    dt, _ = run_augment_steps(a.method, data, tgt, frames, wav, device, a.steps, a.warmup,
-                              barrier, timer=kt)
+    # the timed region carries nothing but the drop-in calls (no event recording inside it)
+    dt, _ = run_augment_steps(a.method, data, tgt, frames, wav, device, a.steps, a.warmup, barrier)
+    kt = KernelTimer()              # separate short run: event pairs around the in-step launches
+    run_augment_steps(a.method, data, tgt, frames, wav, device, 50, 5, lambda: None, timer=kt)
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -229,6 +229,17 @@ int pcgmix_potes_stack_bwd_f32(const float* x, const float* grad_h2, const float
                                const float* b1, const float* w2, const float* b2, float* partial,
                                float* grads, int N, int T, pcgmix_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Skinny linear layer forward (the Potes head's `dimreduc`, models.py:376, 430).    [device]
+ *
+ *   z (B,O) = h (B,K) . W (O,K)^T + bias (O)      O in {8, 16, 20, 32}, K % 4 == 0
+ * Split-K with a deterministic two-stage reduction; `partial` is caller-provided scratch of
+ * pcgmix_skinny_linear_splits(B,K) * B * O floats.  h and W must be 16-byte aligned.
+ */
+int pcgmix_skinny_linear_splits(int B, int K);
+int pcgmix_skinny_linear_fwd_f32(const float* h, const float* W, const float* bias, float* partial,
+                                 float* z, int B, int K, int O, pcgmix_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -541,6 +541,69 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------- dimreduc
+// z[B][O] = h[B][K] . W[O][K]^T + bias for a SKINNY output (O <= 32; the Potes head is 19968 -> 20,
+// models.py:376).  hipBLASLt runs this shape as 32 workgroups with no split-K: 53 us at bs=256
+// for a 20 MB read.  Here: two batch rows per block, K split over gridDim.y, 16-byte loads of h
+// (HBM) and W (L2), per-lane partial dot products, wave-shuffle + LDS reduction, per-split
+// partials summed in a fixed order by a second kernel (deterministic).
+constexpr int kSkinnyMaxO = 32;
+constexpr int kSkinnyRows = 2;
+
+template <int O>
+__global__ __launch_bounds__(kPotThreads) void skinny_linear_partial_kernel(
+    const float* __restrict__ h, const float* __restrict__ W, float* __restrict__ partial, int B,
+    int K, int kchunk) {
+  __shared__ float red[kPotThreads / 64][kSkinnyRows * O];
+  const int r0 = blockIdx.x * kSkinnyRows, ks = blockIdx.y;
+  const int k_lo = ks * kchunk, k_hi = (k_lo + kchunk < K) ? k_lo + kchunk : K;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[kSkinnyRows][O];
+#pragma unroll
+  for (int r = 0; r < kSkinnyRows; ++r)
+#pragma unroll
+    for (int o = 0; o < O; ++o) acc[r][o] = 0.f;
+  const bool row1 = r0 + 1 < B;
+  const float* h0 = h + (size_t)r0 * K;
+  const float* h1 = h + (size_t)(row1 ? r0 + 1 : r0) * K;
+  for (int j = k_lo + 4 * (int)threadIdx.x; j < k_hi; j += 4 * kPotThreads) {
+    const f4 a = *reinterpret_cast<const f4*>(h0 + j);
+    const f4 b = *reinterpret_cast<const f4*>(h1 + j);
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      const f4 w = *reinterpret_cast<const f4*>(W + (size_t)o * K + j);
+      acc[0][o] = fmaf(a.w, w.w, fmaf(a.z, w.z, fmaf(a.y, w.y, fmaf(a.x, w.x, acc[0][o]))));
+      acc[1][o] = fmaf(b.w, w.w, fmaf(b.z, w.z, fmaf(b.y, w.y, fmaf(b.x, w.x, acc[1][o]))));
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kSkinnyRows; ++r)
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+      float v = acc[r][o];
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+      if (lane == 0) red[wave][r * O + o] = v;
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kSkinnyRows * O; e += kPotThreads) {
+    const int r = e / O, o = e - r * O;
+    if (r0 + r < B)
+      partial[((size_t)ks * B + r0 + r) * O + o] =
+          (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  }
+}
+
+__global__ void skinny_linear_reduce_kernel(const float* __restrict__ partial,
+                                            const float* __restrict__ bias, float* __restrict__ z,
+                                            int B, int O, int KS) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * O) return;
+  float v = bias ? bias[i % O] : 0.f;
+  for (int ks = 0; ks < KS; ++ks) v += partial[(size_t)ks * B * O + i];
+  z[i] = v;
+}
+
 // Sum the per-block partial vectors in a fixed order: grads[e] = sum_g partial[g][e].
 __global__ __launch_bounds__(kPotThreads) void potes_reduce_kernel(const float* __restrict__ partial,
                                                                    float* __restrict__ grads,
@@ -611,5 +674,44 @@ extern "C" int pcgmix_potes_stack_bwd_f32(const float* x, const float* grad_h2, 
   hipLaunchKernelGGL(potes_bwd_kernel, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2, w1,
                      b1, w2, b2, partial, N, T);
   hipLaunchKernelGGL(potes_reduce_kernel, dim3(kNGrad), dim3(kPotThreads), 0, s, partial, grads, G);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pcgmix_skinny_linear_splits(int B, int K) {
+  if (B <= 0 || K <= 0) return 0;
+  // enough blocks to fill 256 CUs twice, chunks of whole 1024-element strides
+  int ks = (2 * 256 * pcgmix::kSkinnyRows + B - 1) / B;
+  const int max_ks = (K + 1023) / 1024;
+  ks = ks < 1 ? 1 : (ks > max_ks ? max_ks : ks);
+  return ks;
+}
+
+extern "C" int pcgmix_skinny_linear_fwd_f32(const float* h, const float* W, const float* bias,
+                                            float* partial, float* z, int B, int K, int O,
+                                            pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!h || !W || !partial || !z || B <= 0 || K <= 0 || (K & 3) || O <= 0 || O > kSkinnyMaxO)
+    return hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(W)) & 15)
+    return hipErrorInvalidValue;
+  const int KS = pcgmix_skinny_linear_splits(B, K);
+  int kchunk = (K + KS - 1) / KS;
+  kchunk = ((kchunk + 1023) / 1024) * 1024;
+  const int ks_eff = (K + kchunk - 1) / kchunk;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)((B + kSkinnyRows - 1) / kSkinnyRows), (unsigned)ks_eff), block(kPotThreads);
+#define PCGMIX_SKINNY(OO)                                                                          \
+  hipLaunchKernelGGL((skinny_linear_partial_kernel<OO>), grid, block, 0, s, h, W, partial, B, K, kchunk)
+  if (O == 20) PCGMIX_SKINNY(20);
+  else if (O <= 8) {
+    if (O != 8) return hipErrorInvalidValue;
+    PCGMIX_SKINNY(8);
+  } else if (O == 16) PCGMIX_SKINNY(16);
+  else if (O == 32) PCGMIX_SKINNY(32);
+  else return hipErrorInvalidValue;
+#undef PCGMIX_SKINNY
+  const int n = B * O;
+  hipLaunchKernelGGL(skinny_linear_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                     partial, bias, z, B, O, ks_eff);
   return (int)hipGetLastError();
 }

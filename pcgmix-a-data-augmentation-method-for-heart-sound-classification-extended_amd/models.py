@@ -66,6 +66,37 @@ class PotesStackFunction(torch.autograd.Function):
         return gx, gw1, gb1, gw2, gb2
 
 
+class SkinnyLinearFunction(torch.autograd.Function):
+    """y = x W^T + b for a tall-K, skinny-N layer (the Potes ``dimreduc`` 19968 -> 20) through
+    ``pcgmix_skinny_linear_fwd_f32`` (split-K, deterministic); the backward GEMMs are well served
+    by hipBLASLt and stay in torch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, K = x.shape
+        O = weight.shape[0]
+        lib = _lib.load()
+        xc, wc = x.contiguous(), weight.detach().contiguous()
+        ks = lib.pcgmix_skinny_linear_splits(B, K)
+        partial = torch.empty((ks, B, O), dtype=torch.float32, device=x.device)
+        z = torch.empty((B, O), dtype=torch.float32, device=x.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(lib.pcgmix_skinny_linear_fwd_f32(
+            xc.data_ptr(), wc.data_ptr(), bias.detach().data_ptr() if bias is not None else None,
+            partial.data_ptr(), z.data_ptr(), B, K, O, stream), "pcgmix_skinny_linear_fwd_f32")
+        ctx.save_for_backward(xc, wc)
+        ctx.has_bias = bias is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, w = ctx.saved_tensors
+        gx = gz.mm(w) if ctx.needs_input_grad[0] else None
+        gw = gz.t().mm(x) if ctx.needs_input_grad[1] else None
+        gb = gz.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
 def _potes_block(c_in: int, c_out: int, dropout: float = 0.0) -> nn.Sequential:
     # Conv1d(k=5, padding=1) + ReLU + MaxPool(2) [+ Dropout]   (reference models.py:359-365)
     layers = [nn.Conv1d(c_in, c_out, kernel_size=5, padding=1), nn.ReLU(inplace=True),
@@ -126,8 +157,11 @@ class CNN_potes(nn.Module):
         else:
             z = self.cnn1(rows.unsqueeze(1))
         z = z.reshape(B, -1)
-        z = F.relu(self.dimreduc(z))
-        return self.dropout(z)
+        if self._fused(x) and self.dimreduc.out_features == 20 and z.shape[1] % 4 == 0:
+            z = SkinnyLinearFunction.apply(z, self.dimreduc.weight, self.dimreduc.bias)
+        else:
+            z = self.dimreduc(z)
+        return self.dropout(F.relu(z))
 
     def forward(self, x, depth=None, pass_part=None):
         if pass_part == "first":

@@ -47,3 +47,20 @@ print('shuffle     ', (time.perf_counter() - t) / N * 1e6)
 t = time.perf_counter()
 for s in range(N): np.random.seed(s); np.random.beta(1.0, 1.0)
 print('seed+beta   ', (time.perf_counter() - t) / N * 1e6)
+# the drop-in call itself
+class Args: method = 'durratiomixup'; num_classes = 2
+class SC:
+    count = 0
+sc = SC()
+for name, extra in (('augment()', None), ('augment()+event pairs', 'ev')):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for it in range(N):
+        if extra:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        out = A.augment(Args, data, tgt, fr, wav, sc, None, dev, '')
+        if extra:
+            e1.record()
+        sc.count += 1
+    torch.cuda.synchronize()
+    print(f"{name:24s} {(time.perf_counter() - t0) / N * 1e6:7.1f} us/step")

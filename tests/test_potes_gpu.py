@@ -97,3 +97,19 @@ def test_input_gradient_matches_torch(B, T, device):
     m.fused = False
     m(xb)[:, 0].sum().backward()
     assert torch.allclose(xa.grad, xb.grad, rtol=1e-3, atol=1e-5 * float(xb.grad.abs().max()) + 1e-9)
+
+
+@pytest.mark.parametrize("B,K", [(256, 19968), (32, 9968), (7, 4096), (1, 1028), (3, 19968)])
+def test_skinny_linear_matches_torch(B, K, device):
+    torch.manual_seed(B + K)
+    lin = torch.nn.Linear(K, 20).to(device)
+    x = torch.randn(B, K, device=device, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    z_t = lin(x)
+    z_f = models.SkinnyLinearFunction.apply(x2, lin.weight, lin.bias)
+    assert torch.allclose(z_f, z_t, rtol=1e-4, atol=1e-4 * float(z_t.abs().max()))
+    r = torch.randn_like(z_t)
+    g_t = torch.autograd.grad((z_t * r).sum(), [x, lin.weight, lin.bias])
+    g_f = torch.autograd.grad((z_f * r).sum(), [x2, lin.weight, lin.bias])
+    for a, b in zip(g_f, g_t):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()) + 1e-7)
