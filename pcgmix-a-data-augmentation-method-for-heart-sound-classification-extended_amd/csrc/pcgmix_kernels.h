@@ -1,5 +1,24 @@
 // Internal header shared by the kernel translation units of libpcgmix_hip.so.
 #ifndef PCGMIX_KERNELS_H
 #define PCGMIX_KERNELS_H
+#include <hip/hip_runtime.h>
+
 #include "pcgmix_hip.h"   // public C ABI (include/)
+
+namespace pcgmix {
+
+// Large dynamic-LDS opt-in is a per-device property of the kernel: raise it once per
+// (kernel, device) — `done` is a bitmask indexed by the current device (<= 64 devices).
+inline hipError_t allow_large_lds(const void* kernel, unsigned long long* done, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (*done & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) *done |= bit;
+  return e;
+}
+
+}  // namespace pcgmix
 #endif

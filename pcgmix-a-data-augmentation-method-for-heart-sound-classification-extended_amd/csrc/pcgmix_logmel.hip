@@ -343,13 +343,10 @@ extern "C" int pcgmix_logmel_f32(const float* x, const int32_t* frames, const vo
   if (B == 0) return hipSuccess;
   const MelLayout L = mel_layout(T, n_fft, hop, n_mels, W);
   if (L.total > 158 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(logmel_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static unsigned long long lds_ok = 0;
+  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(logmel_kernel), &lds_ok,
+                                     158 * 1024))
+    return (int)e;
   hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)B), dim3(kMelThreads), (size_t)L.total,
                      reinterpret_cast<hipStream_t>(stream), x, frames,
                      static_cast<const unsigned char*>(tables), spec, frames_out, B, T, n_fft, hop,

@@ -267,13 +267,10 @@ extern "C" int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames
     taps.w[j] = (float)w;
   }
   for (int j = ksize; j < kMaxTaps; ++j) taps.w[j] = 0.f;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(saliency_post_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static unsigned long long lds_ok = 0;
+  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(saliency_post_kernel), &lds_ok,
+                                     150 * 1024))
+    return (int)e;
   hipLaunchKernelGGL(saliency_post_kernel, dim3((unsigned)B), dim3(kSalThreads), lds,
                      reinterpret_cast<hipStream_t>(stream), grad, frames, sal, taps, ksize, B, C,
                      T);
@@ -289,16 +286,13 @@ extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
   if (B == 0) return hipSuccess;
   const size_t lds = sizeof(float) * (size_t)2 * T;
   if (lds > 150 * 1024) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(salopt_disp_kernel<0>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(salopt_disp_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static unsigned long long lds_ok0 = 0, lds_ok1 = 0;
+  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(salopt_disp_kernel<0>), &lds_ok0,
+                                     150 * 1024))
+    return (int)e;
+  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(salopt_disp_kernel<1>), &lds_ok1,
+                                     150 * 1024))
+    return (int)e;
   const float oml = 1.0f - lam;
   dim3 grid(4, (unsigned)B), block(kDispThreads);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
