@@ -232,7 +232,7 @@ int pcgmix_potes_stack_bwd_f32(const float* x, const float* grad_h2, const float
 /* ------------------------------------------------------------------------------------------
  * Skinny linear layer forward (the Potes head's `dimreduc`, models.py:376, 430).    [device]
  *
- *   z (B,O) = h (B,K) . W (O,K)^T + bias (O)      O in {8, 16, 20, 32}, K % 4 == 0
+ *   z (B,O) = h (B,K) . W (O,K)^T + bias (O)      O in {8, 16, 20}, K % 4 == 0
  * Split-K with a deterministic two-stage reduction; `partial` is caller-provided scratch of
  * pcgmix_skinny_linear_splits(B,K) * B * O floats.  h and W must be 16-byte aligned.
  */

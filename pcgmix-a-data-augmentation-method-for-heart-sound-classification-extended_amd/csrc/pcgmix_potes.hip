@@ -548,49 +548,48 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_kernel(
 // (HBM) and W (L2), per-lane partial dot products, wave-shuffle + LDS reduction, per-split
 // partials summed in a fixed order by a second kernel (deterministic).
 constexpr int kSkinnyMaxO = 32;
-constexpr int kSkinnyRows = 2;
+constexpr int kSkinnyRows = 16;     // batch rows per block
+constexpr int kSkinnyChunk = 1024;  // K elements per block (its W slice sits in LDS: O * 4 KB)
 
+// Block = 16 rows x one 1024-wide K chunk.  Thread (r = tid >> 4, jl = tid & 15) owns row r and
+// the float4 columns jl, jl+16, ...: h comes from HBM in 256-byte row segments, W from the LDS
+// copy (the 16 rows read the same address: broadcast), O private accumulators, then a 16-lane
+// shuffle reduction.  W is read from L2 once per block (B/16 * 1.6 MB in total).
 template <int O>
 __global__ __launch_bounds__(kPotThreads) void skinny_linear_partial_kernel(
     const float* __restrict__ h, const float* __restrict__ W, float* __restrict__ partial, int B,
-    int K, int kchunk) {
-  __shared__ float red[kPotThreads / 64][kSkinnyRows * O];
+    int K) {
+  __shared__ __align__(16) float wl[O * kSkinnyChunk];
   const int r0 = blockIdx.x * kSkinnyRows, ks = blockIdx.y;
-  const int k_lo = ks * kchunk, k_hi = (k_lo + kchunk < K) ? k_lo + kchunk : K;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float acc[kSkinnyRows][O];
+  const int k_lo = ks * kSkinnyChunk;
+  const int kn = (K - k_lo < kSkinnyChunk) ? K - k_lo : kSkinnyChunk;   // multiple of 4
+  for (int i = threadIdx.x * 4; i < O * kSkinnyChunk; i += kPotThreads * 4) {
+    const int o = i / kSkinnyChunk, j = i - o * kSkinnyChunk;
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (j < kn) v = *reinterpret_cast<const f4*>(W + (size_t)o * K + k_lo + j);
+    *reinterpret_cast<f4*>(wl + i) = v;
+  }
+  __syncthreads();
+  const int r = threadIdx.x >> 4, jl = threadIdx.x & 15;
+  const int row = r0 + r;
+  const float* hr = h + (size_t)(row < B ? row : B - 1) * K + k_lo;
+  float acc[O];
 #pragma unroll
-  for (int r = 0; r < kSkinnyRows; ++r)
-#pragma unroll
-    for (int o = 0; o < O; ++o) acc[r][o] = 0.f;
-  const bool row1 = r0 + 1 < B;
-  const float* h0 = h + (size_t)r0 * K;
-  const float* h1 = h + (size_t)(row1 ? r0 + 1 : r0) * K;
-  for (int j = k_lo + 4 * (int)threadIdx.x; j < k_hi; j += 4 * kPotThreads) {
-    const f4 a = *reinterpret_cast<const f4*>(h0 + j);
-    const f4 b = *reinterpret_cast<const f4*>(h1 + j);
+  for (int o = 0; o < O; ++o) acc[o] = 0.f;
+  for (int j = jl * 4; j < kn; j += 64) {
+    const f4 a = *reinterpret_cast<const f4*>(hr + j);
 #pragma unroll
     for (int o = 0; o < O; ++o) {
-      const f4 w = *reinterpret_cast<const f4*>(W + (size_t)o * K + j);
-      acc[0][o] = fmaf(a.w, w.w, fmaf(a.z, w.z, fmaf(a.y, w.y, fmaf(a.x, w.x, acc[0][o]))));
-      acc[1][o] = fmaf(b.w, w.w, fmaf(b.z, w.z, fmaf(b.y, w.y, fmaf(b.x, w.x, acc[1][o]))));
+      const f4 w = *reinterpret_cast<const f4*>(wl + o * kSkinnyChunk + j);
+      acc[o] = fmaf(a.w, w.w, fmaf(a.z, w.z, fmaf(a.y, w.y, fmaf(a.x, w.x, acc[o]))));
     }
   }
 #pragma unroll
-  for (int r = 0; r < kSkinnyRows; ++r)
+  for (int o = 0; o < O; ++o) {
+    float v = acc[o];
 #pragma unroll
-    for (int o = 0; o < O; ++o) {
-      float v = acc[r][o];
-#pragma unroll
-      for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
-      if (lane == 0) red[wave][r * O + o] = v;
-    }
-  __syncthreads();
-  for (int e = threadIdx.x; e < kSkinnyRows * O; e += kPotThreads) {
-    const int r = e / O, o = e - r * O;
-    if (r0 + r < B)
-      partial[((size_t)ks * B + r0 + r) * O + o] =
-          (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    for (int s = 8; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);   // the 16 lanes of this row
+    if (jl == 0 && row < B) partial[((size_t)ks * B + row) * O + o] = v;
   }
 }
 
@@ -679,11 +678,7 @@ extern "C" int pcgmix_potes_stack_bwd_f32(const float* x, const float* grad_h2, 
 
 extern "C" int pcgmix_skinny_linear_splits(int B, int K) {
   if (B <= 0 || K <= 0) return 0;
-  // enough blocks to fill 256 CUs twice, chunks of whole 1024-element strides
-  int ks = (2 * 256 * pcgmix::kSkinnyRows + B - 1) / B;
-  const int max_ks = (K + 1023) / 1024;
-  ks = ks < 1 ? 1 : (ks > max_ks ? max_ks : ks);
-  return ks;
+  return (K + pcgmix::kSkinnyChunk - 1) / pcgmix::kSkinnyChunk;   // one partial per K chunk
 }
 
 extern "C" int pcgmix_skinny_linear_fwd_f32(const float* h, const float* W, const float* bias,
@@ -695,23 +690,19 @@ extern "C" int pcgmix_skinny_linear_fwd_f32(const float* h, const float* W, cons
   if ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(W)) & 15)
     return hipErrorInvalidValue;
   const int KS = pcgmix_skinny_linear_splits(B, K);
-  int kchunk = (K + KS - 1) / KS;
-  kchunk = ((kchunk + 1023) / 1024) * 1024;
-  const int ks_eff = (K + kchunk - 1) / kchunk;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid((unsigned)((B + kSkinnyRows - 1) / kSkinnyRows), (unsigned)ks_eff), block(kPotThreads);
-#define PCGMIX_SKINNY(OO)                                                                          \
-  hipLaunchKernelGGL((skinny_linear_partial_kernel<OO>), grid, block, 0, s, h, W, partial, B, K, kchunk)
-  if (O == 20) PCGMIX_SKINNY(20);
-  else if (O <= 8) {
-    if (O != 8) return hipErrorInvalidValue;
-    PCGMIX_SKINNY(8);
-  } else if (O == 16) PCGMIX_SKINNY(16);
-  else if (O == 32) PCGMIX_SKINNY(32);
-  else return hipErrorInvalidValue;
-#undef PCGMIX_SKINNY
+  dim3 grid((unsigned)((B + kSkinnyRows - 1) / kSkinnyRows), (unsigned)KS), block(kPotThreads);
+  if (O == 20) {
+    hipLaunchKernelGGL((skinny_linear_partial_kernel<20>), grid, block, 0, s, h, W, partial, B, K);
+  } else if (O == 8) {
+    hipLaunchKernelGGL((skinny_linear_partial_kernel<8>), grid, block, 0, s, h, W, partial, B, K);
+  } else if (O == 16) {
+    hipLaunchKernelGGL((skinny_linear_partial_kernel<16>), grid, block, 0, s, h, W, partial, B, K);
+  } else {
+    return hipErrorInvalidValue;
+  }
   const int n = B * O;
   hipLaunchKernelGGL(skinny_linear_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                     partial, bias, z, B, O, ks_eff);
+                     partial, bias, z, B, O, KS);
   return (int)hipGetLastError();
 }
