@@ -183,3 +183,18 @@ def test_two_streams_and_second_device_free(device):
         y1, _ = _aug("durmixmagwarp(0.2,4)", x, frames, labels, wav, 9, device)
     s.synchronize()
     assert np.array_equal(y0, y1)
+
+
+def test_full_size_2d_against_oracle(device):
+    """BASELINE.json configs[3] shape: 2D durratiomixup on (256,1,128,128) spectrogram columns."""
+    from pcgmix_amd import frontend
+    B = 256
+    _, frames, labels, wav = synthetic.make_batch(B, 1, 5000, sample_rate=2000, seed=21)
+    fs = frontend.spec_frames(frames, 5000, 34)
+    rs = np.random.RandomState(5)
+    x = rs.standard_normal((B, 1, 128, 128)).astype(np.float32)
+    for method, step in (("durratiomixup", 2), ("durmixcutout(0.4,0.3)", 7)):
+        ref = O.augment(method, x, labels, fs, wav, step)
+        g = dict(x=x, labels=labels, frames=fs, wav=wav, step=step, method=method)
+        _, _, (y, _, mix, _) = run(augmentations2d, g, device)
+        assert np.array_equal(mix, ref["mix"]) and np.array_equal(y.cpu().numpy(), ref["y"])

@@ -99,3 +99,23 @@ def test_bad_arguments(device):
                                         ctypes.c_double(12.0), 1, 1, 8, None) != 0     # even ksize
     assert lib.pcgmix_salopt_disp_f32(z.data_ptr(), z.data_ptr(), z.data_ptr(), ctypes.c_float(0.5),
                                       2, z.data_ptr(), 1, 8, None) != 0               # bad mode
+
+
+def test_displacements_full_batch_vs_oracle(device):
+    """BASELINE.json configs[2] size (B=256, T=5000): every displacement equals the oracle's."""
+    from pcgmix_amd import synthetic
+    B, T = 256, 5000
+    frames, labels, wav = synthetic.make_index_data(B, T, sample_rate=2000, seed=9)
+    rs = np.random.RandomState(3)
+    sal = rs.rand(B, T).astype(np.float32) ** 2
+    sal[np.arange(T)[None, :] >= frames[:, 4:5]] = 0
+    mix = rs.permutation(B)
+    lam = np.float32(0.6180339)
+    lam_np = np.full((1, 1), lam, dtype=np.float32)
+    fr, mx = dev_i32(frames, device), dev_i32(mix, device)
+    sal_d = torch.from_numpy(sal).to(device)
+    for mode, tag in ((0, "(saloptenv)"), (1, "(saloptsum)")):
+        ref = np.stack([O.salopt_displacements(sal[i], sal[mix[i]], frames[i], frames[mix[i]], lam_np, tag)
+                        for i in range(0, B, 4)])                       # every 4th sample: ~4 s of numpy
+        got = saliency.optimal_displacements(sal_d, fr.data_ptr(), mx.data_ptr(), float(lam), mode, B, T)
+        assert np.array_equal(got.cpu().numpy().astype(np.int64)[::4], ref)
