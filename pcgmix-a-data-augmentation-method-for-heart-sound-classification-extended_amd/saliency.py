@@ -28,12 +28,15 @@ from . import _lib
 
 _INJECTED: Optional[torch.nn.Module] = None
 _LOADED: dict = {}          # checkpoint path -> (mtime, model)
+_GRAPHS: dict = {}          # (id(model), shape, classes, k) -> _SaliencyGraph
+USE_GRAPHS = True           # replay the frozen model's fwd+bwd+post-processing as one hipGraph
 
 
 def set_saliency_model(model: Optional[torch.nn.Module], freeze_copy: bool = True) -> None:
     """Use ``model`` (deep-copied and put in eval mode unless ``freeze_copy`` is False) for all
     following saliency computations; ``None`` restores checkpoint loading."""
     global _INJECTED
+    _GRAPHS.clear()
     if model is None:
         _INJECTED = None
         return
@@ -117,6 +120,39 @@ def saliency_post(grad: torch.Tensor, frames_dev_ptr: int, gauss_k_n: int = 101)
     return sal
 
 
+class _SaliencyGraph:
+    """Forward + input-gradient + post-processing of a FROZEN model for one batch shape, captured
+    once in a hipGraph and replayed: the eager chain is ~40 small launches driven by Python
+    autograd (~0.4 ms of host time per step at bs=256) for ~0.2 ms of GPU work."""
+
+    def __init__(self, model, shape, num_classes, device, gauss_k_n):
+        B, C, T = shape
+        self.model, self.k = model, gauss_k_n
+        self.x = torch.zeros(B, C, T, device=device)
+        self.t = torch.zeros(B, num_classes, dtype=torch.int64, device=device)
+        self.t[:, 0] = 1
+        self.fr = torch.zeros(B, 5, dtype=torch.int32, device=device)
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._run()
+        torch.cuda.current_stream(device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.sal = self._run()
+
+    def _run(self):
+        return saliency_post(input_gradient(self.model, self.x, self.t), self.fr.data_ptr(), self.k)
+
+    def __call__(self, data, target_ohe, frames_dev):
+        self.x.copy_(data, non_blocking=True)
+        self.t.copy_(target_ohe, non_blocking=True)
+        self.fr.copy_(frames_dev, non_blocking=True)
+        self.graph.replay()
+        return self.sal.clone()
+
+
 def get_saliency_maps(args, device, data, target_ohe, frames, dim=1, gauss_k_n=101,
                       model_sal: Optional[torch.nn.Module] = None) -> torch.Tensor:
     """Reference signature plus an optional explicit model.  Returns a (B, T) float32 tensor on
@@ -130,6 +166,15 @@ def get_saliency_maps(args, device, data, target_ohe, frames, dim=1, gauss_k_n=1
     with torch.cuda.device(data.device):
         from .augmentations import upload_array
         fr = upload_array(frames_np.astype(np.int32), data.device)
+        if USE_GRAPHS and target_ohe.dtype == torch.int64 and not torch.cuda.is_current_stream_capturing():
+            key = (id(model), tuple(data.shape), int(target_ohe.shape[1]), gauss_k_n, str(data.device))
+            g = _GRAPHS.get(key)
+            if g is None:
+                if len(_GRAPHS) >= 8:
+                    _GRAPHS.clear()
+                g = _GRAPHS[key] = _SaliencyGraph(model, tuple(data.shape), int(target_ohe.shape[1]),
+                                                  data.device, gauss_k_n)
+            return g(data, target_ohe, fr)
         grad = input_gradient(model, data, target_ohe)
         return saliency_post(grad, fr.data_ptr(), gauss_k_n)
 

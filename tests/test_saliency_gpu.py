@@ -119,3 +119,27 @@ def test_displacements_full_batch_vs_oracle(device):
                         for i in range(0, B, 4)])                       # every 4th sample: ~4 s of numpy
         got = saliency.optimal_displacements(sal_d, fr.data_ptr(), mx.data_ptr(), float(lam), mode, B, T)
         assert np.array_equal(got.cpu().numpy().astype(np.int64)[::4], ref)
+
+
+def test_graphed_saliency_equals_eager(device):
+    """hipGraph replay of the frozen model's fwd + input gradient + post-processing == eager."""
+    from pcgmix_amd import synthetic
+    torch.manual_seed(0)
+    model = models.CNN_potes_TS(4, 2, "PhysioNet").to(device)
+    saliency.set_saliency_model(model)
+    try:
+        outs = {}
+        for use in (False, True):
+            saliency.USE_GRAPHS = use
+            res = []
+            for seed in (1, 2, 3):
+                x, frames, labels, wav = synthetic.make_batch(16, 4, 2500, seed=seed)
+                data = torch.from_numpy(x).to(device)
+                tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)
+                res.append(saliency.get_saliency_maps(Args("x"), device, data, tgt, frames).cpu())
+            outs[use] = res
+        for a, b in zip(outs[False], outs[True]):
+            assert torch.allclose(a, b, atol=1e-6)
+    finally:
+        saliency.USE_GRAPHS = True
+        saliency.set_saliency_model(None)
