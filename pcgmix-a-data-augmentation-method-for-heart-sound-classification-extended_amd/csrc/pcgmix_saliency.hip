@@ -96,26 +96,64 @@ __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
 //              n % 8 tail added sequentially
 //   n > 128    n2 = n/2 - (n/2) % 8;  pairwise(a, n2) + pairwise(a + n2, n - n2)
 // Every operation is a separately rounded float32 add.  `elem(i)` yields element i.
+// 16-byte LDS vector whose address is only 4-byte aligned (a lane's window starts at an
+// arbitrary sample): gfx950 serves it with one ds_read_b128.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// `elem.get(i)` yields element i, `elem.get8(i, v)` the eight elements i .. i+7.
 template <class F>
 __device__ __forceinline__ float pw_leaf(F elem, int start, int n) {
   if (n < 8) {
     float res = 0.f;
-    for (int i = 0; i < n; ++i) res = __fadd_rn(res, elem(start + i));
+    for (int i = 0; i < n; ++i) res = __fadd_rn(res, elem.get(start + i));
     return res;
   }
   float r[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = elem(start + j);
+  elem.get8(start, r);
   int i = 8;
   for (; i < n - (n % 8); i += 8) {
+    float v[8];
+    elem.get8(start + i, v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], elem(start + i + j));
+    for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], v[j]);
   }
   float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
                         __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
-  for (; i < n; ++i) res = __fadd_rn(res, elem(start + i));
+  for (; i < n; ++i) res = __fadd_rn(res, elem.get(start + i));
   return res;
 }
+
+__device__ __forceinline__ void lds_get8(const float* p, float (&v)[8]) {
+  const f4u a = *reinterpret_cast<const f4u*>(p), b = *reinterpret_cast<const f4u*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// Accessors of the three summed sequences.
+struct SeqPlain {               // a[i]
+  const float* a;
+  __device__ __forceinline__ float get(int i) const { return a[i]; }
+  __device__ __forceinline__ void get8(int i, float (&v)[8]) const { lds_get8(a + i, v); }
+};
+template <int MODE>
+struct SeqMid {                 // op(l[i], s[i]); own_longer decides which one is the OWN saliency
+  const float* l;
+  const float* s;
+  float lam, oml;
+  bool own_longer;
+  __device__ __forceinline__ float op(float lv, float sv) const {
+    if (MODE == 0) return fmaxf(lv, sv);
+    const float s1 = own_longer ? lv : sv, s2 = own_longer ? sv : lv;
+    return __fadd_rn(__fmul_rn(s1, lam), __fmul_rn(s2, oml));   // s1*lam + s2*(1-lam)
+  }
+  __device__ __forceinline__ float get(int i) const { return op(l[i], s[i]); }
+  __device__ __forceinline__ void get8(int i, float (&v)[8]) const {
+    float a[8], b[8];
+    lds_get8(l + i, a);
+    lds_get8(s + i, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = op(a[j], b[j]);
+  }
+};
 
 // The split tree is walked without a memory stack: a node is (depth, path bits) and its range is
 // recomputed from the root (<= kPwDepth steps, negligible next to a 128-element leaf); the left
@@ -203,17 +241,11 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   float bv = -INFINITY;
   int bd = 0x7fffffff;
   for (int d = threadIdx.x; d <= nL - nS; d += kDispThreads) {
-    auto mid = [&](int i) -> float {
-      const float l = lng[d + i], s = sht[i];
-      if (MODE == 0) return fmaxf(l, s);
-      // s1*lam + s2*(1-lam): s1 is the OWN sample's saliency in both branches
-      const float s1 = own_longer ? l : s, s2 = own_longer ? s : l;
-      return __fadd_rn(__fmul_rn(s1, lam), __fmul_rn(s2, oml));
-    };
+    const SeqMid<MODE> mid{lng + d, sht, lam, oml, own_longer};
     float cur = pw_sum(mid, nS);
     if (own_longer) {  // np.sum(s1[:d]) + np.sum(mid) + np.sum(s1[d+n2:])   (:76-78, :111-113)
-      const float head = pw_sum([&](int i) -> float { return lng[i]; }, d);
-      const float tail = pw_sum([&](int i) -> float { return lng[d + nS + i]; }, nL - nS - d);
+      const float head = pw_sum(SeqPlain{lng}, d);
+      const float tail = pw_sum(SeqPlain{lng + d + nS}, nL - nS - d);
       cur = __fadd_rn(__fadd_rn(head, cur), tail);
     }
     if (cur > bv) {  // ascending d per lane: strict '>' keeps the first maximum
