@@ -138,16 +138,18 @@ __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
   layer1(W, xs, a1s, nullptr, qlo, kFwdNQ, d.P1);
   __syncthreads();
   // conv 8->4 k5 + ReLU + pool 2: wave = output channel, lane = 4 consecutive pooled outputs
-  const int co = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // co is wave-uniform: its 40 weights come through the scalar cache into SGPRs instead of
+  // costing an LDS broadcast read per FMA pair (the LDS pipe is this kernel's busiest unit)
+  const int co = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   float za[4], zb[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) za[u] = zb[u] = W.b2[co];
+  for (int u = 0; u < 4; ++u) za[u] = zb[u] = b2[co];
 #pragma unroll
   for (int ci = 0; ci < kC1; ++ci) {
     float aw[12], w[kK];
     lds_load12(a1s + ci * kFwdNQ + 8 * lane, aw);
 #pragma unroll
-    for (int k = 0; k < kK; ++k) w[k] = W.w2[(co * kC1 + ci) * kK + k];
+    for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci) * kK + k];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -261,15 +263,15 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
     layer1(W, xs, a1s, sel1, qlo, kBwdNQ, d.P1);
     __syncthreads();
     {  // conv2 + ReLU + pool on the extended range -> dz2 = dL/dz2 (wave = co, 2 pooled per lane)
-      const int co = wave;
+      const int co = __builtin_amdgcn_readfirstlane(wave);
       float aw[8], za[2], zb[2];
-      za[0] = za[1] = zb[0] = zb[1] = W.b2[co];
+      za[0] = za[1] = zb[0] = zb[1] = b2[co];
 #pragma unroll 2
       for (int ci = 0; ci < kC1; ++ci) {
         float w[kK];
         lds_load8(a1s + ci * kBwdNQ + 4 * lane, aw);
 #pragma unroll
-        for (int k = 0; k < kK; ++k) w[k] = W.w2[(co * kC1 + ci) * kK + k];
+        for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci) * kK + k];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -299,14 +301,14 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
       const int r0 = 4 * lane;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const int ci = 2 * wave + c;
+        const int ci = __builtin_amdgcn_readfirstlane(2 * wave + c);
         float da1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int co = 0; co < kC2; ++co) {
           float dw[12], w[kK];
           lds_load12(dz2s + co * kDz2Row + r0, dw);   // dz2 index r+5-k, r = r0+u: r0+1 .. r0+8
 #pragma unroll
-          for (int k = 0; k < kK; ++k) w[k] = W.w2[(co * kC1 + ci) * kK + k];
+          for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci) * kK + k];
 #pragma unroll
           for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -449,15 +451,15 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_kernel(
   layer1(W, xs, a1s, sel1, qlo, kBwdNQ, d.P1);
   __syncthreads();
   {  // conv2 + ReLU + pool on pe = p0-3+pp, pp < 128 -> dz2 (wave = co, 2 pooled per lane)
-    const int co = wave;
+    const int co = __builtin_amdgcn_readfirstlane(wave);
     float aw[8], za[2], zb[2];
-    za[0] = za[1] = zb[0] = zb[1] = W.b2[co];
+    za[0] = za[1] = zb[0] = zb[1] = b2[co];
 #pragma unroll
     for (int ci = 0; ci < kC1; ++ci) {
       float w[kK];
       lds_load8(a1s + ci * kBwdNQ + 4 * lane, aw);
 #pragma unroll
-      for (int k = 0; k < kK; ++k) w[k] = W.w2[(co * kC1 + ci) * kK + k];
+      for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci) * kK + k];
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -486,14 +488,14 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_kernel(
     const int r0 = 4 * lane;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int ci = 2 * wave + c;
+      const int ci = __builtin_amdgcn_readfirstlane(2 * wave + c);
       float da1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int co = 0; co < kC2; ++co) {
         float dw[12], w[kK];
         lds_load12(dz2s + co * kDz2Row + r0, dw);   // dz2 index r+5-k
 #pragma unroll
-        for (int k = 0; k < kK; ++k) w[k] = W.w2[(co * kC1 + ci) * kK + k];
+        for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci) * kK + k];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
