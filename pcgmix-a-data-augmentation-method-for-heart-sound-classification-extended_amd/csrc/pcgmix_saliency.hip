@@ -214,7 +214,11 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   extern __shared__ __align__(16) float smem[];
   __shared__ float best_v[kDispThreads / 64];
   __shared__ int best_d[kDispThreads / 64];
-  const int k = blockIdx.x, b = blockIdx.y;
+  // Sample index fastest, states ordered by expected work (diastole, systole, S1, S2): with the
+  // state as the fast index and a batch that is a multiple of 4, round-robin dispatch handed every
+  // diastole block (the long ones) to the same quarter of the CUs.
+  const int b = blockIdx.x;
+  const int k = (0x2013 >> (4 * blockIdx.y)) & 3;   // blockIdx.y 0,1,2,3 -> state 3,1,0,2
   int m = mix_idx[b];
   m = (m < 0 || m >= B) ? b : m;
   int a1 = frames[b * 5 + k], e1 = frames[b * 5 + k + 1];
@@ -314,7 +318,7 @@ extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
                                       int B, int T, pcgmix_stream_t stream) {
   using namespace pcgmix;
   if (!sal || !frames || !mix_idx || !disp) return hipErrorInvalidValue;
-  if (B < 0 || B > 65535 || T <= 0 || (mode != 0 && mode != 1)) return hipErrorInvalidValue;
+  if (B < 0 || T <= 0 || (mode != 0 && mode != 1)) return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
   const size_t lds = sizeof(float) * (size_t)2 * T;
   if (lds > 150 * 1024) return hipErrorInvalidValue;
@@ -326,7 +330,7 @@ extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
                                      150 * 1024))
     return (int)e;
   const float oml = 1.0f - lam;
-  dim3 grid(4, (unsigned)B), block(kDispThreads);
+  dim3 grid((unsigned)B, 4), block(kDispThreads);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (mode == 0)
     hipLaunchKernelGGL(salopt_disp_kernel<0>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
