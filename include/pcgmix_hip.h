@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 2
+#define PCGMIX_ABI_VERSION 3
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -239,6 +239,20 @@ int pcgmix_potes_stack_bwd_f32(const float* x, const float* grad_h2, const float
 int pcgmix_skinny_linear_splits(int B, int K);
 int pcgmix_skinny_linear_fwd_f32(const float* h, const float* W, const float* bias, float* partial,
                                  float* z, int B, int K, int O, pcgmix_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gradient value clipping + Adam update of one parameter tensor.                    [device]
+ *
+ * Replaces nn.utils.clip_grad_value_(…, grad_clip) followed by torch.optim.Adam.step() with L2
+ * weight decay (train_model.py:557-558, 404-407, 566) for one tensor, in one pass:
+ *   g = clamp(g, -clip, clip) (clip <= 0: no clipping) + weight_decay * p
+ *   m = m + (1-beta1)(g - m);  v = beta2 v + (1-beta2) g^2
+ *   p -= lr / (1-beta1^step) * m / (sqrt(v) / sqrt(1-beta2^step) + eps)          step >= 1
+ * p, m, v are updated in place; g is read only.
+ */
+int pcgmix_adam_clip_f32(float* p, const float* g, float* m, float* v, long long n, float clip,
+                         float lr, float beta1, float beta2, float eps, float weight_decay,
+                         long long step, pcgmix_stream_t stream);
 
 #ifdef __cplusplus
 }

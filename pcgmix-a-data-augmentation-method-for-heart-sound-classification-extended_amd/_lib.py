@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -45,6 +45,9 @@ SIGNATURES = {
     "pcgmix_potes_stack_input_grad_f32": (_c_int, [_ptr] * 7 + [_c_int, _c_int, _ptr]),
     "pcgmix_skinny_linear_splits": (_c_int, [_c_int, _c_int]),
     "pcgmix_skinny_linear_fwd_f32": (_c_int, [_ptr] * 5 + [_c_int, _c_int, _c_int, _ptr]),
+    "pcgmix_adam_clip_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, ctypes.c_longlong, _c_float, _c_float,
+                                      _c_float, _c_float, _c_float, _c_float, ctypes.c_longlong,
+                                      _ptr]),
 }
 
 _lib = None

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cmath>
+
 #include "pcgmix_kernels.h"
 
 namespace pcgmix {
@@ -622,7 +624,56 @@ __global__ __launch_bounds__(kPotThreads) void potes_reduce_kernel(const float* 
   if (threadIdx.x == 0) grads[e] = red[0];
 }
 
+// ---------------------------------------------------------------------------------- optimiser
+// clip_grad_value_ + Adam (L2 weight decay) for one parameter tensor in one pass
+// (train_model.py:557-558, 404-407, 566).  torch's foreach/fused Adam launches 512-thread blocks
+// per 65536-element chunk: the 400k-element `dimreduc.weight` gets 7 blocks (41 us), and value
+// clipping is two more foreach launches.  Same update rule as torch.optim.Adam:
+//   g = clamp(g, -clip, clip) + wd * p;  m = lerp(m, g, 1-b1);  v = b2*v + (1-b2)*g*g
+//   p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p,
+                                                        const float* __restrict__ g,
+                                                        float* __restrict__ m,
+                                                        float* __restrict__ v, long long n,
+                                                        float clip, float wd, float one_m_b1,
+                                                        float b2, float one_m_b2, float step_size,
+                                                        float inv_bc2_sqrt, float eps) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+    const float pi = p[i];
+    gi = fmaf(wd, pi, gi);
+    float mi = m[i], vi = v[i];
+    mi = fmaf(one_m_b1, gi - mi, mi);                 // exp_avg.lerp_(grad, 1 - beta1)
+    vi = fmaf(one_m_b2 * gi, gi, b2 * vi);            // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
 }  // namespace pcgmix
+
+extern "C" int pcgmix_adam_clip_f32(float* p, const float* g, float* m, float* v, long long n,
+                                    float clip, float lr, float beta1, float beta2, float eps,
+                                    float weight_decay, long long step, pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!p || !g || !m || !v || n < 0 || step < 1) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  // bias corrections in float64 on the host, as torch computes them from Python floats
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_bc2_sqrt = (float)(1.0 / std::sqrt(bc2));
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, clip, weight_decay,
+                     1.0f - beta1, beta2, 1.0f - beta2, step_size, inv_bc2_sqrt, eps);
+  return (int)hipGetLastError();
+}
 
 extern "C" int pcgmix_potes_out_len(int T) {
   return T < 14 ? 0 : pcgmix::potes_dims(T).P2;

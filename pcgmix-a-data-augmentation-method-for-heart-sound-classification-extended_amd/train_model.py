@@ -74,6 +74,44 @@ class step_counter_class:
         self.count += 1
 
 
+class ClipAdam(torch.optim.Adam):
+    """``clip_grad_value_(clip)`` + ``torch.optim.Adam`` (L2 weight decay) as one HIP pass per
+    parameter (``pcgmix_adam_clip_f32``).  Same state layout (``step``, ``exp_avg``,
+    ``exp_avg_sq``) and param-group keys as torch's Adam, so OneCycleLR cycles ``lr`` and
+    ``betas`` on it unchanged and checkpoints interchange.  Gradients are NOT modified (torch's
+    clip is in place; nothing downstream of the optimiser step reads them)."""
+
+    def __init__(self, params, lr, weight_decay=0.0, clip_value=0.0, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.clip_value = float(clip_value or 0.0)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                stream = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+                _lib.check(lib.pcgmix_adam_clip_f32(
+                    p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                    p.numel(), ctypes.c_float(self.clip_value), ctypes.c_float(float(group["lr"])),
+                    ctypes.c_float(b1), ctypes.c_float(b2), ctypes.c_float(group["eps"]),
+                    ctypes.c_float(group["weight_decay"]), int(st["step"]), stream),
+                    "pcgmix_adam_clip_f32")
+        return None
+
+
 def selc_turning_point(args) -> int:
     """train_model.py:394-402."""
     if "SELC" in args.method and ("mixup" in args.method or "base" in args.method):
@@ -111,9 +149,12 @@ def make_optimizer(args, model: nn.Module):
     if args.op == "SGD":
         opt = torch.optim.SGD(params, lr=args.lr_max, weight_decay=args.weight_decay)
     elif args.op == "adam":
-        # same update rule; on a GPU the single fused kernel replaces ~10 foreach launches
-        opt = torch.optim.Adam(params, lr=args.lr_max, weight_decay=args.weight_decay,
-                               fused=all(p.is_cuda for p in params))
+        if all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params):
+            # clip + Adam in one HIP pass per tensor (train_step then skips clip_grad_value_)
+            opt = ClipAdam(params, lr=args.lr_max, weight_decay=args.weight_decay,
+                           clip_value=args.grad_clip)
+        else:
+            opt = torch.optim.Adam(params, lr=args.lr_max, weight_decay=args.weight_decay)
     else:
         raise ValueError(args.op)
     sched = None
@@ -160,7 +201,7 @@ def train_step(args, model, batch, device, optimizer, scheduler, criterion, epoc
     args.depth = 0
     loss = criterion(out, target_ohe, indices, epoch, "train")
     loss.backward()
-    if args.grad_clip:
+    if args.grad_clip and not isinstance(optimizer, ClipAdam):      # ClipAdam clips in its kernel
         nn.utils.clip_grad_value_([p for p in model.parameters() if p.grad is not None],
                                   clip_value=args.grad_clip)
     optimizer.step()
@@ -215,7 +256,7 @@ class GraphedTrainStep:
         out = self.model(self.x, depth=0, pass_part="second")
         loss = self.ce(out, self.t)
         loss.backward()
-        if self.args.grad_clip:
+        if self.args.grad_clip and not isinstance(self.opt, ClipAdam):
             nn.utils.clip_grad_value_(self.params, clip_value=self.args.grad_clip)
         return loss.detach(), out.detach()
 

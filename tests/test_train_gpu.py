@@ -133,3 +133,28 @@ def test_train_model_driver_learns_and_saves(use_graph, device, tmp_path):
     assert len(ck) == 1
     sd = torch.load(ck[0], weights_only=True)
     assert all(k.startswith("module.") for k in sd) and "module.cnn1.0.0.weight" in sd
+
+
+def test_clip_adam_matches_torch(device):
+    """pcgmix_adam_clip_f32 == clip_grad_value_ + torch.optim.Adam over several steps, with a
+    OneCycleLR schedule cycling lr and beta1 on both."""
+    torch.manual_seed(0)
+    shapes = [(20, 19968), (8, 1, 5), (20,), (2, 20)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=device)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = tm.ClipAdam(pa, lr=0.01, weight_decay=1e-4, clip_value=0.1)
+    ob = torch.optim.Adam(pb, lr=0.01, weight_decay=1e-4)
+    sa = torch.optim.lr_scheduler.OneCycleLR(oa, max_lr=0.01, total_steps=12)
+    sb = torch.optim.lr_scheduler.OneCycleLR(ob, max_lr=0.01, total_steps=12)
+    for it in range(10):
+        for x, y in zip(pa, pb):
+            g = torch.randn_like(x) * (0.3 if it % 2 else 0.05)
+            x.grad, y.grad = g.clone(), g.clone()
+        torch.nn.utils.clip_grad_value_(pb, 0.1)
+        oa.step(); ob.step(); sa.step(); sb.step()
+        assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
+        assert oa.param_groups[0]["betas"] == ob.param_groups[0]["betas"]
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-6), float((x - y).abs().max())
+    for x, y in zip(pa, pb):
+        assert torch.allclose(oa.state[x]["exp_avg_sq"], ob.state[y]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
