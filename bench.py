@@ -209,21 +209,26 @@ class TrainArgs:
 def train_steps_per_s(method, model_name, B, C, T, rate, device, steps, warmup, barrier, rank,
                       use_graph=True):
     """Full training step (train_model.py:498-582): augment + forward + soft CE + backward +
-    clip + Adam + OneCycleLR, batch resident in HBM, DDP gradient all-reduce when world > 1."""
+    clip + Adam + OneCycleLR, batch resident in HBM.  world > 1: one gradient all-reduce per step
+    (FlatGradSync around the hipGraph; DDP for the eager step)."""
     args = TrainArgs(method, model_name, B, C, T, steps + warmup + 1)
     x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=rate, seed=100 + rank)
     batch = (torch.from_numpy(x).to(device), torch.from_numpy(labels), torch.from_numpy(frames), wav,
              torch.ones(B, dtype=torch.long), torch.arange(B))
     torch.manual_seed(4)
-    model = tm.wrap_distributed(tm.build_model(args).to(device), device)
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    graphed = use_graph and device.type == "cuda"
+    model = tm.build_model(args).to(device)
+    if not graphed:
+        model = tm.wrap_distributed(model, device)
     model.train()
     opt, sched = tm.make_optimizer(args, model)
     crit = tm.SELCLoss(labels, 2, es=args.num_epochs + 1, device=device)
     sc = tm.step_counter_class()
-    import torch.distributed as dist
-    graphed = use_graph and not (dist.is_available() and dist.is_initialized())
     if graphed:
-        g = tm.GraphedTrainStep(args, model, opt, sched, crit, device, B, C, T)
+        g = tm.GraphedTrainStep(args, model, opt, sched, crit, device, B, C, T,
+                                sync=tm.FlatGradSync(model, device) if distributed else None)
         step = lambda: g.step(batch, 0, sc)                                  # noqa: E731
     else:
         step = lambda: tm.train_step(args, model, batch, device, opt, sched, crit, 0, sc)  # noqa: E731
@@ -513,8 +518,18 @@ def main():
     # train step/s (second half of BASELINE.json's metric): 1D-CNN, bs 256 per GPU, DDP if N>1
     train = None
     if not a.no_train:
-        train = train_steps_per_s(a.method, "Potes", B, C, T, rate, device, max(20, a.steps // 4),
-                                  max(5, a.warmup // 2), barrier, rank)
+        try:
+            train = train_steps_per_s(a.method, "Potes", B, C, T, rate, device,
+                                      max(20, a.steps // 4), max(5, a.warmup // 2), barrier, rank)
+        except Exception as e:          # same code on every rank: all ranks fall back together
+            if world == 1:
+                raise
+            print(f"[bench] graphed train step failed on rank {rank}: {e!r}; eager DDP instead",
+                  file=sys.stderr)
+            train = train_steps_per_s(a.method, "Potes", B, C, T, rate, device,
+                                      max(20, a.steps // 4), max(5, a.warmup // 2), barrier, rank,
+                                      use_graph=False)
+            train["graph_error"] = repr(e)
         if world == 1:
             eager = train_steps_per_s(a.method, "Potes", B, C, T, rate, device,
                                       max(20, a.steps // 4), max(5, a.warmup // 2), barrier, rank,

@@ -177,6 +177,53 @@ def wrap_distributed(model: nn.Module, device: torch.device) -> nn.Module:
                                                gradient_as_bucket_view=True)
 
 
+class FlatGradSync:
+    """Gradient averaging over ranks without DDP's autograd hooks, so that forward + backward can
+    live in a hipGraph: the gradients are packed into one flat buffer by ONE concat kernel (inside
+    the captured region), summed by ONE all-reduce (RCCL over xGMI under 'nccl'; 0.8 MB for Potes,
+    9.1 MB for ResNet9-1D — a single message per step, the size the per-link-bound ring wants),
+    and the optimiser then reads views of that buffer.  The caller scales backward by 1/world
+    (``backward_scale``) so the sum IS the mean on every backend.  BatchNorm buffers stay per
+    rank, as under the reference's DataParallel (train_model.py:385)."""
+
+    def __init__(self, model: nn.Module, device: torch.device):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.model, self.device = model, device
+        self.params, self.flat, self.views, self._graph_grads = None, None, None, None
+        if self.world > 1:                              # same start on every rank, as DDP does
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, 0)
+
+    @property
+    def backward_scale(self) -> float:
+        return 1.0 / self.world
+
+    def attach(self):
+        """Call once after a first backward: fixes the set of parameters that receive gradients
+        (CNN_potes allocates cnn2..cnn4 but never uses them) and allocates the flat buffer."""
+        self.params = [p for p in self.model.parameters() if p.grad is not None]
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, device=self.device, dtype=self.params[0].dtype)
+        self.views, o = [], 0
+        for p in self.params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+
+    def pack(self):
+        """Concatenate the fresh gradients into the flat buffer (capturable: one kernel)."""
+        self._graph_grads = [p.grad for p in self.params]            # keep graph memory referenced
+        torch.cat([g.reshape(-1) for g in self._graph_grads], out=self.flat)
+
+    def reduce_and_bind(self):
+        """Sum over ranks and hand the optimiser the averaged gradients."""
+        if self.world > 1:
+            self.dist.all_reduce(self.flat)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+
 def shard_batch(batch, rank: int, world: int):
     """Give rank r the r-th contiguous slice of every per-sample field (drop_last semantics of
     dataloader_physionet.py:227: the remainder is dropped)."""
@@ -186,7 +233,7 @@ def shard_batch(batch, rank: int, world: int):
 
 
 def train_step(args, model, batch, device, optimizer, scheduler, criterion, epoch, step_counter,
-               stats: Optional[dict] = None):
+               stats: Optional[dict] = None, sync: Optional["FlatGradSync"] = None):
     """One iteration of the reference's batch loop (train_model.py:498-582) without host syncs.
     ``batch`` = (data, target, frames, wav, sig_qual, indices) as the reference's loaders yield
     it (dataloader_physionet.py:151-172).  Returns the loss tensor (on device, detached)."""
@@ -200,7 +247,14 @@ def train_step(args, model, batch, device, optimizer, scheduler, criterion, epoc
     out = model(data, depth=getattr(args, "depth", 0), pass_part="second")
     args.depth = 0
     loss = criterion(out, target_ohe, indices, epoch, "train")
-    loss.backward()
+    if sync is None:
+        loss.backward()
+    else:                                   # flat-buffer averaging instead of DDP hooks
+        loss.backward(torch.full_like(loss, sync.backward_scale))
+        if sync.params is None:
+            sync.attach()
+        sync.pack()
+        sync.reduce_and_bind()
     if args.grad_clip and not isinstance(optimizer, ClipAdam):      # ClipAdam clips in its kernel
         nn.utils.clip_grad_value_([p for p in model.parameters() if p.grad is not None],
                                   clip_value=args.grad_clip)
@@ -225,11 +279,13 @@ class GraphedTrainStep:
     Stays eager, around the replay: the augmentation (its index upload and the lambda kernel
     argument change every step; it writes straight into the graph's static input), the optimiser
     (OneCycleLR moves lr AND beta1 every step — host scalars that a captured Adam would freeze)
-    and the scheduler.  Single-process only: under DDP the all-reduce hooks are not captured and
-    the eager ``train_step`` is used.  Needs static shapes (the loaders use drop_last=True)."""
+    and the scheduler.  Under torch.distributed pass the UNWRAPPED model: gradients are packed
+    into one flat buffer inside the graph and averaged by one eager all-reduce after the replay
+    (``FlatGradSync``) — DDP's hooks cannot be captured.  Needs static shapes (the loaders use
+    drop_last=True)."""
 
     def __init__(self, args, model, optimizer, scheduler, criterion, device, batch_size, channels,
-                 sig_len):
+                 sig_len, sync: Optional[FlatGradSync] = None):
         if args.dataset in SPECTROGRAM_DATASETS:
             raise NotImplementedError("graphed step is wired for the 1D path")
         self.args, self.model, self.opt, self.sched = args, model, optimizer, scheduler
@@ -240,12 +296,16 @@ class GraphedTrainStep:
         self.x = torch.zeros(batch_size, channels, sig_len, device=device)
         self.t = torch.zeros(batch_size, args.num_classes, device=device)
         self.t[:, 0] = 1
+        self.sync = sync
+        self.bwd_seed = torch.full((), sync.backward_scale if sync else 1.0, device=device)
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):                   # warm-up off the capture (no weight update)
             for _ in range(3):
                 self.opt.zero_grad(set_to_none=True)
                 self._fwd_bwd()
+            if sync is not None:
+                sync.attach()
         torch.cuda.current_stream(device).wait_stream(side)
         self.opt.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
@@ -255,8 +315,10 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         out = self.model(self.x, depth=0, pass_part="second")
         loss = self.ce(out, self.t)
-        loss.backward()
-        if self.args.grad_clip and not isinstance(self.opt, ClipAdam):
+        loss.backward(self.bwd_seed)
+        if self.sync is not None and self.sync.params is not None:
+            self.sync.pack()
+        elif self.args.grad_clip and not isinstance(self.opt, ClipAdam):
             nn.utils.clip_grad_value_(self.params, clip_value=self.args.grad_clip)
         return loss.detach(), out.detach()
 
@@ -283,6 +345,10 @@ class GraphedTrainStep:
             self.x.copy_(data, non_blocking=True)
         self.t.copy_(t_ohe)
         self.graph.replay()
+        if self.sync is not None:
+            self.sync.reduce_and_bind()
+            if self.args.grad_clip and not isinstance(self.opt, ClipAdam):
+                nn.utils.clip_grad_value_(self.sync.params, clip_value=self.args.grad_clip)
         self.opt.step()
         if self.sched is not None:
             self.sched.step()
@@ -378,9 +444,10 @@ def train_model(args, dataset, device, use_graph: bool = True, log=print):
     zoo are out of scope.  Returns the performance dict.
 
     ``dataset`` is the dictionary ``dataloader_physionet.file2dict`` returns; it is selected by
-    ``physionet_dataloader`` and kept resident on ``device``.  On one GPU the step runs as a
-    captured hipGraph (``use_graph``); under torch.distributed each rank trains on its shard of
-    every batch with DDP gradient averaging."""
+    ``physionet_dataloader`` and kept resident on ``device``.  The step runs as a captured
+    hipGraph (``use_graph``); under torch.distributed each rank trains on its shard of every batch
+    and gradients are averaged by one all-reduce per step (``FlatGradSync`` around the graph, DDP
+    for the eager step)."""
     import random
     import time as _time
 
@@ -406,16 +473,19 @@ def train_model(args, dataset, device, use_graph: bool = True, log=print):
     model = build_model(args).to(device)
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rank, world = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
-    model = wrap_distributed(model, device)
     args.num_steps = args.num_epochs * (len(train_loader.dataset) // args.batch_size)   # :390
     criterion = SELCLoss(train_labels, args.num_classes, es=selc_turning_point(args), device=device)
+    graphable = use_graph and device.type == "cuda" and "(salopt" not in args.method \
+        and args.num_epochs <= criterion.es
+    if not graphable:
+        model = wrap_distributed(model, device)
     optimizer, scheduler = make_optimizer(args, model)
     step_counter = step_counter_class()
     graphed = None
-    if use_graph and not distributed and device.type == "cuda" and "(salopt" not in args.method \
-            and args.num_epochs <= criterion.es:
+    if graphable:
         graphed = GraphedTrainStep(args, model, optimizer, scheduler, criterion, device,
-                                   args.batch_size, args.num_channels, args.sig_len)
+                                   args.batch_size // world, args.num_channels, args.sig_len,
+                                   sync=FlatGradSync(model, device) if distributed else None)
     perf = {k: [] for k in ("epochs", "steps", "train_loss", "train_accuracy", "test_accuracy",
                             "test_loss", "test_sensitivity", "test_specificity", "test_f1",
                             "test_rocauc", "times")}

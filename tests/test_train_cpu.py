@@ -140,7 +140,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _ddp_worker(rank, world, port, out_path):
+def _ddp_worker(rank, world, port, out_path, flat=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -148,8 +148,14 @@ def _ddp_worker(rank, world, port, out_path):
     args = make_args(batch_size=8)
     x, frames, labels, wav = synthetic.make_batch(16, 4, 2500, seed=3)
     torch.manual_seed(0)
+    if flat and rank == 1:
+        torch.manual_seed(99)            # FlatGradSync must broadcast rank 0's initial weights
     model = no_dropout(tm.build_model(args)).train()
-    model = tm.wrap_distributed(model, torch.device("cpu"))
+    sync = None
+    if flat:
+        sync = tm.FlatGradSync(model, torch.device("cpu"))
+    else:
+        model = tm.wrap_distributed(model, torch.device("cpu"))
     opt, sched = tm.make_optimizer(args, model)
     crit = tm.SELCLoss(labels, 2, es=args.num_epochs + 1)
     sc = tm.step_counter_class()
@@ -157,7 +163,7 @@ def _ddp_worker(rank, world, port, out_path):
             torch.ones(16, dtype=torch.long), torch.arange(16))
     for _ in range(3):
         tm.train_step(args, model, tm.shard_batch(full, rank, world), torch.device("cpu"), opt,
-                      sched, crit, 0, sc)
+                      sched, crit, 0, sc, sync=sync)
     if rank == 0:
         inner = model.module if hasattr(model, "module") else model
         torch.save({k: v.clone() for k, v in inner.state_dict().items()}, out_path)
@@ -165,13 +171,15 @@ def _ddp_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_ddp_two_ranks_equals_single_process(tmp_path):
+@pytest.mark.parametrize("flat", [False, True], ids=["ddp", "flat_all_reduce"])
+def test_ddp_two_ranks_equals_single_process(tmp_path, flat):
     """2 ranks x batch 8 with averaged gradients == 1 process x batch 16 (same seeds, dropout
     off), within fp32 reduction-order noise — the property SURVEY.md §4 asks for in place of the
-    reference's untested DataParallel."""
+    reference's untested DataParallel.  Both averaging paths: DDP hooks (eager step) and
+    FlatGradSync (the one the hipGraph step uses)."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "ddp.pt")
-    mp.spawn(_ddp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_ddp_worker, args=(2, _free_port(), out, flat), nprocs=2, join=True)
     ddp_state = torch.load(out, weights_only=True)
     args = make_args(batch_size=16)
     x, frames, labels, wav = synthetic.make_batch(16, 4, 2500, seed=3)

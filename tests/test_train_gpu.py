@@ -158,3 +158,69 @@ def test_clip_adam_matches_torch(device):
         assert torch.allclose(x, y, rtol=1e-5, atol=1e-6), float((x - y).abs().max())
     for x, y in zip(pa, pb):
         assert torch.allclose(oa.state[x]["exp_avg_sq"], ob.state[y]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+
+
+def _graph_rank(rank, world, port, out_path, backend):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)                       # rehearsal: both ranks share the one GPU
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    B, C, T = 32, 4, 2500
+    pool = synthetic.make_batch(B, C, T, seed=9)
+    full = (torch.from_numpy(pool[0]), torch.from_numpy(pool[2]), torch.from_numpy(pool[1]), pool[3],
+            torch.ones(B, dtype=torch.long), torch.arange(B))
+    args = make_args(method="base", batch_size=B // world, num_steps=12)
+    torch.manual_seed(rank)                             # rank 0's weights must win
+    net = tm.build_model(args).to(dev)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net.train()
+    opt, sched = tm.make_optimizer(args, net)
+    crit = tm.SELCLoss(pool[2], 2, es=args.num_epochs + 1, device=dev)
+    sc = tm.step_counter_class()
+    g = tm.GraphedTrainStep(args, net, opt, sched, crit, dev, B // world, C, T,
+                            sync=tm.FlatGradSync(net, dev))
+    for _ in range(5):
+        g.step(tm.shard_batch(full, rank, world), 0, sc)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save([p.detach().cpu() for p in net.parameters() if p.requires_grad], out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (1, "nccl")])
+def test_graphed_step_with_flat_all_reduce(world, backend, device, tmp_path):
+    """The N>1 training step: hipGraph(fwd+bwd+pack) -> one all-reduce -> ClipAdam.  Two ranks
+    sharing this box's GPU over gloo (the card allows it; RCCL wants one GPU per rank), and the
+    RCCL call itself with a single rank.  Either must equal one process on the whole batch."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_graph_rank, args=(world, port, out, backend), nprocs=world, join=True)
+    got = torch.load(out, weights_only=True)
+    B, C, T = 32, 4, 2500
+    pool = synthetic.make_batch(B, C, T, seed=9)
+    full = (torch.from_numpy(pool[0]), torch.from_numpy(pool[2]), torch.from_numpy(pool[1]), pool[3],
+            torch.ones(B, dtype=torch.long), torch.arange(B))
+    args = make_args(method="base", batch_size=B, num_steps=12)
+    torch.manual_seed(0)
+    net = tm.build_model(args).to(device)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net.train()
+    opt, sched = tm.make_optimizer(args, net)
+    crit = tm.SELCLoss(pool[2], 2, es=args.num_epochs + 1, device=device)
+    sc = tm.step_counter_class()
+    g = tm.GraphedTrainStep(args, net, opt, sched, crit, device, B, C, T)
+    for _ in range(5):
+        g.step(full, 0, sc)
+    for a, b in zip(got, [p for p in net.parameters() if p.requires_grad]):
+        assert torch.allclose(a.to(device), b, rtol=1e-3, atol=2e-5), float((a.to(device) - b).abs().max())
