@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 3
+#define PCGMIX_ABI_VERSION 4
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -253,6 +253,14 @@ int pcgmix_skinny_linear_fwd_f32(const float* h, const float* W, const float* bi
 int pcgmix_adam_clip_f32(float* p, const float* g, float* m, float* v, long long n, float clip,
                          float lr, float beta1, float beta2, float eps, float weight_decay,
                          long long step, pcgmix_stream_t stream);
+
+/* The same update for n_tensors parameter tensors in one launch (one per 32 tensors).  p, g, m,
+ * v are HOST arrays of n_tensors device pointers, n the HOST array of element counts; all tensors
+ * share the hyper-parameters and the step number (one torch param group).                    */
+int pcgmix_adam_clip_multi_f32(int n_tensors, float* const* p, const float* const* g,
+                               float* const* m, float* const* v, const long long* n, float clip,
+                               float lr, float beta1, float beta2, float eps, float weight_decay,
+                               long long step, pcgmix_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -48,6 +48,9 @@ SIGNATURES = {
     "pcgmix_adam_clip_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, ctypes.c_longlong, _c_float, _c_float,
                                       _c_float, _c_float, _c_float, _c_float, ctypes.c_longlong,
                                       _ptr]),
+    "pcgmix_adam_clip_multi_f32": (_c_int, [_c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float,
+                                            _c_float, _c_float, _c_float, _c_float,
+                                            ctypes.c_longlong, _ptr]),
 }
 
 _lib = None

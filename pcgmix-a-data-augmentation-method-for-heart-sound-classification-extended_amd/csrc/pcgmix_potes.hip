@@ -654,7 +654,90 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p,
   }
 }
 
+// All parameter tensors of a model in ONE launch: eight ~3 us launches (six of them on tensors of
+// <= 160 elements) become one.  The tensor table travels by value in the kernel arguments; a block
+// owns kAdamEPB consecutive elements of one tensor and finds it by a uniform scan of blk_start.
+constexpr int kAdamMaxTensors = 32;
+constexpr int kAdamEPB = 1024;
+struct AdamTable {
+  float* p[kAdamMaxTensors];
+  const float* g[kAdamMaxTensors];
+  float* m[kAdamMaxTensors];
+  float* v[kAdamMaxTensors];
+  long long n[kAdamMaxTensors];
+  int blk_start[kAdamMaxTensors + 1];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void adam_clip_multi_kernel(AdamTable tab, float clip, float wd,
+                                                              float one_m_b1, float b2,
+                                                              float one_m_b2, float step_size,
+                                                              float inv_bc2_sqrt, float eps) {
+  int t = 0;
+  while (t + 1 < tab.count && (int)blockIdx.x >= tab.blk_start[t + 1]) ++t;
+  float* __restrict__ p = tab.p[t];
+  const float* __restrict__ g = tab.g[t];
+  float* __restrict__ m = tab.m[t];
+  float* __restrict__ v = tab.v[t];
+  const long long n = tab.n[t];
+  const long long base = (long long)((int)blockIdx.x - tab.blk_start[t]) * kAdamEPB;
+#pragma unroll
+  for (int j = 0; j < kAdamEPB / 256; ++j) {
+    const long long i = base + j * 256 + threadIdx.x;
+    if (i >= n) break;
+    float gi = g[i];
+    if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+    const float pi = p[i];
+    gi = fmaf(wd, pi, gi);
+    float mi = m[i], vi = v[i];
+    mi = fmaf(one_m_b1, gi - mi, mi);
+    vi = fmaf(one_m_b2 * gi, gi, b2 * vi);
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
 }  // namespace pcgmix
+
+extern "C" int pcgmix_adam_clip_multi_f32(int n_tensors, float* const* p, const float* const* g,
+                                          float* const* m, float* const* v, const long long* n,
+                                          float clip, float lr, float beta1, float beta2, float eps,
+                                          float weight_decay, long long step,
+                                          pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (n_tensors < 0 || step < 1 || (n_tensors > 0 && (!p || !g || !m || !v || !n)))
+    return hipErrorInvalidValue;
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_bc2_sqrt = (float)(1.0 / std::sqrt(bc2));
+  for (int first = 0; first < n_tensors; first += kAdamMaxTensors) {
+    AdamTable tab;
+    tab.count = 0;
+    int blocks = 0;
+    const int last = first + kAdamMaxTensors < n_tensors ? first + kAdamMaxTensors : n_tensors;
+    for (int i = first; i < last; ++i) {
+      if (n[i] < 0 || (n[i] > 0 && (!p[i] || !g[i] || !m[i] || !v[i]))) return hipErrorInvalidValue;
+      if (n[i] == 0) continue;
+      const long long nb = (n[i] + kAdamEPB - 1) / kAdamEPB;
+      if (nb > (1ll << 30) - blocks) return hipErrorInvalidValue;
+      const int k = tab.count++;
+      tab.p[k] = p[i]; tab.g[k] = g[i]; tab.m[k] = m[i]; tab.v[k] = v[i]; tab.n[k] = n[i];
+      tab.blk_start[k] = blocks;
+      blocks += (int)nb;
+    }
+    if (tab.count == 0) continue;
+    tab.blk_start[tab.count] = blocks;
+    hipLaunchKernelGGL(adam_clip_multi_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), tab, clip, weight_decay,
+                       1.0f - beta1, beta2, 1.0f - beta2, step_size, inv_bc2_sqrt, eps);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return (int)err;
+  }
+  return hipSuccess;
+}
 
 extern "C" int pcgmix_adam_clip_f32(float* p, const float* g, float* m, float* v, long long n,
                                     float clip, float lr, float beta1, float beta2, float eps,

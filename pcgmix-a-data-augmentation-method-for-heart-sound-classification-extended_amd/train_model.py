@@ -84,31 +84,52 @@ class ClipAdam(torch.optim.Adam):
     def __init__(self, params, lr, weight_decay=0.0, clip_value=0.0, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.clip_value = float(clip_value or 0.0)
+        self._tables = {}
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}                      # the moment tensors were replaced
 
     @torch.no_grad()
     def step(self, closure=None):
         import ctypes
         from . import _lib
         lib = _lib.load()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
+            live = [p for p in group["params"] if p.grad is not None]
+            if not live:
+                continue
+            for p in live:
                 st = self.state[p]
                 if not st:
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                stream = ctypes.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
-                _lib.check(lib.pcgmix_adam_clip_f32(
-                    p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                    p.numel(), ctypes.c_float(self.clip_value), ctypes.c_float(float(group["lr"])),
-                    ctypes.c_float(b1), ctypes.c_float(b2), ctypes.c_float(group["eps"]),
-                    ctypes.c_float(group["weight_decay"]), int(st["step"]), stream),
-                    "pcgmix_adam_clip_f32")
+            steps = {int(self.state[p]["step"]) for p in live}
+            if len(steps) != 1:
+                raise RuntimeError("ClipAdam: parameters of one group must share the step count")
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in live]
+            key = tuple(p.data_ptr() for p in live)
+            tab = self._tables.get(gi)
+            if tab is None or tab[0] != key:          # pointer tables of the static tensors
+                n = len(live)
+                arr = ctypes.c_void_p * n
+                tab = (key, arr(*key), arr(*[self.state[p]["exp_avg"].data_ptr() for p in live]),
+                       arr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in live]),
+                       (ctypes.c_longlong * n)(*[p.numel() for p in live]), arr())
+                self._tables[gi] = tab
+            gptr = tab[5]
+            for i, g in enumerate(grads):
+                gptr[i] = g.data_ptr()
+            dev = live[0].device
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.pcgmix_adam_clip_multi_f32(
+                len(live), tab[1], gptr, tab[2], tab[3], tab[4], ctypes.c_float(self.clip_value),
+                ctypes.c_float(float(group["lr"])), ctypes.c_float(b1), ctypes.c_float(b2),
+                ctypes.c_float(group["eps"]), ctypes.c_float(group["weight_decay"]),
+                steps.pop(), stream), "pcgmix_adam_clip_multi_f32")
         return None
 
 

@@ -1,6 +1,7 @@
 """Train step on the GPU: the HIP augmentation inside the loop, host-label fast path, DDP
 wrapper degenerate case."""
 import argparse
+import copy
 
 import numpy as np
 import pytest
@@ -224,3 +225,20 @@ def test_graphed_step_with_flat_all_reduce(world, backend, device, tmp_path):
         g.step(full, 0, sc)
     for a, b in zip(got, [p for p in net.parameters() if p.requires_grad]):
         assert torch.allclose(a.to(device), b, rtol=1e-3, atol=2e-5), float((a.to(device) - b).abs().max())
+
+
+def test_clip_adam_state_dict_round_trip(device):
+    """ClipAdam checkpoints interchange with torch.optim.Adam and survive a reload."""
+    torch.manual_seed(1)
+    pa = [torch.nn.Parameter(torch.randn(5000, device=device)), torch.nn.Parameter(torch.randn(7, device=device))]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = tm.ClipAdam(pa, lr=0.01, weight_decay=1e-4, clip_value=0.0), torch.optim.Adam(pb, lr=0.01, weight_decay=1e-4)
+    for it in range(4):
+        if it == 2:
+            oa.load_state_dict(copy.deepcopy(ob.state_dict()))        # torch -> ClipAdam
+        for x, y in zip(pa, pb):
+            g = torch.randn_like(x)
+            x.grad, y.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-6)
