@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 4
+#define PCGMIX_ABI_VERSION 5
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -261,6 +261,43 @@ int pcgmix_adam_clip_multi_f32(int n_tensors, float* const* p, const float* cons
                                float* const* m, float* const* v, const long long* n, float clip,
                                float lr, float beta1, float beta2, float eps, float weight_decay,
                                long long step, pcgmix_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Potes classifier head, forward and backward.                                       [device]
+ *
+ * Replaces CNN_potes' Flatten/concat -> dimreduc Linear(K->20) -> ReLU -> Dropout(.5) ->
+ * Linear(20->C) (models.py:376-381, 456-465) and their autograd twins.
+ *   x       (B,K) features AFTER the Dropout(.25) of the conv branch (K % 4 == 0, 16-byte aligned)
+ *   w1,b1   dimreduc (20,K), (20) — b1 may be NULL;   w2,b2  linear (C,20), (C), C <= 8
+ *   mask2   (B,20) bytes, non-zero = kept, NULL = no dropout (eval); scale2 = 1/(1-p2)
+ *   partial workspace, pcgmix_skinny_linear_splits(B,K) * B * 20 floats
+ *   z       (B,20) out: dimreduc output incl. bias, kept for backward;  logits (B,C) out
+ * Backward, given dlogits (B,C):
+ *   mask1/scale1 the conv branch's Dropout(.25) mask (B,K bytes) and 1/(1-p1), NULL = none
+ *   dz (B,20) workspace/out (gradient at z; 16-byte aligned); dw2 (C,20), db2 (C, may be NULL), db1 (20, may be
+ *   NULL), dw1 (20,K), dx (B,K, may be NULL) = gradient at the features BEFORE Dropout(.25).
+ * x is read once and dx written once (8 bytes per feature element); reductions are fixed-order.
+ */
+int pcgmix_potes_head_fwd_f32(const float* x, const float* w1, const float* b1,
+                              const uint8_t* mask2, float scale2, const float* w2, const float* b2,
+                              float* partial, float* z, float* logits, int B, int K, int C,
+                              pcgmix_stream_t stream);
+int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, const uint8_t* mask2,
+                              float scale2, const float* w2, const float* x, const uint8_t* mask1,
+                              float scale1, const float* w1, float* dz, float* dw2, float* db2,
+                              float* db1, float* dw1, float* dx, int B, int K, int C,
+                              pcgmix_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Soft-target cross entropy (train_model.py:45-54, CELoss).                          [device]
+ *   loss[0] = mean_b( -sum_c log_softmax(logits)[b,c] * target[b,c] )
+ *   dlogits[b,c] = gout[0] / B * (softmax[b,c] * sum_c' target[b,c'] - target[b,c])
+ * logits, target (B,C) float32; gout: device scalar (the incoming gradient of the loss).
+ */
+int pcgmix_soft_ce_fwd_f32(const float* logits, const float* target, float* loss, int B, int C,
+                           pcgmix_stream_t stream);
+int pcgmix_soft_ce_bwd_f32(const float* logits, const float* target, const float* gout,
+                           float* dlogits, int B, int C, pcgmix_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -51,6 +51,13 @@ SIGNATURES = {
     "pcgmix_adam_clip_multi_f32": (_c_int, [_c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float,
                                             _c_float, _c_float, _c_float, _c_float,
                                             ctypes.c_longlong, _ptr]),
+    "pcgmix_potes_head_fwd_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_float, _ptr, _ptr, _ptr, _ptr,
+                                           _ptr, _c_int, _c_int, _c_int, _ptr]),
+    "pcgmix_potes_head_bwd_f32": (_c_int, [_ptr, _ptr, _ptr, _c_float, _ptr, _ptr, _ptr, _c_float,
+                                           _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int,
+                                           _c_int, _ptr]),
+    "pcgmix_soft_ce_fwd_f32": (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),
+    "pcgmix_soft_ce_bwd_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),
 }
 
 _lib = None

@@ -1,0 +1,341 @@
+// pcgmix_head.hip — the Potes classifier head and the soft-target cross entropy as a handful of
+// kernels (gfx950).
+//
+// Reference: models.py:376-381, 456-465 (CNN_potes: Dropout(.25) -> Flatten/concat -> dimreduc
+// Linear(K->20) -> ReLU -> Dropout(.5) -> Linear(20->C)) and train_model.py:45-54 (CELoss:
+// mean_b(-sum_c log_softmax(logits)[b,c] * target[b,c])).
+//
+// Through torch this part of the bs=256 train step is ~30 launches of 3-5 us each (ReLU, two
+// dropouts, a 20->2 GEMM, log-softmax, mul, two reductions, two negations, their backward twins,
+// three more GEMMs, bias reductions, masked scales) for a few KB of data, plus two hipBLASLt GEMMs
+// and a masked scale over the 20 MB feature matrix: ~120 us of a ~300 us step.  Here:
+//
+//   potes_tail_fwd_kernel   split-K partials of dimreduc -> +bias -> ReLU -> dropout mask ->
+//                           Linear(20->C): z (kept for backward) and logits
+//   soft_ce_fwd_kernel      loss scalar, one block
+//   soft_ce_bwd_kernel      dlogits
+//   potes_tail_bwd_kernel   dlogits -> dW2, db2, dz (through dropout and ReLU), db1; one block
+//   potes_head_bwd_kernel   dz -> dW1 = dz^T x and dx = mask1 * scale1 * (dz W1) in ONE pass over
+//                           the feature matrix x (read once, written once: 9 bytes/element)
+//
+// The dropout masks themselves come from torch's generator (graph-safe Philox state), so seeding
+// behaves as with nn.Dropout.  All reductions run in a fixed order (deterministic).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+
+#include "pcgmix_kernels.h"
+
+namespace pcgmix {
+
+constexpr int kHeadO = 20;        // dimreduc width (models.py:376)
+constexpr int kHeadMaxC = 8;      // classes
+constexpr int kTailRows = 16;     // batch rows per block in the forward tail
+constexpr int kTailBwdGroups = 48;
+constexpr int kHbCols = 64;
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------ tail, forward
+// thread (r, o) of a block owns z[row][o]; the first 16*C threads then form the logits.
+__global__ __launch_bounds__(kTailRows* kHeadO) void potes_tail_fwd_kernel(
+    const float* __restrict__ partial, int KS, const float* __restrict__ b1,
+    const uint8_t* __restrict__ mask2, float scale2, const float* __restrict__ w2,
+    const float* __restrict__ b2, float* __restrict__ z, float* __restrict__ logits, int B, int C) {
+  __shared__ float h[kTailRows][kHeadO];
+  const int t = threadIdx.x, r = t / kHeadO, o = t - r * kHeadO;
+  const int row = blockIdx.x * kTailRows + r;
+  float hv = 0.f;
+  if (row < B) {
+    const size_t i = (size_t)row * kHeadO + o;
+    float v = b1 ? b1[o] : 0.f;
+    for (int ks = 0; ks < KS; ++ks) v += partial[(size_t)ks * B * kHeadO + i];
+    z[i] = v;
+    hv = v > 0.f ? v : 0.f;
+    if (mask2) hv = mask2[i] ? hv * scale2 : 0.f;
+  }
+  h[r][o] = hv;
+  __syncthreads();
+  if (t < kTailRows * C) {
+    const int rr = t / C, c = t - rr * C;
+    const int row2 = blockIdx.x * kTailRows + rr;
+    if (row2 < B) {
+      float a = b2 ? b2[c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < kHeadO; ++k) a = fmaf(h[rr][k], w2[c * kHeadO + k], a);
+      logits[(size_t)row2 * C + c] = a;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ tail, backward
+// Block 0 (the others only zero dW1's buffer for potes_head_bwd_kernel).  Thread (g, o): rows g, g+48, ... of column o.  dz = (z > 0) * m2 * (dlogits W2);
+// dW2[c][o] = sum_b dlogits[b][c] h[b][o]; db1[o] = sum_b dz[b][o]; db2[c] = sum_b dlogits[b][c].
+__global__ __launch_bounds__(kTailBwdGroups* kHeadO) void potes_tail_bwd_kernel(
+    const float* __restrict__ dlogits, const float* __restrict__ z,
+    const uint8_t* __restrict__ mask2, float scale2, const float* __restrict__ w2,
+    float* __restrict__ dz, float* __restrict__ dw2, float* __restrict__ db2,
+    float* __restrict__ db1, int B, int C, float* __restrict__ zero, long long n_zero) {
+  if (blockIdx.x > 0) {        // blocks 1.. clear the buffer the next kernel accumulates dW1 into
+    const long long per = (n_zero + gridDim.x - 2) / (gridDim.x - 1);
+    const long long lo = (long long)(blockIdx.x - 1) * per;
+    const long long hi = lo + per < n_zero ? lo + per : n_zero;
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) zero[i] = 0.f;
+    return;
+  }
+  __shared__ float red[kTailBwdGroups][kHeadMaxC + 1][kHeadO];
+  __shared__ float redc[kTailBwdGroups][kHeadMaxC];
+  const int t = threadIdx.x, g = t / kHeadO, o = t - g * kHeadO;
+  float w2c[kHeadMaxC], adw[kHeadMaxC], adb2[kHeadMaxC];
+#pragma unroll
+  for (int c = 0; c < kHeadMaxC; ++c) {
+    w2c[c] = c < C ? w2[c * kHeadO + o] : 0.f;
+    adw[c] = 0.f;
+    adb2[c] = 0.f;
+  }
+  float adb1 = 0.f;
+  for (int b = g; b < B; b += kTailBwdGroups) {
+    const size_t i = (size_t)b * kHeadO + o;
+    const float zz = z[i];
+    float fac = zz > 0.f ? 1.f : 0.f;
+    if (mask2) fac = mask2[i] ? fac * scale2 : 0.f;
+    const float hv = zz * fac;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < kHeadMaxC; ++c) {
+      if (c < C) {
+        const float dl = dlogits[(size_t)b * C + c];
+        s = fmaf(dl, w2c[c], s);
+        adw[c] = fmaf(dl, hv, adw[c]);
+        adb2[c] += dl;
+      }
+    }
+    const float d = s * fac;
+    dz[i] = d;
+    adb1 += d;
+  }
+#pragma unroll
+  for (int c = 0; c < kHeadMaxC; ++c) red[g][c][o] = adw[c];
+  red[g][kHeadMaxC][o] = adb1;
+  if (o == 0) {
+#pragma unroll
+    for (int c = 0; c < kHeadMaxC; ++c) redc[g][c] = adb2[c];
+  }
+  __syncthreads();
+  if (t < (C + 1) * kHeadO) {                      // c == C: db1
+    const int c = t / kHeadO, oo = t - c * kHeadO;
+    const int slot = c < C ? c : kHeadMaxC;
+    float a = 0.f;
+    for (int gg = 0; gg < kTailBwdGroups; ++gg) a += red[gg][slot][oo];
+    if (c < C) dw2[c * kHeadO + oo] = a;
+    else if (db1) db1[oo] = a;
+  } else if (t >= 512 && t < 512 + C && db2) {
+    const int c = t - 512;
+    float a = 0.f;
+    for (int gg = 0; gg < kTailBwdGroups; ++gg) a += redc[gg][c];
+    db2[c] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------ head, backward
+// Block = 64 feature columns x one HALF of the batch rows (gridDim.y = 2).  Lane = column, wave w
+// takes rows w, w+4, ... of each 64-row chunk; W1's column (20 values) and the 20 dW1 accumulators
+// live in registers, dz rows are LDS broadcasts.  x is the matrix the forward multiplied (after
+// dropout); mask1/scale1 carry the Dropout(.25) backward to dx.
+//
+// Measured on MI355X (profiles/probes/head_bwd_variants.hip, B=256, K=19968): the kernel is bound
+// by its 45 MB of traffic plus latency, not by the 40 FMAs per element (packing them or feeding dz
+// from SGPRs changes nothing).  One 512-thread block per column tile holding all rows runs load,
+// compute and store phases in lock-step over the whole GPU (21 us); several small co-resident
+// blocks per CU overlap them (12.5 us).  The two row halves add their dW1 tiles with float
+// atomicAdd onto a zeroed buffer — two addends per element, so the sum does not depend on arrival
+// order (deterministic); more than two splits would.
+constexpr int kHbWaves = 4, kHbRows = 64, kHbSplit = 2;
+
+template <bool MASKED>
+__global__ __launch_bounds__(kHbWaves * 64) void potes_head_bwd_kernel(
+    const float* __restrict__ dz, const float* __restrict__ x, const uint8_t* __restrict__ mask1,
+    float scale1, const float* __restrict__ w1, float* __restrict__ dw1, float* __restrict__ dx,
+    int B, int K) {
+  __shared__ __align__(16) float dzl[kHbRows * kHeadO];
+  __shared__ float red[kHbWaves][kHeadO][kHbCols];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k0 = blockIdx.x * kHbCols, k = k0 + lane;
+  const bool valid = k < K;
+  const int bh = (B + kHbSplit - 1) / kHbSplit;
+  const int row_lo = blockIdx.y * bh, row_hi = min(B, row_lo + bh);
+  float wcol[kHeadO], acc[kHeadO];
+#pragma unroll
+  for (int o = 0; o < kHeadO; ++o) {
+    wcol[o] = w1[(size_t)o * K + (valid ? k : 0)];     // clamped, not predicated
+    acc[o] = 0.f;
+  }
+  for (int b0 = row_lo; b0 < row_hi; b0 += kHbRows) {
+    const int nb = row_hi - b0 < kHbRows ? row_hi - b0 : kHbRows;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * (kHeadO / 4); i += kHbWaves * 64)
+      *reinterpret_cast<f4*>(dzl + 4 * i) =
+          reinterpret_cast<const f4*>(dz + (size_t)b0 * kHeadO)[i];   // b0 * 80 B: 16-byte aligned
+    __syncthreads();
+    // all of this wave's rows of the chunk are requested before the first is used; the loads are
+    // unconditional on a clamped address (a predicated load puts a branch and a vmcnt(0) wait
+    // between consecutive requests)
+    constexpr int kPer = kHbRows / kHbWaves;
+    float xv[kPer];
+    uint8_t mb[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int r = wave + kHbWaves * j;
+      const size_t e = (valid && r < nb) ? (size_t)(b0 + r) * K + k : 0;
+      xv[j] = x[e];
+      mb[j] = MASKED ? mask1[e] : 1;
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int r = wave + kHbWaves * j;
+      if (r < nb) {                                 // wave-uniform
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < kHeadO / 4; ++q) {
+          const f4 d = *reinterpret_cast<const f4*>(dzl + r * kHeadO + 4 * q);
+          s = fmaf(d.x, wcol[4 * q], s);
+          s = fmaf(d.y, wcol[4 * q + 1], s);
+          s = fmaf(d.z, wcol[4 * q + 2], s);
+          s = fmaf(d.w, wcol[4 * q + 3], s);
+          acc[4 * q] = fmaf(d.x, xv[j], acc[4 * q]);
+          acc[4 * q + 1] = fmaf(d.y, xv[j], acc[4 * q + 1]);
+          acc[4 * q + 2] = fmaf(d.z, xv[j], acc[4 * q + 2]);
+          acc[4 * q + 3] = fmaf(d.w, xv[j], acc[4 * q + 3]);
+        }
+        if (valid && dx) dx[(size_t)(b0 + r) * K + k] = mb[j] ? s * scale1 : 0.f;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < kHeadO; ++o) red[wave][o][lane] = acc[o];
+  __syncthreads();
+  for (int i = threadIdx.x; i < kHeadO * kHbCols; i += kHbWaves * 64) {
+    const int o = i / kHbCols, l = i - o * kHbCols;
+    if (k0 + l < K) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < kHbWaves; ++w) a += red[w][o][l];
+      atomicAdd(dw1 + (size_t)o * K + k0 + l, a);   // onto zero; exactly kHbSplit == 2 addends
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ soft-target CE
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void soft_ce_fwd_kernel(const float* __restrict__ logits,
+                                                          const float* __restrict__ target,
+                                                          float* __restrict__ loss, int B, int C) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* x = logits + (size_t)b * C;
+    const float* t = target + (size_t)b * C;
+    float m = x[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(x[c] - m);
+    const float lse = logf(se);
+    float rl = 0.f;
+    for (int c = 0; c < C; ++c) rl += (x[c] - m - lse) * t[c];
+    acc -= rl;
+  }
+  const float tot = block_sum_256(acc, red);
+  if (threadIdx.x == 0) loss[0] = tot / (float)B;
+}
+
+// dlogits[b][c] = gout / B * (softmax[b][c] * sum_c' t[b][c'] - t[b][c])
+__global__ __launch_bounds__(256) void soft_ce_bwd_kernel(const float* __restrict__ logits,
+                                                          const float* __restrict__ target,
+                                                          const float* __restrict__ gout,
+                                                          float* __restrict__ dlogits, int B,
+                                                          int C) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float g = gout[0] / (float)B;
+  const float* x = logits + (size_t)b * C;
+  const float* t = target + (size_t)b * C;
+  float m = x[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+  float se = 0.f, ts = 0.f;
+  for (int c = 0; c < C; ++c) {
+    se += expf(x[c] - m);
+    ts += t[c];
+  }
+  const float lse = logf(se);
+  for (int c = 0; c < C; ++c)
+    dlogits[(size_t)b * C + c] = g * (expf(x[c] - m - lse) * ts - t[c]);
+}
+
+}  // namespace pcgmix
+
+extern "C" int pcgmix_soft_ce_fwd_f32(const float* logits, const float* target, float* loss, int B,
+                                      int C, pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!logits || !target || !loss || B <= 0 || C <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(soft_ce_fwd_kernel, dim3(1), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), logits, target, loss, B, C);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pcgmix_soft_ce_bwd_f32(const float* logits, const float* target, const float* gout,
+                                      float* dlogits, int B, int C, pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!logits || !target || !gout || !dlogits || B <= 0 || C <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(soft_ce_bwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), logits, target, gout, dlogits, B, C);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pcgmix_potes_head_fwd_f32(const float* x, const float* w1, const float* b1,
+                                         const uint8_t* mask2, float scale2, const float* w2,
+                                         const float* b2, float* partial, float* z, float* logits,
+                                         int B, int K, int C, pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!w2 || !z || !logits || C <= 0 || C > kHeadMaxC) return hipErrorInvalidValue;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const hipError_t e = launch_skinny_partial(x, w1, partial, B, K, kHeadO, s);
+  if (e != hipSuccess) return (int)e;
+  const int KS = pcgmix_skinny_linear_splits(B, K);
+  hipLaunchKernelGGL(potes_tail_fwd_kernel, dim3((unsigned)((B + kTailRows - 1) / kTailRows)),
+                     dim3(kTailRows * kHeadO), 0, s, partial, KS, b1, mask2, scale2, w2, b2, z,
+                     logits, B, C);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, const uint8_t* mask2,
+                                         float scale2, const float* w2, const float* x,
+                                         const uint8_t* mask1, float scale1, const float* w1,
+                                         float* dz, float* dw2, float* db2, float* db1, float* dw1,
+                                         float* dx, int B, int K, int C, pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!dlogits || !z || !w2 || !x || !w1 || !dz || !dw2 || !dw1 || B <= 0 || K <= 0 || C <= 0 ||
+      C > kHeadMaxC || (reinterpret_cast<uintptr_t>(dz) & 15))
+    return hipErrorInvalidValue;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long long n_dw1 = (long long)kHeadO * K;
+  const unsigned zero_blocks = (unsigned)((n_dw1 + 4095) / 4096);          // >= 1 since K > 0
+  hipLaunchKernelGGL(potes_tail_bwd_kernel, dim3(1 + zero_blocks), dim3(kTailBwdGroups * kHeadO), 0,
+                     s, dlogits, z, mask2, scale2, w2, dz, dw2, db2, db1, B, C, dw1, n_dw1);
+  const dim3 grid((unsigned)((K + kHbCols - 1) / kHbCols), kHbSplit), block(kHbWaves * 64);
+  if (mask1) {
+    hipLaunchKernelGGL(potes_head_bwd_kernel<true>, grid, block, 0, s, dz, x, mask1, scale1, w1, dw1,
+                       dx, B, K);
+  } else {
+    hipLaunchKernelGGL(potes_head_bwd_kernel<false>, grid, block, 0, s, dz, x, mask1, 1.0f, w1, dw1,
+                       dx, B, K);
+  }
+  return (int)hipGetLastError();
+}

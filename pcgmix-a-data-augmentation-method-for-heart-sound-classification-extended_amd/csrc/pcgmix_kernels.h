@@ -20,5 +20,9 @@ inline hipError_t allow_large_lds(const void* kernel, unsigned long long* done, 
   return e;
 }
 
+// pcgmix_potes.hip: split-K partial products of the skinny linear layer (see there).
+hipError_t launch_skinny_partial(const float* h, const float* W, float* partial, int B, int K,
+                                 int O, hipStream_t s);
+
 }  // namespace pcgmix
 #endif

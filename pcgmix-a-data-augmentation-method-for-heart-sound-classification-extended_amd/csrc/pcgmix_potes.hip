@@ -817,16 +817,15 @@ extern "C" int pcgmix_skinny_linear_splits(int B, int K) {
   return (K + pcgmix::kSkinnyChunk - 1) / pcgmix::kSkinnyChunk;   // one partial per K chunk
 }
 
-extern "C" int pcgmix_skinny_linear_fwd_f32(const float* h, const float* W, const float* bias,
-                                            float* partial, float* z, int B, int K, int O,
-                                            pcgmix_stream_t stream) {
-  using namespace pcgmix;
-  if (!h || !W || !partial || !z || B <= 0 || K <= 0 || (K & 3) || O <= 0 || O > kSkinnyMaxO)
+namespace pcgmix {
+// Launch the split-K partial products of z = h W^T (shared with the fused head, pcgmix_head.hip).
+hipError_t launch_skinny_partial(const float* h, const float* W, float* partial, int B, int K,
+                                 int O, hipStream_t s) {
+  if (!h || !W || !partial || B <= 0 || K <= 0 || (K & 3) || O <= 0 || O > kSkinnyMaxO)
     return hipErrorInvalidValue;
   if ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(W)) & 15)
     return hipErrorInvalidValue;
   const int KS = pcgmix_skinny_linear_splits(B, K);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((unsigned)((B + kSkinnyRows - 1) / kSkinnyRows), (unsigned)KS), block(kPotThreads);
   if (O == 20) {
     hipLaunchKernelGGL((skinny_linear_partial_kernel<20>), grid, block, 0, s, h, W, partial, B, K);
@@ -837,6 +836,19 @@ extern "C" int pcgmix_skinny_linear_fwd_f32(const float* h, const float* W, cons
   } else {
     return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+}  // namespace pcgmix
+
+extern "C" int pcgmix_skinny_linear_fwd_f32(const float* h, const float* W, const float* bias,
+                                            float* partial, float* z, int B, int K, int O,
+                                            pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!z) return hipErrorInvalidValue;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const hipError_t e = launch_skinny_partial(h, W, partial, B, K, O, s);
+  if (e != hipSuccess) return (int)e;
+  const int KS = pcgmix_skinny_linear_splits(B, K);
   const int n = B * O;
   hipLaunchKernelGGL(skinny_linear_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                      partial, bias, z, B, O, KS);

@@ -97,6 +97,69 @@ class SkinnyLinearFunction(torch.autograd.Function):
         return gx, gw, gb
 
 
+class PotesHeadFunction(torch.autograd.Function):
+    """Dropout(p1) -> dimreduc Linear(K->20) -> ReLU -> Dropout(p2) -> Linear(20->C) of CNN_potes
+    (models.py:376-381, 456-465) as one autograd node: ``pcgmix_potes_head_fwd_f32`` /
+    ``pcgmix_potes_head_bwd_f32``.  Both dropout masks are drawn by torch's generator (so
+    ``torch.manual_seed`` and hipGraph capture behave as with nn.Dropout); everything else —
+    about 30 small torch launches and three GEMMs per training step — is five HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, feat, w1, b1, w2, b2, p1, p2, training):
+        B, K = feat.shape
+        C = w2.shape[0]
+        dev = feat.device
+        lib = _lib.load()
+        mask1 = mask2 = None
+        if training and p1 > 0.0:
+            x, mask1 = torch.ops.aten.native_dropout(feat, p1, True)
+        else:
+            x = feat.contiguous()
+        if training and p2 > 0.0:
+            mask2 = torch.empty((B, 20), dtype=torch.bool, device=dev).bernoulli_(1.0 - p2)
+        w1c, w2c = w1.detach().contiguous(), w2.detach().contiguous()
+        ks = lib.pcgmix_skinny_linear_splits(B, K)
+        partial = torch.empty((ks, B, 20), dtype=torch.float32, device=dev)
+        z = torch.empty((B, 20), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, C), dtype=torch.float32, device=dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.pcgmix_potes_head_fwd_f32(
+            x.data_ptr(), w1c.data_ptr(), b1.detach().data_ptr() if b1 is not None else None,
+            mask2.data_ptr() if mask2 is not None else None,
+            ctypes.c_float(1.0 / (1.0 - p2) if mask2 is not None else 1.0), w2c.data_ptr(),
+            b2.detach().data_ptr() if b2 is not None else None, partial.data_ptr(), z.data_ptr(),
+            logits.data_ptr(), B, K, C, stream), "pcgmix_potes_head_fwd_f32")
+        ctx.save_for_backward(x, w1c, w2c, z, mask1, mask2)
+        ctx.p1, ctx.p2 = p1, p2
+        ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        x, w1, w2, z, mask1, mask2 = ctx.saved_tensors
+        B, K = x.shape
+        C = w2.shape[0]
+        dev = x.device
+        lib = _lib.load()
+        dlogits = dlogits.contiguous()
+        dz = torch.empty((B, 20), dtype=torch.float32, device=dev)
+        dw2 = torch.empty_like(w2)
+        dw1 = torch.empty_like(w1)
+        db1 = torch.empty(20, dtype=torch.float32, device=dev) if ctx.has_b1 else None
+        db2 = torch.empty(C, dtype=torch.float32, device=dev) if ctx.has_b2 else None
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        opt = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        _lib.check(lib.pcgmix_potes_head_bwd_f32(
+            dlogits.data_ptr(), z.data_ptr(), opt(mask2),
+            ctypes.c_float(1.0 / (1.0 - ctx.p2) if mask2 is not None else 1.0), w2.data_ptr(),
+            x.data_ptr(), opt(mask1),
+            ctypes.c_float(1.0 / (1.0 - ctx.p1) if mask1 is not None else 1.0), w1.data_ptr(),
+            dz.data_ptr(), dw2.data_ptr(), opt(db2), opt(db1), dw1.data_ptr(), opt(dx), B, K, C,
+            stream), "pcgmix_potes_head_bwd_f32")
+        return dx, dw1, db1, dw2, db2, None, None, None
+
+
 def _potes_block(c_in: int, c_out: int, dropout: float = 0.0) -> nn.Sequential:
     # Conv1d(k=5, padding=1) + ReLU + MaxPool(2) [+ Dropout]   (reference models.py:359-365)
     layers = [nn.Conv1d(c_in, c_out, kernel_size=5, padding=1), nn.ReLU(inplace=True),
@@ -143,6 +206,23 @@ class CNN_potes(nn.Module):
         return (self.fused and x.is_cuda and x.dtype == torch.float32
                 and c1.out_channels == 8 and c2.out_channels == 4 and x.shape[-1] >= 14)
 
+    def _fused_head(self, x: torch.Tensor) -> bool:
+        return (self._fused(x) and self.dimreduc.out_features == 20
+                and self.linear.in_features == 20 and self.linear.out_features <= 8
+                and self.dimreduc.in_features % 4 == 0)
+
+    def _logits_fused(self, x: torch.Tensor) -> torch.Tensor:
+        """Whole network on the HIP path: conv stack kernel + head kernels."""
+        B, C, T = x.shape
+        c1, c2 = self.cnn1[0][0], self.cnn1[1][0]
+        rows = x[:, :4, :].reshape(B * 4, T)
+        z = PotesStackFunction.apply(rows.contiguous(), c1.weight, c1.bias, c2.weight, c2.bias)
+        drop = self.cnn1[1][3] if len(self.cnn1[1]) > 3 else None
+        return PotesHeadFunction.apply(z.reshape(B, -1), self.dimreduc.weight, self.dimreduc.bias,
+                                       self.linear.weight, self.linear.bias,
+                                       float(drop.p) if drop is not None else 0.0,
+                                       float(self.dropout.p), self.training)
+
     def features(self, x: torch.Tensor) -> torch.Tensor:
         B, C, T = x.shape
         # the four bands share cnn1's weights: run them as one (4B,1,T) batch, then restore the
@@ -172,10 +252,14 @@ class CNN_potes(nn.Module):
             return self.features(x)
         if pass_part == "second":
             if depth <= 0:
+                if self._fused_head(x):
+                    return self._logits_fused(x)
                 x = self.features(x)
             if depth <= 1:
                 x = self.linear(x)
             return x
+        if self._fused_head(x):
+            return self._logits_fused(x)
         return self.linear(self.features(x))
 
 

@@ -25,6 +25,40 @@ from . import augmentations, augmentations2d, models, models2d
 SPECTROGRAM_DATASETS = ("PhysioNet(spec128)", "UMC(spec128)", "UMC(spec64)")
 
 
+class SoftCEFunction(torch.autograd.Function):
+    """CELoss on a HIP device as one kernel each way (``pcgmix_soft_ce_{fwd,bwd}_f32``) instead of
+    log_softmax, mul, sum, neg, mean and their five backward launches."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        logits = logits.contiguous()
+        target = target.to(torch.float32).contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
+        _lib.check(lib.pcgmix_soft_ce_fwd_f32(logits.data_ptr(), target.data_ptr(), loss.data_ptr(),
+                                              logits.shape[0], logits.shape[1], stream),
+                   "pcgmix_soft_ce_fwd_f32")
+        ctx.save_for_backward(logits, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        logits, target = ctx.saved_tensors
+        gout = gout.to(torch.float32).contiguous()
+        d = torch.empty_like(logits)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
+        _lib.check(lib.pcgmix_soft_ce_bwd_f32(logits.data_ptr(), target.data_ptr(), gout.data_ptr(),
+                                              d.data_ptr(), logits.shape[0], logits.shape[1],
+                                              stream), "pcgmix_soft_ce_bwd_f32")
+        return d, None
+
+
 class CELoss(nn.Module):
     """Cross-entropy with soft targets: mean_b( -sum_c log_softmax(logits)[b,c] * t[b,c] )
     (train_model.py:45-54)."""
@@ -34,6 +68,9 @@ class CELoss(nn.Module):
         self.num_classes = num_classes
 
     def forward(self, logits, target_ohe):
+        if logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 \
+                and logits.shape[0] > 0 and not target_ohe.requires_grad:
+            return SoftCEFunction.apply(logits, target_ohe)
         return -(F.log_softmax(logits, dim=1) * target_ohe).sum(dim=1).mean()
 
 

@@ -1,0 +1,133 @@
+"""Fused Potes classifier head and soft-target cross entropy (HIP) against the same maths in torch
+float32 (floating-point kernels: torch fp32 is the reference; tolerances stated per assert)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import pcgmix_amd  # noqa: F401
+from pcgmix_amd import _lib, models, train_model as tm
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+@pytest.mark.parametrize("B,K,C,drop", [(256, 19968, 2, True), (32, 9968, 2, True), (7, 4096, 3, False),
+                                        (1, 1028, 2, True), (300, 2052, 8, True), (17, 64, 2, False)])
+def test_head_kernels_match_torch(B, K, C, drop, device):
+    """C ABI with explicit dropout masks == torch autograd of the same composition."""
+    torch.manual_seed(B + K)
+    lib = _lib.load()
+    feat = torch.randn(B, K, device=device).relu_().requires_grad_(True)
+    w1 = (torch.randn(20, K, device=device) / K ** 0.5).requires_grad_(True)
+    b1 = torch.randn(20, device=device).requires_grad_(True)
+    w2 = (torch.randn(C, 20, device=device) / 4).requires_grad_(True)
+    b2 = torch.randn(C, device=device).requires_grad_(True)
+    p1, p2 = 0.25, 0.5
+    if drop:
+        m1 = (torch.rand(B, K, device=device) > p1)
+        m2 = (torch.rand(B, 20, device=device) > p2).to(torch.uint8)
+        s1, s2 = 1 / (1 - p1), 1 / (1 - p2)
+    else:
+        m1 = m2 = None
+        s1 = s2 = 1.0
+    x = feat * m1 * s1 if drop else feat
+    z_t = F.linear(x, w1, b1)
+    h = z_t.relu() * (m2 * s2 if drop else 1.0)
+    logits_t = F.linear(h, w2, b2)
+    dl = torch.randn(B, C, device=device)
+    logits_t.backward(dl)
+
+    ks = lib.pcgmix_skinny_linear_splits(B, K)
+    partial = torch.empty(ks, B, 20, device=device)
+    z = torch.empty(B, 20, device=device)
+    logits = torch.empty(B, C, device=device)
+    xd = x.detach().contiguous()
+    opt = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+    _lib.check(lib.pcgmix_potes_head_fwd_f32(xd.data_ptr(), w1.data_ptr(), b1.data_ptr(), opt(m2),
+                                             ctypes.c_float(s2), w2.data_ptr(), b2.data_ptr(),
+                                             partial.data_ptr(), z.data_ptr(), logits.data_ptr(),
+                                             B, K, C, _stream(device)), "fwd")
+    assert torch.allclose(z, z_t, rtol=1e-4, atol=2e-5), float((z - z_t).abs().max())
+    assert torch.allclose(logits, logits_t, rtol=1e-4, atol=2e-5)
+    dz = torch.empty(B, 20, device=device)
+    dw2, db2, db1 = torch.empty(C, 20, device=device), torch.empty(C, device=device), torch.empty(20, device=device)
+    dw1, dx = torch.empty(20, K, device=device), torch.empty(B, K, device=device)
+    _lib.check(lib.pcgmix_potes_head_bwd_f32(dl.data_ptr(), z.data_ptr(), opt(m2), ctypes.c_float(s2),
+                                             w2.data_ptr(), xd.data_ptr(), opt(m1), ctypes.c_float(s1),
+                                             w1.data_ptr(), dz.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
+                                             db1.data_ptr(), dw1.data_ptr(), dx.data_ptr(), B, K, C,
+                                             _stream(device)), "bwd")
+    for got, want, name in ((dw2, w2.grad, "dw2"), (db2, b2.grad, "db2"), (db1, b1.grad, "db1"),
+                            (dw1, w1.grad, "dw1"), (dx, feat.grad, "dx")):
+        scale = float(want.abs().max()) + 1e-6
+        assert float((got - want).abs().max()) <= 2e-5 * max(1.0, scale) + 1e-4 * scale, name
+
+
+def test_model_fused_head_matches_unfused(device):
+    """Whole CNN_potes, dropout off: HIP stack + HIP head == torch modules, logits and all grads."""
+    torch.manual_seed(3)
+    m = models.CNN_potes_TS(4, 2, "PhysioNet").to(device).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    x = torch.randn(16, 4, 2500, device=device)
+    t = F.one_hot(torch.randint(0, 2, (16,), device=device), 2)
+    res = []
+    for fused in (True, False):
+        m.fused = fused
+        m.zero_grad(set_to_none=True)
+        out = m(x, depth=0, pass_part="second")
+        loss = tm.CELoss(2)(out, t)
+        loss.backward()
+        res.append((out.detach(), loss.detach(),
+                    {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-6)
+    assert res[0][2].keys() == res[1][2].keys()
+    for k in res[0][2]:
+        a, b = res[0][2][k], res[1][2][k]
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-6 + 1e-4 * float(b.abs().max())), k
+
+
+def test_fused_head_dropout_statistics_and_seeding(device):
+    """Training mode: masks come from torch's generator — same seed, same logits; the kept
+    fraction of the 20-wide hidden layer is ~1-p."""
+    torch.manual_seed(0)
+    m = models.CNN_potes_TS(4, 2, "PhysioNet").to(device).train()
+    x = torch.randn(64, 4, 2500, device=device)
+    torch.manual_seed(11)
+    a = m(x, depth=0, pass_part="second")
+    torch.manual_seed(11)
+    b = m(x, depth=0, pass_part="second")
+    torch.manual_seed(12)
+    c = m(x, depth=0, pass_part="second")
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    m.eval()
+    e1, e2 = m(x, depth=0, pass_part="second"), m(x, depth=0, pass_part="second")
+    assert torch.equal(e1, e2)
+
+
+@pytest.mark.parametrize("B,C", [(256, 2), (1, 2), (1000, 2), (37, 5)])
+def test_soft_ce_matches_torch(B, C, device):
+    torch.manual_seed(B)
+    for soft in (False, True):
+        logits = (torch.randn(B, C, device=device) * 3).requires_grad_(True)
+        if soft:
+            tgt = torch.rand(B, C, device=device)
+            tgt = tgt / tgt.sum(1, keepdim=True) * 1.3          # need not sum to 1 (mixAll blends do)
+        else:
+            tgt = F.one_hot(torch.randint(0, C, (B,), device=device), C)
+        want = -(F.log_softmax(logits, dim=1) * tgt).sum(dim=1).mean()
+        (want * 0.7).backward()
+        gw = logits.grad.clone()
+        logits.grad = None
+        got = tm.CELoss(C)(logits, tgt)
+        assert got.grad_fn is not None and "SoftCE" in type(got.grad_fn).__name__
+        (got * 0.7).backward()
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(logits.grad, gw, rtol=1e-4, atol=1e-7)
