@@ -394,14 +394,18 @@ class GraphedTrainStep:
             if hostprep.select_method(args.method, False) else hostprep.MixPlan(fired=False)
         if plan.salopt_mode is not None:
             raise NotImplementedError("saliency-guided steps are not captured; use train_step")
-        t_ohe = F.one_hot(target, args.num_classes).to(self.device, non_blocking=True)
         if plan.fired:
             augmentations.apply_plan(plan, data, frames_np, out=self.x)
-            if plan.mix_all:
-                t_ohe = augmentations.blend_targets(t_ohe, plan)
         else:
             self.x.copy_(data, non_blocking=True)
-        self.t.copy_(t_ohe)
+        if plan.fired and plan.mix_all:                 # float blend of the one-hot rows
+            t_ohe = F.one_hot(target, args.num_classes).to(self.device, non_blocking=True)
+            self.t.copy_(augmentations.blend_targets(t_ohe, plan))
+        elif target.is_cuda:
+            self.t.copy_(F.one_hot(target, args.num_classes))
+        else:                                           # one-hot in float on the host: one small
+            self.t.copy_(F.one_hot(target, args.num_classes).to(torch.float32),   # H2D, no kernel
+                         non_blocking=True)
         self.graph.replay()
         if self.sync is not None:
             self.sync.reduce_and_bind()
