@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 5
+#define PCGMIX_ABI_VERSION 6
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -298,6 +298,30 @@ int pcgmix_soft_ce_fwd_f32(const float* logits, const float* target, float* loss
                            pcgmix_stream_t stream);
 int pcgmix_soft_ce_bwd_f32(const float* logits, const float* target, const float* gout,
                            float* dlogits, int B, int C, pcgmix_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One-call step of the plain PCGmix methods (durratiomixup / durmixmagwarp, same-label partners,
+ * no '(rand)', no saliency): everything augmentations.py:941, 962-977 (and :874, 906-928) do
+ * between the probability gate and the returned tensor.                      [host + device]
+ *
+ *   labels (B) int64, frames (B,5) int64: HOST.  x, y (B,C,T): device.  lam: float32(lambda).
+ *   knots: HOST (B,n_knots,C) float64 as numpy drew them, or NULL (no warp); spline_op: DEVICE
+ *   operator of pcgmix_spline_operator_f64 for (T, n_knots).
+ *   staging: PINNED host scratch, dev_idx: device scratch, both pcgmix_splice_staging_bytes(B, C,
+ *   n_knots) bytes; staging may be reused once the copy enqueued here has completed (record an
+ *   event on `stream` after the call).
+ *   mix_out (B) int64 HOST: the partner permutation — groups of equal label in order of first
+ *   appearance, each permuted by a FRESH Random(step).sample (bit-identical to CPython).
+ * Does: permutation, boundary validation, packing, ONE hipMemcpyAsync, the kernel launch.
+ * Returns 0; -1 frames not monotone / negative, -2 cycle end beyond T, -3 partner out of range
+ * (nothing enqueued); or a hipError_t.
+ */
+int pcgmix_splice_same_label_f32(const float* x, float* y, const int64_t* labels,
+                                 const int64_t* frames, uint64_t step, float lam,
+                                 const double* knots, const double* spline_op, int n_knots,
+                                 void* staging, void* dev_idx, int64_t* mix_out, int B, int C,
+                                 int T, pcgmix_stream_t stream);
+long long pcgmix_splice_staging_bytes(int B, int C, int n_knots);
 
 #ifdef __cplusplus
 }

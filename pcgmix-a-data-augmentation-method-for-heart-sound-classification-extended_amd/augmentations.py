@@ -216,6 +216,57 @@ def apply_plan(plan: MixPlan, data: torch.Tensor, frames: np.ndarray,
     return out
 
 
+_SPLICE_ERRORS = {-1: _PACK_ERRORS[1], -2: _PACK_ERRORS[2], -3: _PACK_ERRORS[3]}
+
+
+def splice_plain(recipe, data: torch.Tensor, labels, frames: np.ndarray, step: int,
+                 out: Optional[torch.Tensor] = None):
+    """One fired step of a plain splice (``hostprep.plain_recipe``) through
+    ``pcgmix_splice_same_label_f32``: the partner draw, validation, packing, the single H2D copy and
+    the launch happen inside the library; Python only draws lambda (and the warp knots) from
+    numpy's global stream exactly where the reference does (augmentations.py:661-663, 677) and
+    picks the staging slot.  ``data`` is (B, C, T) — the 2D path passes (B, F, W).
+    Returns (out, mix_indices)."""
+    _name, _p, alpha, sigma, n_knots = recipe
+    B, C, T = data.shape
+    device = data.device
+    labels = np.ascontiguousarray(np.asarray(labels).reshape(-1), dtype=np.int64)
+    if labels.shape[0] != B or frames.shape != (B, 5):
+        raise ValueError("labels/frames do not match the batch size")
+    if alpha > 0.0:
+        np.random.seed(step)                      # global stream, as the reference
+        lam32 = np.float32(np.random.beta(alpha, alpha))
+    else:
+        lam32 = np.float32(1.0)
+    knots = None
+    if n_knots:
+        knots = np.random.normal(loc=1.0, scale=sigma, size=(B, n_knots, C))
+    lib = _lib.load()
+    nbytes = lib.pcgmix_splice_staging_bytes(B, C, n_knots)
+    mix = np.empty(B, dtype=np.int64)
+    with torch.cuda.device(device):
+        op_ptr = spline_operator(device, T, n_knots).data_ptr() if n_knots else None
+        ring = _RINGS.setdefault(device.index, _StagingRing())
+        slot, pinned = ring.stage(nbytes)
+        dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if out is None:
+            out = torch.empty_like(data)
+        elif out.shape != data.shape or out.dtype != data.dtype or not out.is_contiguous() \
+                or out.data_ptr() == data.data_ptr():
+            raise ValueError("out must be a distinct contiguous tensor shaped like data")
+        stream = torch.cuda.current_stream(device)
+        err = lib.pcgmix_splice_same_label_f32(
+            data.data_ptr(), out.data_ptr(), labels.ctypes.data, frames.ctypes.data, step,
+            ctypes.c_float(lam32), knots.ctypes.data if knots is not None else None, op_ptr,
+            n_knots, pinned.data_ptr(), dev.data_ptr(), mix.ctypes.data, B, C, T,
+            ctypes.c_void_p(stream.cuda_stream))
+        if err < 0:
+            raise ValueError(_SPLICE_ERRORS.get(err, f"pcgmix_splice_same_label_f32 error {err}"))
+        _lib.check(err, "pcgmix_splice_same_label_f32")
+        ring.sent(slot, stream)
+    return out, mix
+
+
 def blend_targets(target_ohe: torch.Tensor, plan: MixPlan) -> torch.Tensor:
     """'(mixAll)': float blend of the one-hot targets (augmentations.py:915-917, 978-980)."""
     B = target_ohe.shape[0]
@@ -248,6 +299,13 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
     _check_data(data, 3)
     B, C, T = data.shape
     frames_np = _as_numpy_frames(frames)
+    recipe = hostprep.plain_recipe(method, False)
+    if recipe is not None and B > 0:              # the common case: one library call
+        if recipe[1] < 1.0 and not hostprep.gate_fires(method, step):
+            return data, target_ohe, [], None
+        labels = labels_from_ohe(target_ohe) if host_labels is None else host_labels
+        out, mix = splice_plain(recipe, data, labels, frames_np, step)
+        return out, target_ohe, mix, None
     labels = (lambda: labels_from_ohe(target_ohe)) if host_labels is None else np.asarray(host_labels)
     plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, C, is2d=False)
     if not plan.fired:

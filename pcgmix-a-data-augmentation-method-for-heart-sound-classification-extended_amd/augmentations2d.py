@@ -14,7 +14,8 @@ applied to every frequency row, so the same kernel runs with C = F rows and T = 
 from __future__ import annotations
 
 from . import hostprep
-from .augmentations import (_as_numpy_frames, _check_data, apply_plan, labels_from_ohe)
+from .augmentations import (_as_numpy_frames, _check_data, apply_plan, labels_from_ohe,
+                            splice_plain)
 
 
 def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RESULTS_ARGS,
@@ -28,6 +29,13 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
     _check_data(data, 4)
     B, Cc, F, W = data.shape
     frames_np = _as_numpy_frames(frames)
+    recipe = hostprep.plain_recipe(method, True)
+    if recipe is not None and B > 0:              # durratiomixup: one library call
+        if recipe[1] < 1.0 and not hostprep.gate_fires(method, step):
+            return data, target_ohe, [], None
+        labels = labels_from_ohe(target_ohe) if host_labels is None else host_labels
+        out, mix = splice_plain(recipe, data.view(B, Cc * F, W), labels, frames_np, step)
+        return out.view(B, Cc, F, W), target_ohe, mix, None
     labels = (lambda: labels_from_ohe(target_ohe)) if host_labels is None else host_labels
     plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, Cc * F, is2d=True, n_cols=W)
     if not plan.fired:

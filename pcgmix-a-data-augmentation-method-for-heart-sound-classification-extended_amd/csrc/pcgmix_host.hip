@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "pcgmix_kernels.h"
@@ -270,4 +271,69 @@ extern "C" int pcgmix_pack_plan_i32(const int64_t* frames, const int64_t* mix,
   if (rect)
     for (int i = 0; i < B * 4; ++i) o[i] = rect[i];
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole per-step host prologue of the plain PCGmix methods in one call: partner draw, boundary
+// validation, packing into pinned staging, ONE async H2D copy, kernel launch.  In Python the same
+// steps cost ~45 us per call (numpy temporaries, three ctypes crossings, torch's copy_ dispatch)
+// for a 10 us kernel; here ~10 us.
+extern "C" int pcgmix_splice_same_label_f32(const float* x, float* y, const int64_t* labels,
+                                            const int64_t* frames, uint64_t step, float lam,
+                                            const double* knots, const double* spline_op,
+                                            int n_knots, void* staging, void* dev_idx,
+                                            int64_t* mix_out, int B, int C, int T,
+                                            pcgmix_stream_t stream) {
+  if (!x || !y || !labels || !frames || !staging || !dev_idx || !mix_out || B <= 0 || C <= 0 ||
+      T <= 0 || (knots && (!spline_op || n_knots < 2)))
+    return hipErrorInvalidValue;
+  // groups of equal label in order of first appearance (augmentations.py:500-510)
+  std::vector<int64_t> keys;
+  std::vector<std::vector<int64_t>> members;
+  for (int b = 0; b < B; ++b) {
+    size_t g = 0;
+    while (g < keys.size() && keys[g] != labels[b]) ++g;
+    if (g == keys.size()) {
+      keys.push_back(labels[b]);
+      members.emplace_back();
+    }
+    members[g].push_back(b);
+  }
+  // a fresh Random(step) per group: initialise the generator once, copy its state per group
+  const PyRandom seeded(step);
+  std::vector<int64_t> pool;
+  for (const auto& idx : members) {
+    const size_t n = idx.size();
+    PyRandom rng = seeded;
+    pool = idx;
+    for (size_t i = 0; i < n; ++i) {                 // sample(population, k = n): pool branch
+      const uint64_t j = rng.randbelow((uint64_t)(n - i));
+      mix_out[idx[i]] = pool[j];
+      pool[j] = pool[n - i - 1];
+    }
+  }
+  int32_t* st = static_cast<int32_t*>(staging);
+  const int perr = pcgmix_pack_plan_i32(frames, mix_out, nullptr, nullptr, B, T, st);
+  if (perr) return perr > 0 && perr <= 3 ? -perr : perr;   // -1..-3: malformed boundaries
+  const size_t n_int = (size_t)B * 6, n_int_pad = (n_int + 1) & ~(size_t)1;
+  size_t nbytes = n_int_pad * 4;
+  const double* knots_dev = nullptr;
+  if (knots) {
+    const size_t nk = (size_t)B * n_knots * C;
+    std::memcpy(reinterpret_cast<char*>(staging) + nbytes, knots, nk * sizeof(double));
+    knots_dev = reinterpret_cast<const double*>(static_cast<char*>(dev_idx) + nbytes);
+    nbytes += nk * sizeof(double);
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const hipError_t ce = hipMemcpyAsync(dev_idx, staging, nbytes, hipMemcpyHostToDevice, s);
+  if (ce != hipSuccess) return (int)ce;
+  const int32_t* d = static_cast<const int32_t*>(dev_idx);
+  return pcgmix_mix_warp_f32(x, y, d, d + (size_t)B * 5, nullptr, lam, knots_dev, spline_op,
+                             knots ? n_knots : 0, nullptr, B, C, T, stream);
+}
+
+extern "C" long long pcgmix_splice_staging_bytes(int B, int C, int n_knots) {
+  if (B < 0 || C < 0 || n_knots < 0) return 0;
+  const long long n_int_pad = ((long long)B * 6 + 1) & ~1ll;
+  return n_int_pad * 4 + (long long)B * n_knots * C * 8;
 }

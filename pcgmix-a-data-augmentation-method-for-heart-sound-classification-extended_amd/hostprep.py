@@ -112,6 +112,24 @@ def parse_magwarp(method: str):
     return sigma, knot
 
 
+@functools.lru_cache(maxsize=256)
+def plain_recipe(method: str, is2d: bool):
+    """(name, p, alpha, sigma, knots) when ``method`` is a plain splice — same-label partners, no
+    '(rand)' offsets, no saliency, no 2D mask — i.e. what ``pcgmix_splice_same_label_f32`` does in
+    one call; None otherwise (the general ``make_plan`` path handles those)."""
+    name = select_method(method, is2d)
+    if name is None:
+        return None
+    if is2d:
+        if name != "durratiomixup":
+            return None
+        return name, parse_probability(method), 1.0, 0.0, 0          # augmentations2d.py:411
+    if any(t in method for t in ("(rand)", "(salopt", "(samePCG)", "(sameDataset)", "(mixAll)")):
+        return None
+    sigma, knot = parse_magwarp(method) if name == "durmixmagwarp" else (0.0, -2)
+    return name, parse_probability(method), parse_alpha(method, name), sigma, knot + 2
+
+
 def gate_fires(method: str, step: int) -> bool:
     """Fresh ``Random(step)``; the method runs iff u < p (augmentations.py:869-872).  The draw is
     the library's bit-exact restatement of ``random.Random(step).uniform(0, 1)``."""

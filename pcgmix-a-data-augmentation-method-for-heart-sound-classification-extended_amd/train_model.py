@@ -389,14 +389,22 @@ class GraphedTrainStep:
         data = data.to(self.device, non_blocking=True)
         frames_np = augmentations._as_numpy_frames(frames)
         B, C, T = data.shape
-        plan = hostprep.make_plan(args.method, target.numpy(), frames_np, wav,
-                                  int(step_counter.count), B, C) \
-            if hostprep.select_method(args.method, False) else hostprep.MixPlan(fired=False)
-        if plan.salopt_mode is not None:
-            raise NotImplementedError("saliency-guided steps are not captured; use train_step")
-        if plan.fired:
-            augmentations.apply_plan(plan, data, frames_np, out=self.x)
+        step = int(step_counter.count)
+        recipe = hostprep.plain_recipe(args.method, False)
+        if recipe is not None and B > 0:                # plain splice: one library call
+            fired = recipe[1] >= 1.0 or hostprep.gate_fires(args.method, step)
+            plan = hostprep.MixPlan(fired=False)
+            if fired:
+                augmentations.splice_plain(recipe, data, target.numpy(), frames_np, step, out=self.x)
         else:
+            plan = hostprep.make_plan(args.method, target.numpy(), frames_np, wav, step, B, C) \
+                if hostprep.select_method(args.method, False) else hostprep.MixPlan(fired=False)
+            if plan.salopt_mode is not None:
+                raise NotImplementedError("saliency-guided steps are not captured; use train_step")
+            fired = plan.fired
+            if fired:
+                augmentations.apply_plan(plan, data, frames_np, out=self.x)
+        if not fired:
             self.x.copy_(data, non_blocking=True)
         if plan.fired and plan.mix_all:                 # float blend of the one-hot rows
             t_ohe = F.one_hot(target, args.num_classes).to(self.device, non_blocking=True)
