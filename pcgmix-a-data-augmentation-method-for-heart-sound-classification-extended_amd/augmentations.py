@@ -276,10 +276,27 @@ def blend_targets(target_ohe: torch.Tensor, plan: MixPlan) -> torch.Tensor:
     return target_ohe * lt + target_ohe[mix] * (1 - lt)
 
 
+_LABEL_PINNED: dict = {}
+
+
 def labels_from_ohe(target_ohe: torch.Tensor) -> np.ndarray:
     """Reverse the one-hot encoding on the host (augmentations.py:501): one D2H copy of the
-    (B, classes) matrix, argmax (first maximum, like torch.max) in numpy — no reduce kernel."""
-    return target_ohe.detach().cpu().numpy().argmax(axis=1)
+    (B, classes) matrix, argmax (first maximum, like torch.max) in numpy — no reduce kernel.
+    The copy lands in a cached pinned buffer and the launch stream is synchronised: with the
+    previous step's kernel still in flight ``tensor.cpu()`` measured 51 us, this 23 us
+    (profiles/probes/label_readback.py)."""
+    t = target_ohe.detach()
+    if not t.is_cuda:
+        return t.numpy().argmax(axis=1)
+    key = (t.device.index, t.dtype)
+    buf = _LABEL_PINNED.get(key)
+    if buf is None or buf.numel() < t.numel():
+        buf = torch.empty(max(4096, t.numel()), dtype=t.dtype, pin_memory=True)
+        _LABEL_PINNED[key] = buf
+    host = buf[:t.numel()].view(t.shape)
+    host.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return host.numpy().argmax(axis=1)
 
 
 def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RESULTS_ARGS,

@@ -181,3 +181,20 @@ def test_mask_rectangles_match_reference_zero_pattern():
         mask = ((rows >= r[:, 0, None, None]) & (rows < r[:, 1, None, None])
                 & (cols >= r[:, 2, None, None]) & (cols < r[:, 3, None, None]))
         assert np.array_equal(mask, g["y"][:, 0] == 0), path
+
+
+def test_plain_recipe_selects_the_one_call_path():
+    """Which method strings take pcgmix_splice_same_label_f32 (plain same-label splice) and which
+    fall back to the general plan; parsed fields follow the reference's string rules."""
+    from pcgmix_amd import hostprep as H
+    assert H.plain_recipe("durratiomixup", False) == ("durratiomixup", 1.0, 1.0, 0.0, 0)
+    assert H.plain_recipe("durratiomixup+0.2", False)[1] == 0.2
+    assert H.plain_recipe("(alpha=0.4)durratiomixup", False)[2] == 0.4
+    assert H.plain_recipe("durmixmagwarp(0.3,5)+0.5", False) == ("durmixmagwarp", 0.5, 1.0, 0.3, 7)
+    assert H.plain_recipe("durmixmagwarp", False)[3:] == (0.2, 6)
+    for m in ("(rand)durratiomixup", "(saloptenv)durmixmagwarp(0.2,4)", "(samePCG)durratiomixup",
+              "(sameDataset)durratiomixup", "(mixAll)durratiomixup"):
+        assert H.plain_recipe(m, False) is None, m
+    assert H.plain_recipe("base", False) is None and H.plain_recipe("base", True) is None
+    assert H.plain_recipe("(alpha=0.4)durratiomixup", True) == ("durratiomixup", 1.0, 1.0, 0.0, 0)
+    assert H.plain_recipe("durmixcutout(0.2,0.2)", True) is None
