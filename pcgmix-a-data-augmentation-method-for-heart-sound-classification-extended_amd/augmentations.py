@@ -324,14 +324,21 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
         out, mix = splice_plain(recipe, data, labels, frames_np, step)
         return out, target_ohe, mix, None
     labels = (lambda: labels_from_ohe(target_ohe)) if host_labels is None else np.asarray(host_labels)
-    plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, C, is2d=False)
-    if not plan.fired:
-        return data, target_ohe, [], None
     sal = None
-    if plan.salopt_mode is not None:
+    if "(salopt" in method and B > 0:
+        # Saliency-guided step: read the labels back FIRST (the stream is still short), enqueue
+        # the frozen model's forward + input gradient + post-processing, and only then do the
+        # host part of the plan (permutation, lambda, B*(k+2)*C normal draws: ~0.1 ms) while the
+        # GPU works.  The saliency maps use no host RNG, so the reference's draw order is kept.
+        if not hostprep.gate_fires(method, step):
+            return data, target_ohe, [], None
+        labels = labels() if callable(labels) else labels
         from . import saliency as _sal
         sal = _sal.get_saliency_maps(args, data.device, data, target_ohe, frames_np, dim=1,
                                      gauss_k_n=101)
+    plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, C, is2d=False)
+    if not plan.fired:
+        return data, target_ohe, [], None
     out = apply_plan(plan, data, frames_np, sal)
     if plan.mix_all:
         target_ohe = blend_targets(target_ohe, plan)

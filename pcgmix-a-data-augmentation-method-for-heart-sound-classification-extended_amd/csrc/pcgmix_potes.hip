@@ -301,28 +301,33 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
     {  // back through conv2 to the owned a1 positions q = 2p0+r, then pool1/ReLU1 -> dz1
        // wave w -> channels 2w, 2w+1; lane -> r0 = 4*lane .. +3
       const int r0 = 4 * lane;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int ci = __builtin_amdgcn_readfirstlane(2 * wave + c);
-        float da1[4] = {0.f, 0.f, 0.f, 0.f};
+      const int ci0 = __builtin_amdgcn_readfirstlane(2 * wave);
+      float da1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 1
-        for (int co = 0; co < kC2; ++co) {
-          float dw[12], w[kK];
-          lds_load12(dz2s + co * kDz2Row + r0, dw);   // dz2 index r+5-k, r = r0+u: r0+1 .. r0+8
+      for (int co = 0; co < kC2; ++co) {     // one dz2 window per co serves both channels
+        float dw[12];
+        lds_load12(dz2s + co * kDz2Row + r0, dw);   // dz2 index r+5-k, r = r0+u: r0+1 .. r0+8
 #pragma unroll
-          for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci) * kK + k];
+        for (int c = 0; c < 2; ++c) {
+          float w[kK];
+#pragma unroll
+          for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci0 + c) * kK + k];
 #pragma unroll
           for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int k = 0; k < kK; ++k) da1[u] = fmaf(dw[u + 5 - k], w[k], da1[u]);
+            for (int k = 0; k < kK; ++k) da1[c][u] = fmaf(dw[u + 5 - k], w[k], da1[c][u]);
         }
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int ci = ci0 + c;
         float out[8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int r = r0 + u;
           const uint8_t sc = r < kBwdNS ? sel1[ci * kBwdNQ + r + 5] : 0;   // 0 outside [0,P1) too
-          out[2 * u] = sc == 1 ? da1[u] : 0.f;
-          out[2 * u + 1] = sc == 2 ? da1[u] : 0.f;
+          out[2 * u] = sc == 1 ? da1[c][u] : 0.f;
+          out[2 * u + 1] = sc == 2 ? da1[c][u] : 0.f;
         }
         f4* dst = reinterpret_cast<f4*>(dz1s + ci * kBwdNIpad + 8 * lane);
         dst[0] = f4{out[0], out[1], out[2], out[3]};

@@ -98,12 +98,14 @@ def _baseline_model(args, device, dim: int) -> torch.nn.Module:
 
 def input_gradient(model: torch.nn.Module, data: torch.Tensor, target_ohe: torch.Tensor):
     """d score[true class] / d input (saliency.py:52-61); model is in eval mode and frozen."""
-    target = target_ohe.max(1, keepdim=True)[1]
-    x = data.detach().clone().requires_grad_(True)
+    target = target_ohe.max(1, keepdim=True)[1]            # first maximum, as the reference
+    x = data.detach().requires_grad_(True)                 # shares storage; nothing writes to it
     with torch.enable_grad():
         out = model(x)
-        scores = out.gather(1, target.view(-1, 1)).squeeze(1)
-        (grad,) = torch.autograd.grad(scores, x, torch.ones_like(scores))
+        # d(out[b, target_b])/dx summed over b == backward of `out` seeded with one-hot(target):
+        # spares the gather, its backward scatter and the ones() of the reference formulation
+        seed = torch.zeros_like(out).scatter_(1, target, 1.0)
+        (grad,) = torch.autograd.grad(out, x, seed)
     return grad.contiguous()
 
 
