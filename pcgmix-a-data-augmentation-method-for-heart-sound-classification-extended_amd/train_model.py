@@ -147,7 +147,9 @@ class ClipAdam(torch.optim.Adam):
             steps = {int(self.state[p]["step"]) for p in live}
             if len(steps) != 1:
                 raise RuntimeError("ClipAdam: parameters of one group must share the step count")
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in live]
+            # flat iteration over raw memory: p, grad, m, v must share one dense layout
+            grads = [p.grad if p.grad.stride() == p.stride() else torch.empty_like(p).copy_(p.grad)
+                     for p in live]
             key = tuple(p.data_ptr() for p in live)
             tab = self._tables.get(gi)
             if tab is None or tab[0] != key:          # pointer tables of the static tensors
@@ -207,7 +209,9 @@ def make_optimizer(args, model: nn.Module):
     if args.op == "SGD":
         opt = torch.optim.SGD(params, lr=args.lr_max, weight_decay=args.weight_decay)
     elif args.op == "adam":
-        if all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params):
+        dense = lambda p: p.is_contiguous() or (   # noqa: E731
+            p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+        if all(p.is_cuda and p.dtype == torch.float32 and dense(p) for p in params):
             # clip + Adam in one HIP pass per tensor (train_step then skips clip_grad_value_)
             opt = ClipAdam(params, lr=args.lr_max, weight_decay=args.weight_decay,
                            clip_value=args.grad_clip)

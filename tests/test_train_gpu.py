@@ -242,3 +242,60 @@ def test_clip_adam_state_dict_round_trip(device):
         oa.step(); ob.step()
     for x, y in zip(pa, pb):
         assert torch.allclose(x, y, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_resnet9_channels_last_path_matches_float64(train, device):
+    """ResNet9-1D executed as (B,C,1,L) channels_last conv2d/batch_norm/max_pool2d with the same
+    parameters, against a float64 CPU run of the Conv1d/BatchNorm1d/MaxPool1d modules: logits,
+    every gradient (relative L2), BN buffers.  (The fp32 module path on this stack goes through
+    MIOpen Winograd kernels and is itself 5e-2 away from float64 on some gradients, the
+    channels_last path 1e-3: profiles/probes/resnet_grad_noise.py — so float64 is the yardstick.)"""
+    import copy
+    from pcgmix_amd import models
+    torch.manual_seed(5)
+    ref = models.ResNet9(4, 2).train(train)
+    x = torch.randn(8, 4, 2500)
+    m = copy.deepcopy(ref).to(device)
+    assert m.nhwc
+    ref = ref.double()
+    xd = x.to(device)
+    out = m(xd, depth=0, pass_part="second")
+    want = ref(x.double(), depth=0, pass_part="second")
+    assert torch.allclose(out.cpu().double(), want, rtol=1e-4, atol=1e-4)
+    mid = m(xd, depth=1, pass_part="first")
+    assert mid.shape == (8, 128, 1250)
+    ref_mid = ref(x.double(), depth=1, pass_part="first")
+    assert torch.allclose(mid.cpu().double(), ref_mid, rtol=1e-3, atol=1e-4)
+    tail = m(mid, depth=1, pass_part="second")
+    ref(ref_mid, depth=1, pass_part="second")       # same sequence of BatchNorm buffer updates
+    if not train:                                   # eval: the two-part pass equals the full pass
+        assert torch.allclose(tail, out, rtol=1e-4, atol=1e-4)
+    else:
+        m.zero_grad(set_to_none=True)
+        m(xd).square().sum().backward()
+        ref(x.double()).square().sum().backward()
+        for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            n = float(q.grad.norm())
+            err = float((p.grad.cpu().double() - q.grad).norm())
+            assert err <= 1e-2 * n + 1e-4, (k, err, n)
+    for (k, v), (_, w) in zip(m.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(v.cpu().double(), w.double(), rtol=1e-4, atol=1e-5), k
+
+
+def test_clip_adam_channels_last_parameters(device):
+    """Conv weights kept channels_last (models2d) update exactly like contiguous ones, whether the
+    gradient arrives in the parameter's layout or contiguous."""
+    torch.manual_seed(2)
+    w = torch.randn(16, 8, 3, 3, device=device)
+    pa = [torch.nn.Parameter(w.clone().contiguous(memory_format=torch.channels_last))]
+    pb = [torch.nn.Parameter(w.clone())]
+    oa, ob = tm.ClipAdam(pa, lr=0.01, weight_decay=1e-4, clip_value=0.1), torch.optim.Adam(pb, lr=0.01, weight_decay=1e-4)
+    for it in range(4):
+        g = torch.randn_like(w) * 0.2
+        pa[0].grad = g.clone().contiguous(memory_format=torch.channels_last) if it % 2 else g.clone()
+        pb[0].grad = g.clone()
+        torch.nn.utils.clip_grad_value_(pb, 0.1)
+        oa.step(); ob.step()
+    assert pa[0].is_contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(pa[0], pb[0], rtol=1e-5, atol=1e-6)
