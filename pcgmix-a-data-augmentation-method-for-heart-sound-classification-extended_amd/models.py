@@ -288,6 +288,49 @@ def _res_block(c_in: int, c_out: int, pool: bool = False) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
+def conv_bn_relu_pool(h, weight4, conv_bias, padding, bn, training: bool, pool):
+    """Conv -> BatchNorm -> ReLU [-> MaxPool] on a 4-D (channels_last) activation with the
+    convolution's bias folded into the BatchNorm instead of added by a separate pass.
+
+    BN(conv(x) + b) == BN(conv(x)): a per-channel constant cancels in (y - mean(y)), so in training
+    mode the bias only shows up in the running mean (+ momentum * b per step, added below) and its
+    true gradient is zero — through torch it comes out as ~1e-14 rounding noise, which Adam's eps
+    (1e-8) swamps; ``beta + 0 * b`` gives it an exact zero gradient so that the optimiser still
+    applies weight decay to it, as it does in the reference.  In eval mode the running mean is
+    shifted by b instead.  Saves a bias-add pass over the activation and a (B, L) reduction for the
+    bias gradient per layer (2.7 ms of a 42 ms ResNet9-1D step)."""
+    h = F.conv2d(h, weight4, None, padding=padding)
+    batch_stats = training or not bn.track_running_stats
+    if bn.momentum is None or bn.momentum >= 1.0 or conv_bias is None:    # no fold
+        if conv_bias is not None:
+            h = h + conv_bias.view(1, -1, 1, 1)
+        if training and bn.track_running_stats:
+            bn.num_batches_tracked.add_(1)
+        factor = 0.0 if bn.momentum is None else bn.momentum
+        if bn.momentum is None and training and bn.track_running_stats:
+            factor = 1.0 / float(bn.num_batches_tracked)
+        h = F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias, batch_stats,
+                         factor, bn.eps)
+    elif batch_stats:
+        if training and bn.track_running_stats:
+            bn.num_batches_tracked.add_(1)                  # as nn.BatchNorm.forward does
+        beta = bn.bias + 0.0 * conv_bias
+        if bn.track_running_stats and bn.momentum < 1.0:
+            # new = (1-m) * (old + m/(1-m) * b) + m * mean(conv) = (1-m) * old + m * (mean(conv) + b);
+            # shifted BEFORE the call: autograd saves the buffer and rejects a later in-place edit
+            with torch.no_grad():
+                bn.running_mean.add_(conv_bias, alpha=bn.momentum / (1.0 - bn.momentum))
+        h = F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, beta, True, bn.momentum,
+                         bn.eps)
+    else:
+        h = F.batch_norm(h, bn.running_mean - conv_bias.detach(), bn.running_var, bn.weight,
+                         bn.bias, False, 0.0, bn.eps)
+    h = F.relu(h, inplace=True)
+    if pool is not None:
+        h = F.max_pool2d(h, pool)
+    return h
+
+
 class ResNet9_myrtle(nn.Module):
     """reference models.py:520-589 (the second definition, which shadows the first)."""
 
@@ -316,16 +359,9 @@ class ResNet9_myrtle(nn.Module):
     def _block(self, seq, h):
         if h.dim() == 3:
             return seq(h)
-        conv, bn = seq[0], seq[1]
-        h = F.conv2d(h, conv.weight.unsqueeze(2), conv.bias, padding=(0, conv.padding[0]))
-        if self.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)                  # as nn.BatchNorm1d.forward does
-        h = F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                         self.training or not bn.track_running_stats, bn.momentum, bn.eps)
-        h = F.relu(h, inplace=True)
-        if len(seq) > 3:
-            h = F.max_pool2d(h, (1, seq[3].kernel_size))
-        return h
+        pool = (1, seq[3].kernel_size) if len(seq) > 3 else None
+        return conv_bn_relu_pool(h, seq[0].weight.unsqueeze(2), seq[0].bias, (0, seq[0].padding[0]),
+                                 seq[1], self.training, pool)
 
     def _stage1(self, out):
         out = self._block(self.conv2, self._block(self.conv1, out))

@@ -35,13 +35,21 @@ class ResNet9_myrtle(nn.Module):
         # Values, state_dict keys and shapes are unchanged (a memory format, not a reshape).
         self.to(memory_format=torch.channels_last)
 
+    def _block(self, seq, h):
+        if not h.is_cuda:
+            return seq(h)
+        from .models import conv_bn_relu_pool               # bias folded into the BatchNorm
+        pool = seq[3].kernel_size if len(seq) > 3 else None
+        return conv_bn_relu_pool(h, seq[0].weight, seq[0].bias, seq[0].padding, seq[1],
+                                 self.training, pool)
+
     def _stage1(self, out):
-        out = self.conv2(self.conv1(out))
-        return self.res1(out) + out
+        out = self._block(self.conv2, self._block(self.conv1, out))
+        return self._block(self.res1[1], self._block(self.res1[0], out)) + out
 
     def _stage2(self, out):
-        out = self.conv4(self.conv3(out))
-        return self.res2(out) + out
+        out = self._block(self.conv4, self._block(self.conv3, out))
+        return self._block(self.res2[1], self._block(self.res2[0], out)) + out
 
     def forward(self, out, depth=None, pass_part=None):
         if pass_part == "first" and depth == 0:

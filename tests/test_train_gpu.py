@@ -299,3 +299,27 @@ def test_clip_adam_channels_last_parameters(device):
         oa.step(); ob.step()
     assert pa[0].is_contiguous(memory_format=torch.channels_last)
     assert torch.allclose(pa[0], pb[0], rtol=1e-5, atol=1e-6)
+
+
+def test_resnet9_2d_matches_float64(device):
+    """ResNet9-2D on the HIP path (channels_last, conv bias folded into BN) against a float64 CPU
+    run of the plain modules: logits, gradients (relative L2), BN buffers; and eval mode."""
+    import copy
+    from pcgmix_amd import models2d
+    torch.manual_seed(3)
+    ref = models2d.ResNet9(2).train()
+    x = torch.randn(4, 1, 128, 128)
+    m = copy.deepcopy(ref).to(device)
+    ref = ref.double()
+    out = m(x.to(device))
+    want = ref(x.double())
+    assert torch.allclose(out.cpu().double(), want, rtol=1e-4, atol=1e-4)
+    out.square().sum().backward()
+    want.square().sum().backward()
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        n = float(q.grad.norm())
+        assert float((p.grad.cpu().double() - q.grad).norm()) <= 1e-2 * n + 1e-4, k
+    for (k, v), (_, w) in zip(m.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(v.cpu().double(), w.double(), rtol=1e-4, atol=1e-5), k
+    m.eval(); ref.eval()
+    assert torch.allclose(m(x.to(device)).cpu().double(), ref(x.double()), rtol=1e-4, atol=1e-4)
