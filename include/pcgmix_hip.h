@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 6
+#define PCGMIX_ABI_VERSION 7
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -322,6 +322,31 @@ int pcgmix_splice_same_label_f32(const float* x, float* y, const int64_t* labels
                                  void* staging, void* dev_idx, int64_t* mix_out, int B, int C,
                                  int T, pcgmix_stream_t stream);
 long long pcgmix_splice_staging_bytes(int B, int C, int n_knots);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm (training mode) + ReLU + MaxPool of a ResNet9 block, channels innermost.  [device]
+ *
+ * Replaces nn.BatchNorm1d/2d -> nn.ReLU -> nn.MaxPool1d/2d of conv_block (models.py:468-473,
+ * models2d.py:13-19) and their autograd.  y is the convolution output stored NHWC: (B, H, W, C)
+ * row-major (H = 1 for the 1D network), C % 4 == 0 and 256 % (C / 4) == 0 (64 ... 1024).
+ *   forward : batch mean / biased variance per channel -> z (B, H/ph, W/pw, C) =
+ *             maxpool_{ph x pw}(relu(gamma * (y - mean) / sqrt(var + eps) + beta));  ph = pw = 1:
+ *             no pooling.  mean, invstd (C each) are outputs kept for backward; running_mean /
+ *             running_var (may be NULL) are updated in place with `momentum` (unbiased variance).
+ *   backward: dz (shape of z) -> dx (shape of y), dgamma, dbeta (C each).  The ReLU mask and the
+ *             pooling arg-max (first maximum) are recomputed from y.
+ * workspace: pcgmix_bnrp_workspace_floats(B, H, W, C) floats.  All pointers 16-byte aligned.
+ * Each direction reads y twice and writes its output once; reductions are fixed-order.
+ */
+long long pcgmix_bnrp_workspace_floats(int B, int H, int W, int C);
+int pcgmix_bnrp_fwd_f32(const float* y, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float momentum, float eps, float* z, float* mean,
+                        float* invstd, float* workspace, int B, int H, int W, int C, int ph, int pw,
+                        pcgmix_stream_t stream);
+int pcgmix_bnrp_bwd_f32(const float* y, const float* dz, const float* gamma, const float* beta,
+                        const float* mean, const float* invstd, float* dx, float* dgamma,
+                        float* dbeta, float* workspace, int B, int H, int W, int C, int ph, int pw,
+                        pcgmix_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -62,6 +62,11 @@ SIGNATURES = {
                                               _ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int,
                                               _ptr]),
     "pcgmix_splice_staging_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
+    "pcgmix_bnrp_workspace_floats": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int]),
+    "pcgmix_bnrp_fwd_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float, _ptr, _ptr, _ptr,
+                                     _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr]),
+    "pcgmix_bnrp_bwd_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int,
+                                     _c_int, _c_int, _c_int, _c_int, _c_int, _ptr]),
 }
 
 _lib = None

@@ -288,6 +288,64 @@ def _res_block(c_in: int, c_out: int, pool: bool = False) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
+FUSED_BN = True      # BatchNorm + ReLU + MaxPool through the HIP kernels (False: torch ops)
+
+
+class BNReLUPoolFunction(torch.autograd.Function):
+    """Training-mode BatchNorm + ReLU + MaxPool on a channels_last activation through
+    ``pcgmix_bnrp_{fwd,bwd}_f32``: five passes over the activation per block (forward + backward)
+    instead of ten.  ``y`` is (B, C, H, W) channels_last; returns (B, C, H/ph, W/pw) channels_last.
+    The running statistics are updated in place, as ``F.batch_norm(training=True)`` does."""
+
+    @staticmethod
+    def supported(y: torch.Tensor) -> bool:
+        C = y.shape[1] if y.dim() == 4 else 0
+        return (y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and C % 4 == 0
+                and C // 4 <= 256 and 256 % (C // 4) == 0 and y.numel() > 0
+                and y.is_contiguous(memory_format=torch.channels_last))
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum, eps, ph, pw):
+        B, C, H, W = y.shape
+        lib = _lib.load()
+        dev = y.device
+        z = torch.empty((B, C, H // ph, W // pw), dtype=torch.float32, device=dev,
+                        memory_format=torch.channels_last)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.pcgmix_bnrp_workspace_floats(B, H, W, C), dtype=torch.float32, device=dev)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.pcgmix_bnrp_fwd_f32(
+            y.data_ptr(), g.data_ptr(), b.data_ptr(),
+            running_mean.data_ptr() if running_mean is not None else None,
+            running_var.data_ptr() if running_var is not None else None,
+            ctypes.c_float(momentum), ctypes.c_float(eps), z.data_ptr(), mean.data_ptr(),
+            invstd.data_ptr(), ws.data_ptr(), B, H, W, C, ph, pw, stream), "pcgmix_bnrp_fwd_f32")
+        ctx.save_for_backward(y, g, b, mean, invstd)
+        ctx.pool = (ph, pw)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, g, b, mean, invstd = ctx.saved_tensors
+        B, C, H, W = y.shape
+        ph, pw = ctx.pool
+        lib = _lib.load()
+        dev = y.device
+        dz = dz.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(y)                             # preserves channels_last
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.pcgmix_bnrp_workspace_floats(B, H, W, C), dtype=torch.float32, device=dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.pcgmix_bnrp_bwd_f32(
+            y.data_ptr(), dz.data_ptr(), g.data_ptr(), b.data_ptr(), mean.data_ptr(),
+            invstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+            B, H, W, C, ph, pw, stream), "pcgmix_bnrp_bwd_f32")
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
 def conv_bn_relu_pool(h, weight4, conv_bias, padding, bn, training: bool, pool):
     """Conv -> BatchNorm -> ReLU [-> MaxPool] on a 4-D (channels_last) activation with the
     convolution's bias folded into the BatchNorm instead of added by a separate pass.
@@ -320,6 +378,10 @@ def conv_bn_relu_pool(h, weight4, conv_bias, padding, bn, training: bool, pool):
             # shifted BEFORE the call: autograd saves the buffer and rejects a later in-place edit
             with torch.no_grad():
                 bn.running_mean.add_(conv_bias, alpha=bn.momentum / (1.0 - bn.momentum))
+        if FUSED_BN and training and bn.track_running_stats and BNReLUPoolFunction.supported(h):
+            ph, pw = (1, 1) if pool is None else ((pool, pool) if isinstance(pool, int) else pool)
+            return BNReLUPoolFunction.apply(h, bn.weight, beta, bn.running_mean, bn.running_var,
+                                            float(bn.momentum), float(bn.eps), int(ph), int(pw))
         h = F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, beta, True, bn.momentum,
                          bn.eps)
     else:
