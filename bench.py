@@ -521,6 +521,22 @@ def main():
 
     # train step/s (second half of BASELINE.json's metric): 1D-CNN, bs 256 per GPU, DDP if N>1
     train = None
+    guard = None
+    if not a.no_train and world > 1:
+        # The N>1 train leg is the one part of this file that cannot be rehearsed on a one-GPU
+        # box with RCCL.  If it ever hangs (a collective waiting for a rank that failed), the
+        # headline line must still come out: after 180 s every rank gives up, rank 0 prints the
+        # result it has, and the processes exit without waiting for the stuck call.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                result["train"] = {"error": "train leg did not finish within 180 s"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+        guard = threading.Timer(180.0, give_up)
+        guard.daemon = True
+        guard.start()
     if not a.no_train:
         try:
             train = train_steps_per_s(a.method, "Potes", B, C, T, rate, device,
@@ -547,6 +563,8 @@ def main():
         train["global_batch"] = B * world
         train["samples_per_s"] = train["steps_per_s"] * B * world
         result["train"] = train
+        if guard is not None:
+            guard.cancel()
 
     if rank == 0 and world == 1:
         extra = {}

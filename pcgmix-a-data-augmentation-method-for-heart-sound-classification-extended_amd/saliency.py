@@ -141,7 +141,8 @@ class _SaliencyGraph:
                 self._run()
         torch.cuda.current_stream(device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: HIP calls of other threads (e.g. RCCL's watchdog) must not abort the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.sal = self._run()
 
     def _run(self):

@@ -370,8 +370,14 @@ class GraphedTrainStep:
                 sync.attach()
         torch.cuda.current_stream(device).wait_stream(side)
         self.opt.zero_grad(set_to_none=True)
+        if sync is not None and sync.world > 1:
+            # no collective may be in flight while the graph is captured, and every rank must
+            # capture (or fail) together
+            torch.cuda.synchronize(device)
+            sync.dist.barrier()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: HIP calls of other threads (RCCL's watchdog) must not abort the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss, self.out = self._fwd_bwd()
 
     def _fwd_bwd(self):
