@@ -221,7 +221,9 @@ __global__ __launch_bounds__(kFinCh * 16) void bn_bwd_finalize_kernel(
 }
 
 // dx = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat)), dy = dz at the window's arg-max
-// where the activation is positive, 0 elsewhere (also for rows no window covers).
+// where the activation is positive, 0 elsewhere.  One thread per (window, channel quad): every y
+// of the window is read once and every dx written once.  Positions that no window covers (odd
+// lengths: H % ph rows, W % pw columns) have dy = 0 and are written by the tail loop.
 __global__ __launch_bounds__(kBnThreads) void bnrp_bwd_apply_kernel(
     const f4* __restrict__ y, const f4* __restrict__ dz, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mean,
@@ -232,28 +234,65 @@ __global__ __launch_bounds__(kBnThreads) void bnrp_bwd_apply_kernel(
   const f4 mu = *reinterpret_cast<const f4*>(mean + 4 * q), is = *reinterpret_cast<const f4*>(invstd + 4 * q);
   const f4 c1 = *reinterpret_cast<const f4*>(coef + 4 * q), c2 = *reinterpret_cast<const f4*>(coef + s.C + 4 * q);
   const f4 scale = g * is, shift = bt - mu * scale;
-  const long long n_in = (long long)s.B * s.H * s.W * s.Q;
   const long long stride = (long long)gridDim.x * kBnThreads;
-  for (long long i = (long long)blockIdx.x * kBnThreads + threadIdx.x; i < n_in; i += stride) {
-    const long long row = i / s.Q;
-    const int w = (int)(row % s.W);
-    const long long t = row / s.W;
-    const int h = (int)(t % s.H);
-    const long long b = t / s.H;
-    const int ho = h / s.ph, wo = w / s.pw;
-    const f4 v = y[i];
-    f4 dy = {0.f, 0.f, 0.f, 0.f};
-    if (ho < s.Ho && wo < s.Wo) {
-      int arg[4];
-      const f4 best = window_max(y, s, b, ho, wo, q, scale, shift, arg);
-      const f4 d = dz[((b * s.Ho + ho) * s.Wo + wo) * s.Q + q];
-      const int mine = (h - ho * s.ph) * s.pw + (w - wo * s.pw);
+  const long long n_out = (long long)s.B * s.Ho * s.Wo * s.Q;
+  for (long long o = (long long)blockIdx.x * kBnThreads + threadIdx.x; o < n_out; o += stride) {
+    const long long orow = o / s.Q;
+    const int wo = (int)(orow % s.Wo);
+    const long long t = orow / s.Wo;
+    const int ho = (int)(t % s.Ho);
+    const long long b = t / s.Ho;
+    // pass 1 over the window: arg-max of relu(a) (first maximum)
+    f4 best = {-1.f, -1.f, -1.f, -1.f};
+    int arg[4] = {0, 0, 0, 0};
+    for (int i = 0; i < s.ph; ++i)
+      for (int j = 0; j < s.pw; ++j) {
+        const long long row = (b * s.H + (ho * s.ph + i)) * s.W + (wo * s.pw + j);
+        const f4 a = f4_fma(y[row * s.Q + q], scale, shift);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (best[e] > 0.f && arg[e] == mine) dy[e] = d[e];
-    }
-    const f4 xh = (v - mu) * is;
-    dx[i] = scale * (dy - c1 - xh * c2);
+        for (int e = 0; e < 4; ++e) {
+          const float r = a[e] > 0.f ? a[e] : 0.f;
+          if (r > best[e]) {
+            best[e] = r;
+            arg[e] = i * s.pw + j;
+          }
+        }
+      }
+    const f4 d = dz[o];
+    // pass 2 (the window is in cache): dx for every position
+    for (int i = 0; i < s.ph; ++i)
+      for (int j = 0; j < s.pw; ++j) {
+        const long long row = (b * s.H + (ho * s.ph + i)) * s.W + (wo * s.pw + j);
+        const f4 v = y[row * s.Q + q];
+        f4 dy = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (best[e] > 0.f && arg[e] == i * s.pw + j) dy[e] = d[e];
+        const f4 xh = (v - mu) * is;
+        dx[row * s.Q + q] = scale * (dy - c1 - xh * c2);
+      }
+  }
+  // uncovered positions: columns w >= Wo*pw of every row, then rows h >= Ho*ph of the covered columns
+  const int wc = s.Wo * s.pw, hc = s.Ho * s.ph;
+  const long long n_col = (long long)s.B * s.H * (s.W - wc) * s.Q;
+  for (long long i = (long long)blockIdx.x * kBnThreads + threadIdx.x; i < n_col; i += stride) {
+    const long long r = i / s.Q;
+    const int w = wc + (int)(r % (s.W - wc));
+    const long long bh = r / (s.W - wc);                           // b * H + h
+    const long long e = (bh * s.W + w) * s.Q + q;
+    const f4 xh = (y[e] - mu) * is;
+    dx[e] = scale * (-c1 - xh * c2);
+  }
+  const long long n_row = (long long)s.B * (s.H - hc) * wc * s.Q;
+  for (long long i = (long long)blockIdx.x * kBnThreads + threadIdx.x; i < n_row; i += stride) {
+    const long long r = i / s.Q;
+    const int w = (int)(r % wc);
+    const long long t = r / wc;
+    const int h = hc + (int)(t % (s.H - hc));
+    const long long b = t / (s.H - hc);
+    const long long e = ((b * s.H + h) * s.W + w) * s.Q + q;
+    const f4 xh = (y[e] - mu) * is;
+    dx[e] = scale * (-c1 - xh * c2);
   }
 }
 
@@ -321,7 +360,7 @@ extern "C" int pcgmix_bnrp_bwd_f32(const float* y, const float* dz, const float*
     return hipErrorInvalidValue;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long long rows = (long long)B * H * W;
-  const long long n_out = (long long)B * s.Ho * s.Wo * s.Q, n_in = rows * s.Q;
+  const long long n_out = (long long)B * s.Ho * s.Wo * s.Q;
   const int nblk = bn_blocks(n_out * 2);
   float* coef = workspace + (size_t)kBnMaxBlocks * 2 * C;
   hipLaunchKernelGGL(bnrp_bwd_reduce_kernel, dim3(nblk), dim3(kBnThreads), 0, st,
@@ -329,7 +368,7 @@ extern "C" int pcgmix_bnrp_bwd_f32(const float* y, const float* dz, const float*
                      mean, invstd, workspace, s);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * 16), 0, st, workspace, nblk,
                      C, (double)rows, dgamma, dbeta, coef);
-  hipLaunchKernelGGL(bnrp_bwd_apply_kernel, dim3(bn_blocks(n_in)), dim3(kBnThreads), 0, st,
+  hipLaunchKernelGGL(bnrp_bwd_apply_kernel, dim3(bn_blocks(n_out * 2)), dim3(kBnThreads), 0, st,
                      reinterpret_cast<const f4*>(y), reinterpret_cast<const f4*>(dz), gamma, beta,
                      mean, invstd, coef, reinterpret_cast<f4*>(dx), s);
   return (int)hipGetLastError();
