@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 7
+#define PCGMIX_ABI_VERSION 8
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -321,6 +321,16 @@ int pcgmix_splice_same_label_f32(const float* x, float* y, const int64_t* labels
                                  const double* knots, const double* spline_op, int n_knots,
                                  void* staging, void* dev_idx, int64_t* mix_out, int B, int C,
                                  int T, pcgmix_stream_t stream);
+/* Same, with the labels still on the device as the reference passes them (one-hot int64
+ * (B, num_classes), contiguous): copies them into `ohe_pinned` (PINNED host, B*num_classes
+ * int64), synchronises `stream` (the one host sync the reference's signature forces,
+ * augmentations.py:501), takes the first-maximum argmax and continues as above. */
+int pcgmix_splice_same_label_ohe_f32(const float* x, float* y, const int64_t* target_ohe_dev,
+                                     int num_classes, int64_t* ohe_pinned, const int64_t* frames,
+                                     uint64_t step, float lam, const double* knots,
+                                     const double* spline_op, int n_knots, void* staging,
+                                     void* dev_idx, int64_t* mix_out, int B, int C, int T,
+                                     pcgmix_stream_t stream);
 long long pcgmix_splice_staging_bytes(int B, int C, int n_knots);
 
 /* ------------------------------------------------------------------------------------------

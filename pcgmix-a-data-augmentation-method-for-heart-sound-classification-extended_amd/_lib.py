@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -61,6 +61,9 @@ SIGNATURES = {
     "pcgmix_splice_same_label_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, ctypes.c_uint64, _c_float, _ptr,
                                               _ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int,
                                               _ptr]),
+    "pcgmix_splice_same_label_ohe_f32": (_c_int, [_ptr, _ptr, _ptr, _c_int, _ptr, _ptr, ctypes.c_uint64,
+                                                  _c_float, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr,
+                                                  _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_splice_staging_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
     "pcgmix_bnrp_workspace_floats": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int]),
     "pcgmix_bnrp_fwd_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float, _ptr, _ptr, _ptr,

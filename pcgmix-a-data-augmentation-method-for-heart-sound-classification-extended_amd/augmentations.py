@@ -220,18 +220,25 @@ _SPLICE_ERRORS = {-1: _PACK_ERRORS[1], -2: _PACK_ERRORS[2], -3: _PACK_ERRORS[3]}
 
 
 def splice_plain(recipe, data: torch.Tensor, labels, frames: np.ndarray, step: int,
-                 out: Optional[torch.Tensor] = None):
+                 out: Optional[torch.Tensor] = None, target_ohe: Optional[torch.Tensor] = None):
     """One fired step of a plain splice (``hostprep.plain_recipe``) through
     ``pcgmix_splice_same_label_f32``: the partner draw, validation, packing, the single H2D copy and
     the launch happen inside the library; Python only draws lambda (and the warp knots) from
     numpy's global stream exactly where the reference does (augmentations.py:661-663, 677) and
     picks the staging slot.  ``data`` is (B, C, T) — the 2D path passes (B, F, W).
-    Returns (out, mix_indices)."""
+    ``labels`` = host class labels, or None with ``target_ohe`` = the device one-hot int64 matrix
+    (read back inside the library call).  Returns (out, mix_indices)."""
     _name, _p, alpha, sigma, n_knots = recipe
     B, C, T = data.shape
     device = data.device
-    labels = np.ascontiguousarray(np.asarray(labels).reshape(-1), dtype=np.int64)
-    if labels.shape[0] != B or frames.shape != (B, 5):
+    ohe = None
+    if labels is None:
+        ohe = target_ohe.detach()
+        if not (ohe.is_cuda and ohe.dtype == torch.int64 and ohe.dim() == 2 and ohe.is_contiguous()):
+            labels, ohe = labels_from_ohe(target_ohe), None
+    if ohe is None:
+        labels = np.ascontiguousarray(np.asarray(labels).reshape(-1), dtype=np.int64)
+    if (ohe.shape[0] if ohe is not None else labels.shape[0]) != B or frames.shape != (B, 5):
         raise ValueError("labels/frames do not match the batch size")
     if alpha > 0.0:
         np.random.seed(step)                      # global stream, as the reference
@@ -255,11 +262,23 @@ def splice_plain(recipe, data: torch.Tensor, labels, frames: np.ndarray, step: i
                 or out.data_ptr() == data.data_ptr():
             raise ValueError("out must be a distinct contiguous tensor shaped like data")
         stream = torch.cuda.current_stream(device)
-        err = lib.pcgmix_splice_same_label_f32(
-            data.data_ptr(), out.data_ptr(), labels.ctypes.data, frames.ctypes.data, step,
-            ctypes.c_float(lam32), knots.ctypes.data if knots is not None else None, op_ptr,
-            n_knots, pinned.data_ptr(), dev.data_ptr(), mix.ctypes.data, B, C, T,
-            ctypes.c_void_p(stream.cuda_stream))
+        knots_ptr = knots.ctypes.data if knots is not None else None
+        if ohe is not None:
+            key = (device.index, torch.int64)
+            lab = _LABEL_PINNED.get(key)
+            if lab is None or lab.numel() < ohe.numel():
+                lab = _LABEL_PINNED[key] = torch.empty(max(4096, ohe.numel()), dtype=torch.int64,
+                                                       pin_memory=True)
+            err = lib.pcgmix_splice_same_label_ohe_f32(
+                data.data_ptr(), out.data_ptr(), ohe.data_ptr(), ohe.shape[1], lab.data_ptr(),
+                frames.ctypes.data, step, ctypes.c_float(lam32), knots_ptr, op_ptr, n_knots,
+                pinned.data_ptr(), dev.data_ptr(), mix.ctypes.data, B, C, T,
+                ctypes.c_void_p(stream.cuda_stream))
+        else:
+            err = lib.pcgmix_splice_same_label_f32(
+                data.data_ptr(), out.data_ptr(), labels.ctypes.data, frames.ctypes.data, step,
+                ctypes.c_float(lam32), knots_ptr, op_ptr, n_knots, pinned.data_ptr(),
+                dev.data_ptr(), mix.ctypes.data, B, C, T, ctypes.c_void_p(stream.cuda_stream))
         if err < 0:
             raise ValueError(_SPLICE_ERRORS.get(err, f"pcgmix_splice_same_label_f32 error {err}"))
         _lib.check(err, "pcgmix_splice_same_label_f32")
@@ -320,8 +339,7 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
     if recipe is not None and B > 0:              # the common case: one library call
         if recipe[1] < 1.0 and not hostprep.gate_fires(method, step):
             return data, target_ohe, [], None
-        labels = labels_from_ohe(target_ohe) if host_labels is None else host_labels
-        out, mix = splice_plain(recipe, data, labels, frames_np, step)
+        out, mix = splice_plain(recipe, data, host_labels, frames_np, step, target_ohe=target_ohe)
         return out, target_ohe, mix, None
     labels = (lambda: labels_from_ohe(target_ohe)) if host_labels is None else np.asarray(host_labels)
     sal = None

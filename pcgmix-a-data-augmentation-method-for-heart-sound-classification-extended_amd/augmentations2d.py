@@ -33,8 +33,8 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
     if recipe is not None and B > 0:              # durratiomixup: one library call
         if recipe[1] < 1.0 and not hostprep.gate_fires(method, step):
             return data, target_ohe, [], None
-        labels = labels_from_ohe(target_ohe) if host_labels is None else host_labels
-        out, mix = splice_plain(recipe, data.view(B, Cc * F, W), labels, frames_np, step)
+        out, mix = splice_plain(recipe, data.view(B, Cc * F, W), host_labels, frames_np, step,
+                                target_ohe=target_ohe)
         return out.view(B, Cc, F, W), target_ohe, mix, None
     labels = (lambda: labels_from_ohe(target_ohe)) if host_labels is None else host_labels
     plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, Cc * F, is2d=True, n_cols=W)

@@ -332,6 +332,37 @@ extern "C" int pcgmix_splice_same_label_f32(const float* x, float* y, const int6
                              knots ? n_knots : 0, nullptr, B, C, T, stream);
 }
 
+// The label read-back the reference's signature forces (target_ohe lives on the device,
+// augmentations.py:501) done here as well: D2H of the one-hot matrix into pinned memory, stream
+// synchronisation, first-maximum argmax — then the call above.  Saves the torch dispatch of the
+// copy and a second ctypes crossing per step.
+extern "C" int pcgmix_splice_same_label_ohe_f32(const float* x, float* y,
+                                                const int64_t* target_ohe_dev, int num_classes,
+                                                int64_t* ohe_pinned, const int64_t* frames,
+                                                uint64_t step, float lam, const double* knots,
+                                                const double* spline_op, int n_knots,
+                                                void* staging, void* dev_idx, int64_t* mix_out,
+                                                int B, int C, int T, pcgmix_stream_t stream) {
+  if (!target_ohe_dev || !ohe_pinned || num_classes <= 0 || B <= 0) return hipErrorInvalidValue;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t n = (size_t)B * num_classes;
+  hipError_t e = hipMemcpyAsync(ohe_pinned, target_ohe_dev, n * sizeof(int64_t),
+                                hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return (int)e;
+  e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return (int)e;
+  std::vector<int64_t> labels((size_t)B);
+  for (int b = 0; b < B; ++b) {
+    const int64_t* row = ohe_pinned + (size_t)b * num_classes;
+    int best = 0;
+    for (int c = 1; c < num_classes; ++c)
+      if (row[c] > row[best]) best = c;               // first maximum, as torch.max / np.argmax
+    labels[(size_t)b] = best;
+  }
+  return pcgmix_splice_same_label_f32(x, y, labels.data(), frames, step, lam, knots, spline_op,
+                                      n_knots, staging, dev_idx, mix_out, B, C, T, stream);
+}
+
 extern "C" long long pcgmix_splice_staging_bytes(int B, int C, int n_knots) {
   if (B < 0 || C < 0 || n_knots < 0) return 0;
   const long long n_int_pad = ((long long)B * 6 + 1) & ~1ll;
