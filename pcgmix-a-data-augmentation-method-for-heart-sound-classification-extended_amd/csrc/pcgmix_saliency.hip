@@ -17,7 +17,7 @@
 
 namespace pcgmix {
 
-constexpr int kSalThreads = 256;   // saliency_post: one block per row
+constexpr int kSalThreads = 640;   // saliency_post: one block per row (625 x 8 outputs at T = 5000)
 constexpr int kDispThreads = 1024; // displacement scan: all candidates of a (sample, state) at once
 constexpr int kMaxTaps = 255;
 
@@ -41,7 +41,13 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
   return r;
 }
 
-// One block per row b.  LDS: a[T + ksize - 1] (channel-summed |grad| with zero halo), s[T].
+// One block per row b.  LDS: a[T + ksize - 1 (+pad)] (channel-summed |grad| with zero halo), s[T].
+// KS > 0: the tap count is a compile-time constant and every thread produces 8 consecutive
+// outputs from one 8+KS-1 sample window held in registers (27 ds_read_b128 for 808 FMAs with the
+// reference's 101 taps, instead of one ds_read_b32 per multiply-add): 25 -> ~10 us at bs=256.
+// KS == 0: any odd ksize <= 255, one output per thread per round.  Taps are applied in ascending
+// order either way.
+template <int KS>
 __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
     const float* __restrict__ grad, const int32_t* __restrict__ frames, float* __restrict__ sal,
     Taps taps, int ksize, int B, int C, int T) {
@@ -49,12 +55,13 @@ __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
   __shared__ float red[kSalThreads / 64];
   const int b = blockIdx.x;
   const int half = ksize / 2;
+  const int a_len = (T + ksize - 1 + 8 + 3) & ~3;   // +8: the last window may start up to 7 past T
   float* a = smem;                  // a[half + t]
-  float* s = smem + T + ksize - 1;  // s[t]
+  float* s = smem + a_len;          // s[t]
   int f4 = frames[b * 5 + 4];
   f4 = f4 < 0 ? 0 : (f4 > T ? T : f4);
 
-  for (int i = threadIdx.x; i < T + ksize - 1; i += kSalThreads) {
+  for (int i = threadIdx.x; i < a_len; i += kSalThreads) {
     const int t = i - half;
     float acc = 0.f;
     if (t >= 0 && t < f4) {  // saliency.py:66-67 zeroes t >= f[-1] before the channel sum
@@ -66,13 +73,40 @@ __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
   __syncthreads();
 
   float lmin = INFINITY;
-  for (int t = threadIdx.x; t < T; t += kSalThreads) {
-    float acc = 0.f;
-    if (t < f4) {  // saliency.py:78-79 zeroes the tail again after smoothing
-      for (int j = 0; j < ksize; ++j) acc = __fadd_rn(acc, __fmul_rn(taps.w[j], a[t + j]));
+  if (KS > 0) {
+    constexpr int kWin = (KS > 0 ? KS : 1) + 7;                  // samples feeding 8 outputs
+    constexpr int kWin4 = (kWin + 3) / 4;
+    for (int t0 = 8 * threadIdx.x; t0 < T; t0 += 8 * kSalThreads) {
+      float win[4 * kWin4];
+#pragma unroll
+      for (int q = 0; q < kWin4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(a + t0 + 4 * q);
+        win[4 * q] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+      }
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < kWin; ++j)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j - u >= 0 && j - u < KS) acc[u] = fmaf(taps.w[j - u], win[j], acc[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u;
+        if (t < T) {
+          const float v = t < f4 ? acc[u] : 0.f;   // saliency.py:78-79 zeroes the tail again
+          s[t] = v;
+          lmin = fminf(lmin, v);
+        }
+      }
     }
-    s[t] = acc;
-    lmin = fminf(lmin, acc);
+  } else {
+    for (int t = threadIdx.x; t < T; t += kSalThreads) {
+      float acc = 0.f;
+      if (t < f4)
+        for (int j = 0; j < ksize; ++j) acc = fmaf(taps.w[j], a[t + j], acc);
+      s[t] = acc;
+      lmin = fminf(lmin, acc);
+    }
   }
   const float rmin = block_reduce(lmin, red, false);
   float lmax = -INFINITY;
@@ -292,7 +326,8 @@ extern "C" int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames
   if (B < 0 || C <= 0 || T <= 0 || ksize < 1 || ksize > kMaxTaps || !(ksize & 1) || !(sigma > 0))
     return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
-  const size_t lds = sizeof(float) * ((size_t)2 * T + ksize - 1);
+  const size_t a_len = ((size_t)T + ksize - 1 + 8 + 3) & ~(size_t)3;
+  const size_t lds = sizeof(float) * (a_len + (size_t)T);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
   // gaussian_kernel(), saliency.py:15-18: Python float64 arithmetic, then torch.FloatTensor
   Taps taps;
@@ -303,13 +338,21 @@ extern "C" int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames
     taps.w[j] = (float)w;
   }
   for (int j = ksize; j < kMaxTaps; ++j) taps.w[j] = 0.f;
-  static unsigned long long lds_ok = 0;
-  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(saliency_post_kernel), &lds_ok,
-                                     150 * 1024))
-    return (int)e;
-  hipLaunchKernelGGL(saliency_post_kernel, dim3((unsigned)B), dim3(kSalThreads), lds,
-                     reinterpret_cast<hipStream_t>(stream), grad, frames, sal, taps, ksize, B, C,
-                     T);
+  static unsigned long long lds_ok101 = 0, lds_ok0 = 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (ksize == 101) {             // the reference's gauss_k_n (augmentations.py:966)
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(saliency_post_kernel<101>),
+                                       &lds_ok101, 150 * 1024))
+      return (int)e;
+    hipLaunchKernelGGL(saliency_post_kernel<101>, dim3((unsigned)B), dim3(kSalThreads), lds, st, grad,
+                       frames, sal, taps, ksize, B, C, T);
+  } else {
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(saliency_post_kernel<0>),
+                                       &lds_ok0, 150 * 1024))
+      return (int)e;
+    hipLaunchKernelGGL(saliency_post_kernel<0>, dim3((unsigned)B), dim3(kSalThreads), lds, st, grad,
+                       frames, sal, taps, ksize, B, C, T);
+  }
   return (int)hipGetLastError();
 }
 
