@@ -13,12 +13,15 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_line_contract(device):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20",
-                          "--warmup", "3", "--no-extra", "--no-cpu", "--no-train"],
+                          "--warmup", "3", "--no-extra", "--no-cpu"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
+    def no_constants(c):                          # NaN / Infinity are not JSON
+        raise AssertionError(f"non-JSON constant {c} in the bench line")
+    d = json.loads(lines[0], parse_constant=no_constants)
+    assert d["train"]["hipgraph"] is True and d["train"]["steps_per_s"] > 0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
               "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
