@@ -57,3 +57,28 @@ class StepCounter:
 
     def add(self):
         self.count += 1
+
+
+def learnable_dataset(n_rec=48, T=2500, seed=0):
+    """A dataset dictionary in the reference's container layout whose classes are separable:
+    class-1 cycles carry a louder 80-200 Hz band."""
+    import pcgmix_amd  # noqa: F401
+    from pcgmix_amd import synthetic
+    rs = np.random.RandomState(seed)
+    bands = ["25-45", "45-80", "80-200", "200-400", "25-400"]
+    out = {}
+    for split, n in (("train", n_rec), ("test", n_rec // 2)):
+        d = {"data": {b: [] for b in bands}, "label": [], "frames": [], "wav": [], "sig_qual": []}
+        for r in range(n):
+            wav, label = f"{'abcdef'[r % 6]}{r:04d}", (r // 6) % 2
+            for _ in range(4):
+                fr = synthetic.make_frames(1, 1.0, rs)[0]
+                for b in bands:
+                    sig = rs.standard_normal(T).astype(np.float32)
+                    if b == "80-200" and label:
+                        sig *= 3.0
+                    sig[fr[4]:] = 0
+                    d["data"][b].append(sig)
+                d["label"].append(label); d["frames"].append(fr); d["wav"].append(wav); d["sig_qual"].append(1)
+        out[split] = d
+    return out

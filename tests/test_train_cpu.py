@@ -194,3 +194,38 @@ def test_ddp_two_ranks_equals_single_process(tmp_path, flat):
         tm.train_step(args, model, full, torch.device("cpu"), opt, sched, crit, 0, sc)
     for k, v in model.state_dict().items():
         assert torch.allclose(v, ddp_state[k], atol=2e-6), k
+
+
+def _driver_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from conftest import learnable_dataset
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    ds = learnable_dataset(n_rec=12, T=2500)
+    args = argparse.Namespace(dataset="PhysioNet", model="Potes", method="base", num_epochs=2,
+                              batch_size=16, op="adam", use_sched=True, lr_max=0.003,
+                              weight_decay=1e-4, grad_clip=0.1, seed=4, seed_data=1100001,
+                              n_fraction=1.0, train_balance=True, num_classes=2, sample_rate=1000,
+                              num_channels=4, valid=False, depth=0, EXPERIMENTS=out_dir)
+    perf = tm.train_model(args, ds, torch.device("cpu"), use_graph=False, log=None)
+    inner = perf["model"].module if hasattr(perf["model"], "module") else perf["model"]
+    torch.save({"steps": perf["steps"], "params": [p.detach().clone() for p in inner.parameters()]},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_model_driver_two_ranks(tmp_path):
+    """The run driver under torch.distributed (gloo, world 2): every rank trains on its shard of
+    each batch, gradients are averaged, so the replicas stay identical; rank 0 alone writes
+    model.pth; the step count is the single-process one."""
+    import glob
+    import torch.multiprocessing as mp
+    mp.spawn(_driver_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(str(tmp_path / "rank0.pt"), weights_only=True)
+    r1 = torch.load(str(tmp_path / "rank1.pt"), weights_only=True)
+    assert r0["steps"] == r1["steps"] and r0["steps"][-1] == 2 * (48 // 16)
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+    assert len(glob.glob(str(tmp_path / "*" / "model.pth"))) == 1

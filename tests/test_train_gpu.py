@@ -9,7 +9,7 @@ import torch
 
 import pcgmix_amd  # noqa: F401
 from pcgmix_amd import augmentations, synthetic, train_model as tm
-from conftest import Args, StepCounter
+from conftest import Args, StepCounter, learnable_dataset as _learnable_dataset
 
 pytestmark = pytest.mark.gpu
 
@@ -90,29 +90,6 @@ def test_graphed_step_matches_eager(device):
     assert np.allclose(results[0][0], results[1][0], rtol=1e-4, atol=1e-5), results
     for a, b in zip(results[0][1], results[1][1]):
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-4)
-
-
-def _learnable_dataset(n_rec=48, T=2500, seed=0):
-    """A dataset dictionary in the reference's container layout whose classes are separable:
-    class-1 cycles carry a louder 80-200 Hz band."""
-    rs = np.random.RandomState(seed)
-    bands = ["25-45", "45-80", "80-200", "200-400", "25-400"]
-    out = {}
-    for split, n in (("train", n_rec), ("test", n_rec // 2)):
-        d = {"data": {b: [] for b in bands}, "label": [], "frames": [], "wav": [], "sig_qual": []}
-        for r in range(n):
-            wav, label = f"{'abcdef'[r % 6]}{r:04d}", (r // 6) % 2
-            for _ in range(4):
-                fr = synthetic.make_frames(1, 1.0, rs)[0]
-                for b in bands:
-                    sig = rs.standard_normal(T).astype(np.float32)
-                    if b == "80-200" and label:
-                        sig *= 3.0
-                    sig[fr[4]:] = 0
-                    d["data"][b].append(sig)
-                d["label"].append(label); d["frames"].append(fr); d["wav"].append(wav); d["sig_qual"].append(1)
-        out[split] = d
-    return out
 
 
 @pytest.mark.parametrize("use_graph", [True, False])
@@ -323,3 +300,44 @@ def test_resnet9_2d_matches_float64(device):
         assert torch.allclose(v.cpu().double(), w.double(), rtol=1e-4, atol=1e-5), k
     m.eval(); ref.eval()
     assert torch.allclose(m(x.to(device)).cpu().double(), ref(x.double()), rtol=1e-4, atol=1e-4)
+
+
+def _driver_rank(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ds = _learnable_dataset(n_rec=24)
+    args = argparse.Namespace(dataset="PhysioNet", model="Potes", method="durratiomixup+0.8",
+                              num_epochs=3, batch_size=32, op="adam", use_sched=True, lr_max=0.003,
+                              weight_decay=1e-4, grad_clip=0.1, seed=4, seed_data=1100001,
+                              n_fraction=1.0, train_balance=True, num_classes=2, sample_rate=1000,
+                              num_channels=4, valid=False, depth=0, EXPERIMENTS=out_dir)
+    perf = tm.train_model(args, ds, dev, use_graph=True, log=None)
+    torch.save({"steps": perf["steps"], "loss": perf["train_loss"],
+                "params": [p.detach().cpu() for p in perf["model"].parameters()]},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_model_driver_two_ranks_graphed(device, tmp_path):
+    """train_model() under torch.distributed with the captured step (hipGraph + FlatGradSync):
+    two gloo ranks sharing this box's GPU, each on its half of every batch.  Replicas must stay
+    bit-identical (same averaged gradients, same optimiser state), the loss must fall."""
+    import glob
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_driver_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(str(tmp_path / "rank0.pt"), weights_only=True)
+    r1 = torch.load(str(tmp_path / "rank1.pt"), weights_only=True)
+    assert r0["steps"] == r1["steps"] and r0["steps"][-1] == 3 * (96 // 32)
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
+    assert r0["loss"][-1] < r0["loss"][0]
+    assert len(glob.glob(str(tmp_path / "*" / "model.pth"))) == 1
