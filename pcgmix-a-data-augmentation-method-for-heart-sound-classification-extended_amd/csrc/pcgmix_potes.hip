@@ -84,26 +84,67 @@ __device__ __forceinline__ void lds_load8(const float* p, float (&v)[8]) {  // p
 // nq % 4 == 0.  Work item = (channel, 4 consecutive qq): 12 staged inputs feed 8 conv outputs.
 // a1s[ci*nq + qq] is 0 outside [0,P1) — that IS conv2's zero padding.  If sel != nullptr it gets
 // which conv output won the pool and survived the ReLU: 0 none, 1 first (i = 2q), 2 second.
-__device__ __forceinline__ void layer1(const PotesWeights& W, const float* xs, float* a1s,
-                                       uint8_t* sel, int qlo, int nq, int P1) {
+// SWZ (forward kernel): xs and a1s are stored as two planes of float4 — even-indexed float4 in
+// plane E, odd-indexed in plane O (plane strides xplane / aplane floats) — so that the three
+// 16-byte reads of a 12-float window starting at float4 index 2g become E[g], O[g], E[g+1]:
+// consecutive lanes read consecutive 16 bytes.  With the plain layout the windows start 32 bytes
+// apart and every ds_read_b128 is a 2-way bank conflict (64 banks x 4 B, 16 lanes per group).
+template <bool SWZ>
+__device__ __forceinline__ void layer1_t(const PotesWeights& W, const float* xs, float* a1s,
+                                         uint8_t* sel, int qlo, int nq, int P1, int xplane,
+                                         int aplane) {
   const int groups = nq / 4;
   for (int item = threadIdx.x; item < kC1 * groups; item += kPotThreads) {
     const int ci = item / groups, g = item - ci * groups;
     float xw[12], w[kK];
-    lds_load12(xs + 8 * g, xw);
+    if (SWZ) {
+      const f4 a = *reinterpret_cast<const f4*>(xs + 4 * g),
+               b = *reinterpret_cast<const f4*>(xs + xplane + 4 * g),
+               c = *reinterpret_cast<const f4*>(xs + 4 * g + 4);
+      xw[0] = a.x; xw[1] = a.y; xw[2] = a.z; xw[3] = a.w; xw[4] = b.x; xw[5] = b.y; xw[6] = b.z;
+      xw[7] = b.w; xw[8] = c.x; xw[9] = c.y; xw[10] = c.z; xw[11] = c.w;
+    } else {
+      lds_load12(xs + 8 * g, xw);
+    }
 #pragma unroll
     for (int k = 0; k < kK; ++k) w[k] = W.w1[ci * kK + k];
     const float bias = W.b1[ci];
+    // c[m] = bias + sum_k w[k] * xw[m + k], m < 8, as float2 pairs (see potes_fwd_kernel)
+    f2 ce[4], co_[3];
+    float o0 = 0.f, o7 = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) ce[m] = f2{bias, bias};
+#pragma unroll
+    for (int m = 0; m < 3; ++m) co_[m] = f2{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < kK; k += 2) {
+      const f2 wk = {w[k], w[k]};
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        ce[m] = __builtin_elementwise_fma(wk, f2{xw[2 * m + k], xw[2 * m + k + 1]}, ce[m]);
+    }
+#pragma unroll
+    for (int k = 1; k < kK; k += 2) {
+      const f2 wk = {w[k], w[k]};
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+        co_[m] = __builtin_elementwise_fma(wk, f2{xw[2 * m + 1 + k], xw[2 * m + 2 + k]}, co_[m]);
+      o0 = fmaf(w[k], xw[k], o0);
+      o7 = fmaf(w[k], xw[7 + k], o7);
+    }
+    float c[8];
+    c[0] = ce[0].x + o0;
+    c[7] = ce[3].y + o7;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      c[2 * m + 1] = ce[m].y + co_[m].x;
+      c[2 * m + 2] = ce[m + 1].x + co_[m].y;
+    }
     f4 out;
     uint32_t sels = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      float za = bias, zb = bias;
-#pragma unroll
-      for (int k = 0; k < kK; ++k) {
-        za = fmaf(w[k], xw[2 * u + k], za);
-        zb = fmaf(w[k], xw[2 * u + 1 + k], zb);
-      }
+      const float za = c[2 * u], zb = c[2 * u + 1];
       const int q = qlo + 4 * g + u;
       const float ra = fmaxf(za, 0.f), rb = fmaxf(zb, 0.f);
       float a = 0.f;
@@ -115,30 +156,51 @@ __device__ __forceinline__ void layer1(const PotesWeights& W, const float* xs, f
       out[u] = a;
       sels |= sc << (8 * u);
     }
-    *reinterpret_cast<f4*>(a1s + ci * nq + 4 * g) = out;
-    if (sel) *reinterpret_cast<uint32_t*>(sel + ci * nq + 4 * g) = sels;
+    if (SWZ) {
+      *reinterpret_cast<f4*>(a1s + ci * 2 * aplane + (g & 1) * aplane + 4 * (g >> 1)) = out;
+    } else {
+      *reinterpret_cast<f4*>(a1s + ci * nq + 4 * g) = out;
+      if (sel) *reinterpret_cast<uint32_t*>(sel + ci * nq + 4 * g) = sels;
+    }
   }
 }
 
+__device__ __forceinline__ void layer1(const PotesWeights& W, const float* xs, float* a1s,
+                                       uint8_t* sel, int qlo, int nq, int P1) {
+  layer1_t<false>(W, xs, a1s, sel, qlo, nq, P1, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------- forward
-constexpr int kFwdTP = 256;                     // pooled outputs per block (4 per lane, wave = co)
-constexpr int kFwdNQ = 2 * kFwdTP + 4;          // 516
-constexpr int kFwdNX = 4 * kFwdTP + 12;         // 1036
+constexpr int kFwdTP = 252;                     // pooled outputs per block (4 per lane, wave = co):
+                                                // 2*252+4 = 508 layer-1 positions = 127 groups x 8
+                                                // channels = 1016 work items = 4 rounds of 256 threads
+                                                // (256 outputs would need a 5th round for 8 items)
+constexpr int kFwdNQ = 2 * kFwdTP + 4;          // 508
+constexpr int kFwdNX = 4 * kFwdTP + 12;         // 1020
 
 __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ h2, int N,
     int T) {
   __shared__ PotesWeights W;
-  __shared__ __align__(16) float xs[kFwdNX];
-  __shared__ __align__(16) float a1s[kC1 * kFwdNQ];
+  // swizzled planes (see layer1_t): x = 255 float4 -> E 128 + O 128; a1 = 127 float4 per channel
+  // -> E 64 + O 64 per channel (+4 floats: lane 63 of conv2 reads E[64] of the last channel)
+  constexpr int kXPlane = 512, kAPlane = 256;
+  __shared__ __align__(16) float xs[2 * kXPlane];
+  __shared__ __align__(16) float a1s[kC1 * 2 * kAPlane + 4];
   const PotesDims d = potes_dims(T);
   const int n = blockIdx.y, p0 = blockIdx.x * kFwdTP;
   const int qlo = 2 * p0 - 1, xlo = 2 * qlo - 1;
   load_weights(&W, w1, b1, w2, b2);
-  stage_x(xs, x + (size_t)n * T, xlo, kFwdNX, T);
+  {
+    const float* xrow = x + (size_t)n * T;
+    for (int u = threadIdx.x; u < kFwdNX; u += kPotThreads) {
+      const int g = xlo + u, i = u >> 2;
+      xs[(i & 1) * kXPlane + 4 * (i >> 1) + (u & 3)] = (g >= 0 && g < T) ? xrow[g] : 0.f;
+    }
+  }
   __syncthreads();
-  layer1(W, xs, a1s, nullptr, qlo, kFwdNQ, d.P1);
+  layer1_t<true>(W, xs, a1s, nullptr, qlo, kFwdNQ, d.P1, kXPlane, kAPlane);
   __syncthreads();
   // conv 8->4 k5 + ReLU + pool 2: wave = output channel, lane = 4 consecutive pooled outputs
   // co is wave-uniform: its 40 weights come through the scalar cache into SGPRs instead of
@@ -159,7 +221,14 @@ __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
 #pragma unroll
   for (int ci = 0; ci < kC1; ++ci) {
     float aw[12], w[kK];
-    lds_load12(a1s + ci * kFwdNQ + 8 * lane, aw);
+    {
+      const float* row = a1s + ci * 2 * kAPlane;
+      const f4 a = *reinterpret_cast<const f4*>(row + 4 * lane),
+               b = *reinterpret_cast<const f4*>(row + kAPlane + 4 * lane),
+               c = *reinterpret_cast<const f4*>(row + 4 * lane + 4);
+      aw[0] = a.x; aw[1] = a.y; aw[2] = a.z; aw[3] = a.w; aw[4] = b.x; aw[5] = b.y; aw[6] = b.z;
+      aw[7] = b.w; aw[8] = c.x; aw[9] = c.y; aw[10] = c.z; aw[11] = c.w;
+    }
 #pragma unroll
     for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci) * kK + k];
 #pragma unroll
@@ -192,6 +261,7 @@ __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
   f4 o;
 #pragma unroll
   for (int u = 0; u < 4; ++u) o[u] = fmaxf(fmaxf(c[2 * u], 0.f), fmaxf(c[2 * u + 1], 0.f));
+  if (4 * lane >= kFwdTP) return;                  // lane 63: outputs owned by the next tile
   if (p + 3 < d.P2 && (d.P2 & 3) == 0) {
     *reinterpret_cast<f4*>(dst) = o;
   } else {
