@@ -512,30 +512,31 @@ def main():
         guard.daemon = True
         guard.start()
     if not a.no_train:
+        n_tr, w_tr = max(20, a.steps // 4), max(5, a.warmup // 2)
         try:
-            train = train_steps_per_s(a.method, "Potes", B, C, T, rate, device,
-                                      max(20, a.steps // 4), max(5, a.warmup // 2), barrier, rank)
-        except Exception as e:          # same code on every rank: all ranks fall back together
-            if world == 1:
-                raise
-            print(f"[bench] graphed train step failed on rank {rank}: {e!r}; eager DDP instead",
-                  file=sys.stderr)
-            train = train_steps_per_s(a.method, "Potes", B, C, T, rate, device,
-                                      max(20, a.steps // 4), max(5, a.warmup // 2), barrier, rank,
-                                      use_graph=False)
-            train["graph_error"] = repr(e)
-        if world == 1:
-            eager = train_steps_per_s(a.method, "Potes", B, C, T, rate, device,
-                                      max(20, a.steps // 4), max(5, a.warmup // 2), barrier, rank,
-                                      use_graph=False)
-            train["eager_steps_per_s"] = eager["steps_per_s"]
-        if dist is not None:
-            t = torch.tensor([train["ms_per_step"]], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            train["ms_per_step"] = float(t.item())
-            train["steps_per_s"] = 1e3 / train["ms_per_step"]
-        train["global_batch"] = B * world
-        train["samples_per_s"] = train["steps_per_s"] * B * world
+            try:
+                train = train_steps_per_s(a.method, "Potes", B, C, T, rate, device, n_tr, w_tr,
+                                          barrier, rank)
+            except Exception as e:      # same code on every rank: all ranks fall back together
+                print(f"[bench] graphed train step failed on rank {rank}: {e!r}; eager step instead",
+                      file=sys.stderr)
+                train = train_steps_per_s(a.method, "Potes", B, C, T, rate, device, n_tr, w_tr,
+                                          barrier, rank, use_graph=False)
+                train["graph_error"] = repr(e)[:300]
+            if world == 1 and "graph_error" not in train:
+                eager = train_steps_per_s(a.method, "Potes", B, C, T, rate, device, n_tr, w_tr,
+                                          barrier, rank, use_graph=False)
+                train["eager_steps_per_s"] = eager["steps_per_s"]
+            if dist is not None:
+                t = torch.tensor([train["ms_per_step"]], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                train["ms_per_step"] = float(t.item())
+                train["steps_per_s"] = 1e3 / train["ms_per_step"]
+            train["global_batch"] = B * world
+            train["samples_per_s"] = train["steps_per_s"] * B * world
+        except Exception as e:          # the augmentation line above must still be printed
+            print(f"[bench] train leg failed on rank {rank}: {e!r}", file=sys.stderr)
+            train = {"error": repr(e)[:300]}
         result["train"] = train
         if guard is not None:
             guard.cancel()
