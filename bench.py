@@ -587,8 +587,13 @@ def main():
                     rank))
         result["extra"] = extra
         if not a.no_cpu:
-            result["cpu_baseline"] = cpu_baseline(a.method, B, C, T, rate)
-            result["extra"]["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+            try:
+                result["cpu_baseline"] = cpu_baseline(a.method, B, C, T, rate)
+                result["extra"]["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+            except Exception as e:      # noqa: BLE001
+                print(f"[bench] cpu_baseline failed: {e!r}", file=sys.stderr)
+                result["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0,
+                                          "kind": "port", "sample": "failed: " + repr(e)[:200]}
     if rank == 0:
         print(strict_json(result))
     if dist is not None:
