@@ -131,3 +131,22 @@ def test_soft_ce_matches_torch(B, C, device):
         (got * 0.7).backward()
         assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
         assert torch.allclose(logits.grad, gw, rtol=1e-4, atol=1e-7)
+
+
+def test_head_backward_is_deterministic(device):
+    """dW1 is accumulated by two row halves with float atomicAdd onto a zeroed buffer: exactly two
+    addends per element, so the result must not depend on arrival order — bit-identical reruns."""
+    torch.manual_seed(4)
+    m = models.CNN_potes_TS(4, 2, "PhysioNet", sig_len=5000).to(device).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    x = torch.randn(256, 4, 5000, device=device)
+    t = F.one_hot(torch.randint(0, 2, (256,), device=device), 2)
+    grads = []
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        tm.CELoss(2)(m(x, depth=0, pass_part="second"), t).backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]) and torch.equal(grads[0][k], grads[2][k]), k
