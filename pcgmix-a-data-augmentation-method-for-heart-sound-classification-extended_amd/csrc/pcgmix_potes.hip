@@ -650,52 +650,82 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_kernel(
 // ---------------------------------------------------------------------------------- dimreduc
 // z[B][O] = h[B][K] . W[O][K]^T + bias for a SKINNY output (O <= 32; the Potes head is 19968 -> 20,
 // models.py:376).  hipBLASLt runs this shape as 32 workgroups with no split-K: 53 us at bs=256
-// for a 20 MB read.  Here: two batch rows per block, K split over gridDim.y, 16-byte loads of h
-// (HBM) and W (L2), per-lane partial dot products, wave-shuffle + LDS reduction, per-split
-// partials summed in a fixed order by a second kernel (deterministic).
+// for a 20 MB read.  The first version here (VALU dot products against an LDS copy of W, 16 rows x
+// 1024 columns per block) ran 18 us, bound by ds_read_b128 of W and instruction issue.  This one
+// uses the f32-input matrix instruction, v_mfma_f32_32x32x2_f32 (exact f32, same peak as the f32
+// VALU but none of its issue slots and no LDS in the inner loop):
+//   D[o][b] += W[o][k] * h[b][k]      A = W (rows o >= O are zero lanes), B = h^T, 32 x 32 x 2
+// Block = 32 batch rows x one 1024-wide K chunk, 8 waves x 128 columns.  Per 64 columns a lane
+// (r = lane & 31, half = lane >> 5) loads the 32 consecutive floats h[row r][k0 + 32 half ..] —
+// a whole 128-byte line per lane — and the same span of W[r][..]; MFMA step j multiplies element
+// j of both (the k index may be permuted freely inside a reduction as long as A and B agree).
+// The eight waves' 32x32 tiles are added in a fixed order through LDS; per-chunk partials are
+// summed in a fixed order by the consumer (deterministic).
 constexpr int kSkinnyMaxO = 32;
-constexpr int kSkinnyRows = 16;     // batch rows per block
-constexpr int kSkinnyChunk = 1024;  // K elements per block (its W slice sits in LDS: O * 4 KB)
+constexpr int kSkinnyRows = 32;     // batch rows per block
+constexpr int kSkinnyChunk = 1024;  // K elements per block (one partial per chunk)
+typedef float f16v __attribute__((ext_vector_type(16)));
 
-// Block = 16 rows x one 1024-wide K chunk.  Thread (r = tid >> 4, jl = tid & 15) owns row r and
-// the float4 columns jl, jl+16, ...: h comes from HBM in 256-byte row segments, W from the LDS
-// copy (the 16 rows read the same address: broadcast), O private accumulators, then a 16-lane
-// shuffle reduction.  W is read from L2 once per block (B/16 * 1.6 MB in total).
+constexpr int kSkinnyWaves = 8;     // 128 columns per wave, all of them requested up front
+
 template <int O>
-__global__ __launch_bounds__(kPotThreads) void skinny_linear_partial_kernel(
+__global__ __launch_bounds__(kSkinnyWaves * 64) void skinny_linear_partial_kernel(
     const float* __restrict__ h, const float* __restrict__ W, float* __restrict__ partial, int B,
     int K) {
-  __shared__ __align__(16) float wl[O * kSkinnyChunk];
-  const int r0 = blockIdx.x * kSkinnyRows, ks = blockIdx.y;
-  const int k_lo = ks * kSkinnyChunk;
-  const int kn = (K - k_lo < kSkinnyChunk) ? K - k_lo : kSkinnyChunk;   // multiple of 4
-  for (int i = threadIdx.x * 4; i < O * kSkinnyChunk; i += kPotThreads * 4) {
-    const int o = i / kSkinnyChunk, j = i - o * kSkinnyChunk;
-    f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (j < kn) v = *reinterpret_cast<const f4*>(W + (size_t)o * K + k_lo + j);
-    *reinterpret_cast<f4*>(wl + i) = v;
+  __shared__ float red[kSkinnyWaves - 1][16][64];
+  constexpr int kPerWave = kSkinnyChunk / kSkinnyWaves;                  // 128 columns
+  constexpr int kSteps = kPerWave / 64;                                  // 2 x 64 columns
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, half = lane >> 5;
+  const int row = blockIdx.x * kSkinnyRows + r, ks = blockIdx.y;
+  const int k_w = ks * kSkinnyChunk + wave * kPerWave;
+  const float* hr = h + (size_t)(row < B ? row : B - 1) * K;
+  const float* wr = W + (size_t)(r < O ? r : 0) * K;
+  // One wave per SIMD at most (B/32 x K/1024 blocks): nothing hides a load but the wave's own
+  // requests, so every float4 of the wave's span is in flight before the first MFMA.
+  f4 xa[kSteps][8], wa[kSteps][8];
+#pragma unroll
+  for (int c = 0; c < kSteps; ++c)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                   // clamped addresses, selected values
+      const int k = k_w + 64 * c + 32 * half + 4 * q;
+      const bool ok = k < K;                        // K % 4 == 0: a float4 is inside or outside
+      const f4 xv = *reinterpret_cast<const f4*>(hr + (ok ? k : 0));
+      const f4 wv = *reinterpret_cast<const f4*>(wr + (ok ? k : 0));
+      const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+      xa[c][q] = ok ? xv : z4;
+      wa[c][q] = (ok && r < O) ? wv : z4;
+    }
+  f16v acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int c = 0; c < kSteps; ++c)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c][q].x, xa[c][q].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c][q].y, xa[c][q].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c][q].z, xa[c][q].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c][q].w, xa[c][q].w, acc, 0, 0, 0);
+    }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave - 1][i][lane] = acc[i];
   }
   __syncthreads();
-  const int r = threadIdx.x >> 4, jl = threadIdx.x & 15;
-  const int row = r0 + r;
-  const float* hr = h + (size_t)(row < B ? row : B - 1) * K + k_lo;
-  float acc[O];
+  if (wave > 0) return;
 #pragma unroll
-  for (int o = 0; o < O; ++o) acc[o] = 0.f;
-  for (int j = jl * 4; j < kn; j += 64) {
-    const f4 a = *reinterpret_cast<const f4*>(hr + j);
+  for (int w = 0; w < kSkinnyWaves - 1; ++w)
 #pragma unroll
-    for (int o = 0; o < O; ++o) {
-      const f4 w = *reinterpret_cast<const f4*>(wl + o * kSkinnyChunk + j);
-      acc[o] = fmaf(a.w, w.w, fmaf(a.z, w.z, fmaf(a.y, w.y, fmaf(a.x, w.x, acc[o]))));
+    for (int i = 0; i < 16; ++i) acc[i] += red[w][i][lane];
+  // C/D layout: column = lane & 31 (batch row), row o = (i & 3) + 8 (i >> 2) + 4 half
+  if (row < B) {
+    float* dst = partial + ((size_t)ks * B + row) * O;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int o = (i & 3) + 8 * (i >> 2) + 4 * half;
+      if (o < O) dst[o] = acc[i];
     }
-  }
-#pragma unroll
-  for (int o = 0; o < O; ++o) {
-    float v = acc[o];
-#pragma unroll
-    for (int s = 8; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);   // the 16 lanes of this row
-    if (jl == 0 && row < B) partial[((size_t)ks * B + row) * O + o] = v;
   }
 }
 
@@ -928,7 +958,8 @@ hipError_t launch_skinny_partial(const float* h, const float* W, float* partial,
   if ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(W)) & 15)
     return hipErrorInvalidValue;
   const int KS = pcgmix_skinny_linear_splits(B, K);
-  dim3 grid((unsigned)((B + kSkinnyRows - 1) / kSkinnyRows), (unsigned)KS), block(kPotThreads);
+  dim3 grid((unsigned)((B + kSkinnyRows - 1) / kSkinnyRows), (unsigned)KS),
+      block(kSkinnyWaves * 64);
   if (O == 20) {
     hipLaunchKernelGGL((skinny_linear_partial_kernel<20>), grid, block, 0, s, h, W, partial, B, K);
   } else if (O == 8) {
