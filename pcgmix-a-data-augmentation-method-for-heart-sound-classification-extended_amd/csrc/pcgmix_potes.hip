@@ -655,70 +655,105 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_kernel(
 // uses the f32-input matrix instruction, v_mfma_f32_32x32x2_f32 (exact f32, same peak as the f32
 // VALU but none of its issue slots and no LDS in the inner loop):
 //   D[o][b] += W[o][k] * h[b][k]      A = W (rows o >= O are zero lanes), B = h^T, 32 x 32 x 2
-// Block = 32 batch rows x one 1024-wide K chunk, 8 waves x 128 columns.  Per 64 columns a lane
-// (r = lane & 31, half = lane >> 5) loads the 32 consecutive floats h[row r][k0 + 32 half ..] —
-// a whole 128-byte line per lane — and the same span of W[r][..]; MFMA step j multiplies element
+// Block = 32 batch rows x one 1024-wide K chunk, 4 waves x 256 columns.  Per 64 columns a lane
+// (r = lane & 31, half = lane >> 5) takes the 32 consecutive floats h[row r][k0 + 32 half ..]
+// and the same span of W[r][..] (through LDS, see the kernel); MFMA step j multiplies element
 // j of both (the k index may be permuted freely inside a reduction as long as A and B agree).
-// The eight waves' 32x32 tiles are added in a fixed order through LDS; per-chunk partials are
+// The four waves' 32x32 tiles are added in a fixed order through LDS; per-chunk partials are
 // summed in a fixed order by the consumer (deterministic).
 constexpr int kSkinnyMaxO = 32;
 constexpr int kSkinnyRows = 32;     // batch rows per block
 constexpr int kSkinnyChunk = 1024;  // K elements per block (one partial per chunk)
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-constexpr int kSkinnyWaves = 8;     // 128 columns per wave, all of them requested up front
+constexpr int kSkinnyWaves = 4;     // 256 columns per wave, in steps of 64
+constexpr int kSkStep = 64;         // columns per MFMA round
+constexpr int kSkStride = 68;       // LDS row stride in floats (16-byte aligned, +4 against banks)
 
+// The matrix instruction wants lane = (row, k-half): read straight from memory that is 32-byte
+// pieces of 32 rows per request (14.5 us).  So each wave loads its 32 x 64 tile of h and O x 64
+// tile of W row-contiguously (4 rows x 256 B per request), parks them in LDS and reads them back
+// in operand order; the next step's global loads are in flight while the MFMAs run.
 template <int O>
 __global__ __launch_bounds__(kSkinnyWaves * 64) void skinny_linear_partial_kernel(
     const float* __restrict__ h, const float* __restrict__ W, float* __restrict__ partial, int B,
     int K) {
-  __shared__ float red[kSkinnyWaves - 1][16][64];
-  constexpr int kPerWave = kSkinnyChunk / kSkinnyWaves;                  // 128 columns
-  constexpr int kSteps = kPerWave / 64;                                  // 2 x 64 columns
+  constexpr int kWRows = (O + 3) / 4 * 4;                                // W tile rows in LDS
+  constexpr int kWaveFloats = (32 + kWRows) * kSkStride;
+  __shared__ __align__(16) float smem[kSkinnyWaves * kWaveFloats];
+  constexpr int kPerWave = kSkinnyChunk / kSkinnyWaves;                  // 256 columns
+  constexpr int kSteps = kPerWave / kSkStep;                             // 4
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, half = lane >> 5;
-  const int row = blockIdx.x * kSkinnyRows + r, ks = blockIdx.y;
+  const int row_base = blockIdx.x * kSkinnyRows, ks = blockIdx.y;
   const int k_w = ks * kSkinnyChunk + wave * kPerWave;
-  const float* hr = h + (size_t)(row < B ? row : B - 1) * K;
-  const float* wr = W + (size_t)(r < O ? r : 0) * K;
-  // One wave per SIMD at most (B/32 x K/1024 blocks): nothing hides a load but the wave's own
-  // requests, so every float4 of the wave's span is in flight before the first MFMA.
-  f4 xa[kSteps][8], wa[kSteps][8];
+  float* xs = smem + wave * kWaveFloats;            // [32][kSkStride]
+  float* ws = xs + 32 * kSkStride;                  // [kWRows][kSkStride]
+  // loader mapping: request `it` covers rows 4 it + (lane >> 4), float4 column lane & 15
+  const int lr = lane >> 4, lc = 4 * (lane & 15);
+  f4 gx[8], gw[kWRows / 4];
+  auto fetch = [&](int step) {
+    const int k = k_w + kSkStep * step + lc;
+    const bool ok = k < K;                          // K % 4 == 0: a float4 is inside or outside
+    const f4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < kSteps; ++c)
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {                   // clamped addresses, selected values
-      const int k = k_w + 64 * c + 32 * half + 4 * q;
-      const bool ok = k < K;                        // K % 4 == 0: a float4 is inside or outside
-      const f4 xv = *reinterpret_cast<const f4*>(hr + (ok ? k : 0));
-      const f4 wv = *reinterpret_cast<const f4*>(wr + (ok ? k : 0));
-      const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-      xa[c][q] = ok ? xv : z4;
-      wa[c][q] = (ok && r < O) ? wv : z4;
+    for (int it = 0; it < 8; ++it) {
+      const int row = row_base + 4 * it + lr;
+      const f4 v = *reinterpret_cast<const f4*>(h + (size_t)(row < B ? row : B - 1) * K + (ok ? k : 0));
+      gx[it] = ok ? v : z4;
     }
+#pragma unroll
+    for (int it = 0; it < kWRows / 4; ++it) {
+      const int o = 4 * it + lr;
+      const f4 v = *reinterpret_cast<const f4*>(W + (size_t)(o < O ? o : 0) * K + (ok ? k : 0));
+      gw[it] = (ok && o < O) ? v : z4;
+    }
+  };
+  fetch(0);
   f16v acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 1
+  for (int step = 0; step < kSteps; ++step) {
 #pragma unroll
-  for (int c = 0; c < kSteps; ++c)
+    for (int it = 0; it < 8; ++it)
+      *reinterpret_cast<f4*>(xs + (4 * it + lr) * kSkStride + lc) = gx[it];
+#pragma unroll
+    for (int it = 0; it < kWRows / 4; ++it)
+      *reinterpret_cast<f4*>(ws + (4 * it + lr) * kSkStride + lc) = gw[it];
+    if (step + 1 < kSteps) fetch(step + 1);
+    __syncthreads();                                // tiles complete (all waves run in step)
+    f4 xa[8], wa[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c][q].x, xa[c][q].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c][q].y, xa[c][q].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c][q].z, xa[c][q].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[c][q].w, xa[c][q].w, acc, 0, 0, 0);
+      xa[q] = *reinterpret_cast<const f4*>(xs + r * kSkStride + 32 * half + 4 * q);
+      const f4 z4 = {0.f, 0.f, 0.f, 0.f};
+      wa[q] = r < O ? *reinterpret_cast<const f4*>(ws + (r < O ? r : 0) * kSkStride + 32 * half + 4 * q)
+                    : z4;
     }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[q].x, xa[q].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[q].y, xa[q].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[q].z, xa[q].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[q].w, xa[q].w, acc, 0, 0, 0);
+    }
+    __syncthreads();                                // tiles consumed before they are overwritten
+  }
+  // fixed-order sum of the waves' tiles (reusing the staging memory), then one partial per block
+  float* red = smem;                                // [kSkinnyWaves - 1][16][64]
   if (wave > 0) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) red[wave - 1][i][lane] = acc[i];
+    for (int i = 0; i < 16; ++i) red[((wave - 1) * 16 + i) * 64 + lane] = acc[i];
   }
   __syncthreads();
   if (wave > 0) return;
 #pragma unroll
   for (int w = 0; w < kSkinnyWaves - 1; ++w)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] += red[w][i][lane];
+    for (int i = 0; i < 16; ++i) acc[i] += red[(w * 16 + i) * 64 + lane];
   // C/D layout: column = lane & 31 (batch row), row o = (i & 3) + 8 (i >> 2) + 4 half
+  const int row = row_base + r;
   if (row < B) {
     float* dst = partial + ((size_t)ks * B + row) * O;
 #pragma unroll
