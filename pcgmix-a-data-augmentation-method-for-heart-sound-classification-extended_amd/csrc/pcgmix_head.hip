@@ -50,7 +50,15 @@ __global__ __launch_bounds__(kTailRows* kHeadO) void potes_tail_fwd_kernel(
   if (row < B) {
     const size_t i = (size_t)row * kHeadO + o;
     float v = b1 ? b1[o] : 0.f;
-    for (int ks = 0; ks < KS; ++ks) v += partial[(size_t)ks * B * kHeadO + i];
+    int ks = 0;
+    for (; ks + 8 <= KS; ks += 8) {                 // eight independent loads in flight
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = partial[(size_t)(ks + u) * B * kHeadO + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];        // same order as the plain loop
+    }
+    for (; ks < KS; ++ks) v += partial[(size_t)ks * B * kHeadO + i];
     z[i] = v;
     hv = v > 0.f ? v : 0.f;
     if (mask2) hv = mask2[i] ? hv * scale2 : 0.f;

@@ -663,10 +663,10 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_kernel(
 // summed in a fixed order by the consumer (deterministic).
 constexpr int kSkinnyMaxO = 32;
 constexpr int kSkinnyRows = 32;     // batch rows per block
-constexpr int kSkinnyChunk = 1024;  // K elements per block (one partial per chunk)
+constexpr int kSkinnyChunk = 512;   // K elements per block (one partial per chunk)
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-constexpr int kSkinnyWaves = 4;     // 256 columns per wave, in steps of 64
+constexpr int kSkinnyWaves = 4;     // 128 columns per wave, in steps of 64
 constexpr int kSkStep = 64;         // columns per MFMA round
 constexpr int kSkStride = 68;       // LDS row stride in floats (16-byte aligned, +4 against banks)
 
