@@ -18,7 +18,9 @@ dw1 = torch.empty(20, K, device=dev); dx = torch.empty(B, K, device=dev)
 st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 f = lambda: lib.pcgmix_potes_head_fwd_f32(x.data_ptr(), w1.data_ptr(), b1.data_ptr(), m2.data_ptr(), ctypes.c_float(2.0), w2.data_ptr(), b2.data_ptr(), partial.data_ptr(), z.data_ptr(), logits.data_ptr(), B, K, C, st)
 g = lambda: lib.pcgmix_potes_head_bwd_f32(dl.data_ptr(), z.data_ptr(), m2.data_ptr(), ctypes.c_float(2.0), w2.data_ptr(), x.data_ptr(), m1.data_ptr(), ctypes.c_float(4 / 3), w1.data_ptr(), dz.data_ptr(), dw2.data_ptr(), db2.data_ptr(), db1.data_ptr(), dw1.data_ptr(), dx.data_ptr(), B, K, C, st)
-for name, fn in (("head_fwd (partial+tail)", f), ("head_bwd (tail+head)", g)):
+g_nomask = lambda: lib.pcgmix_potes_head_bwd_f32(dl.data_ptr(), z.data_ptr(), m2.data_ptr(), ctypes.c_float(2.0), w2.data_ptr(), x.data_ptr(), None, ctypes.c_float(1.0), w1.data_ptr(), dz.data_ptr(), dw2.data_ptr(), db2.data_ptr(), db1.data_ptr(), dw1.data_ptr(), dx.data_ptr(), B, K, C, st)
+g_nodx = lambda: lib.pcgmix_potes_head_bwd_f32(dl.data_ptr(), z.data_ptr(), m2.data_ptr(), ctypes.c_float(2.0), w2.data_ptr(), x.data_ptr(), None, ctypes.c_float(1.0), w1.data_ptr(), dz.data_ptr(), dw2.data_ptr(), db2.data_ptr(), db1.data_ptr(), dw1.data_ptr(), None, B, K, C, st)
+for name, fn in (("head_fwd (partial+tail)", f), ("head_bwd (tail+head)", g), ("head_bwd, no dropout mask", g_nomask), ("head_bwd, no dx (dW1 only)", g_nodx)):
     for _ in range(10): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
