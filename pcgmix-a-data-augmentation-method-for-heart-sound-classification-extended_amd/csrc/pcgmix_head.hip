@@ -31,39 +31,44 @@ namespace pcgmix {
 
 constexpr int kHeadO = 20;        // dimreduc width (models.py:376)
 constexpr int kHeadMaxC = 8;      // classes
-constexpr int kTailRows = 16;     // batch rows per block in the forward tail
+constexpr int kTailRows = 4;      // batch rows per block in the forward tail (x 20 x 4 lanes)
 constexpr int kTailBwdGroups = 48;
 constexpr int kHbCols = 64;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------ tail, forward
-// thread (r, o) of a block owns z[row][o]; the first 16*C threads then form the logits.
-__global__ __launch_bounds__(kTailRows* kHeadO) void potes_tail_fwd_kernel(
+// Four lanes (q = t & 3) share one z[row][o]: lane q sums the K-split partials q, q+4, ... with
+// up to four loads in flight, then the four sub-sums are added in a fixed order by shuffles.
+// The first kTailRows*C threads then form the logits.
+__global__ __launch_bounds__(kTailRows* kHeadO * 4) void potes_tail_fwd_kernel(
     const float* __restrict__ partial, int KS, const float* __restrict__ b1,
     const uint8_t* __restrict__ mask2, float scale2, const float* __restrict__ w2,
     const float* __restrict__ b2, float* __restrict__ z, float* __restrict__ logits, int B, int C) {
   __shared__ float h[kTailRows][kHeadO];
-  const int t = threadIdx.x, r = t / kHeadO, o = t - r * kHeadO;
+  const int t = threadIdx.x, q = t & 3, e = t >> 2;            // e = r * kHeadO + o
+  const int r = e / kHeadO, o = e - r * kHeadO;
   const int row = blockIdx.x * kTailRows + r;
+  const size_t i = (size_t)(row < B ? row : 0) * kHeadO + o;
+  const size_t plane = (size_t)B * kHeadO;
+  float v = 0.f;
+  int ks = q;
+  for (; ks + 12 < KS; ks += 16) {                  // four independent loads in flight
+    const float t0 = partial[(size_t)ks * plane + i], t1 = partial[(size_t)(ks + 4) * plane + i],
+                t2 = partial[(size_t)(ks + 8) * plane + i], t3 = partial[(size_t)(ks + 12) * plane + i];
+    v += t0; v += t1; v += t2; v += t3;
+  }
+  for (; ks < KS; ks += 4) v += partial[(size_t)ks * plane + i];
+  v += __shfl_xor(v, 1, 64);                        // (q0 + q1), (q2 + q3): same value in both lanes
+  v += __shfl_xor(v, 2, 64);
   float hv = 0.f;
-  if (row < B) {
-    const size_t i = (size_t)row * kHeadO + o;
-    float v = b1 ? b1[o] : 0.f;
-    int ks = 0;
-    for (; ks + 8 <= KS; ks += 8) {                 // eight independent loads in flight
-      float t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = partial[(size_t)(ks + u) * B * kHeadO + i];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v += t[u];        // same order as the plain loop
-    }
-    for (; ks < KS; ++ks) v += partial[(size_t)ks * B * kHeadO + i];
+  if (row < B && q == 0) {
+    v += b1 ? b1[o] : 0.f;
     z[i] = v;
     hv = v > 0.f ? v : 0.f;
     if (mask2) hv = mask2[i] ? hv * scale2 : 0.f;
   }
-  h[r][o] = hv;
+  if (q == 0) h[r][o] = hv;
   __syncthreads();
   if (t < kTailRows * C) {
     const int rr = t / C, c = t - rr * C;
@@ -318,7 +323,7 @@ extern "C" int pcgmix_potes_head_fwd_f32(const float* x, const float* w1, const 
   if (e != hipSuccess) return (int)e;
   const int KS = pcgmix_skinny_linear_splits(B, K);
   hipLaunchKernelGGL(potes_tail_fwd_kernel, dim3((unsigned)((B + kTailRows - 1) / kTailRows)),
-                     dim3(kTailRows * kHeadO), 0, s, partial, KS, b1, mask2, scale2, w2, b2, z,
+                     dim3(kTailRows * kHeadO * 4), 0, s, partial, KS, b1, mask2, scale2, w2, b2, z,
                      logits, B, C);
   return (int)hipGetLastError();
 }
