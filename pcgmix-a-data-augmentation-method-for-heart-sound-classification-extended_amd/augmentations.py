@@ -298,12 +298,19 @@ def blend_targets(target_ohe: torch.Tensor, plan: MixPlan) -> torch.Tensor:
 _LABEL_PINNED: dict = {}
 
 
-def labels_from_ohe(target_ohe: torch.Tensor) -> np.ndarray:
+_SIDE_STREAMS: dict = {}
+
+
+def labels_from_ohe(target_ohe: torch.Tensor, after: Optional["torch.cuda.Event"] = None) -> np.ndarray:
     """Reverse the one-hot encoding on the host (augmentations.py:501): one D2H copy of the
     (B, classes) matrix, argmax (first maximum, like torch.max) in numpy — no reduce kernel.
     The copy lands in a cached pinned buffer and the launch stream is synchronised: with the
     previous step's kernel still in flight ``tensor.cpu()`` measured 51 us, this 23 us
-    (profiles/probes/label_readback.py)."""
+    (profiles/probes/label_readback.py).
+
+    ``after``: an event recorded on the launch stream.  The copy then runs on a side stream that
+    waits for that event only, so work enqueued on the launch stream AFTER the event (the
+    saliency graph of a saliency-guided step) does not delay the read-back."""
     t = target_ohe.detach()
     if not t.is_cuda:
         return t.numpy().argmax(axis=1)
@@ -313,8 +320,17 @@ def labels_from_ohe(target_ohe: torch.Tensor) -> np.ndarray:
         buf = torch.empty(max(4096, t.numel()), dtype=t.dtype, pin_memory=True)
         _LABEL_PINNED[key] = buf
     host = buf[:t.numel()].view(t.shape)
-    host.copy_(t, non_blocking=True)
-    torch.cuda.current_stream(t.device).synchronize()
+    if after is None:
+        host.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+    else:
+        side = _SIDE_STREAMS.get(t.device.index)
+        if side is None:
+            side = _SIDE_STREAMS[t.device.index] = torch.cuda.Stream(t.device)
+        side.wait_event(after)
+        with torch.cuda.stream(side):
+            host.copy_(t, non_blocking=True)
+        side.synchronize()
     return host.numpy().argmax(axis=1)
 
 
@@ -344,16 +360,25 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
     labels = (lambda: labels_from_ohe(target_ohe)) if host_labels is None else np.asarray(host_labels)
     sal = None
     if "(salopt" in method and B > 0:
-        # Saliency-guided step: read the labels back FIRST (the stream is still short), enqueue
-        # the frozen model's forward + input gradient + post-processing, and only then do the
-        # host part of the plan (permutation, lambda, B*(k+2)*C normal draws: ~0.1 ms) while the
-        # GPU works.  The saliency maps use no host RNG, so the reference's draw order is kept.
+        # Saliency-guided step: enqueue the frozen model's forward + input gradient +
+        # post-processing FIRST, then do the host part of the plan (label read-back, permutation,
+        # lambda, B*(k+2)*C normal draws: ~0.1 ms) while the GPU works.  The saliency maps use no
+        # host RNG, so the reference's draw order is kept.
         if not hostprep.gate_fires(method, step):
             return data, target_ohe, [], None
-        labels = labels() if callable(labels) else labels
         from . import saliency as _sal
-        sal = _sal.get_saliency_maps(args, data.device, data, target_ohe, frames_np, dim=1,
-                                     gauss_k_n=101)
+        if host_labels is None:
+            # the read-back must wait for whatever produced target_ohe, but not for the saliency
+            # graph: mark the stream, enqueue the graph (the GPU goes straight from the previous
+            # step's kernel into it), then read the labels on a side stream behind the mark
+            mark = torch.cuda.Event()
+            mark.record(torch.cuda.current_stream(data.device))
+            sal = _sal.get_saliency_maps(args, data.device, data, target_ohe, frames_np, dim=1,
+                                         gauss_k_n=101)
+            labels = labels_from_ohe(target_ohe, after=mark)
+        else:
+            sal = _sal.get_saliency_maps(args, data.device, data, target_ohe, frames_np, dim=1,
+                                         gauss_k_n=101)
     plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, C, is2d=False)
     if not plan.fired:
         return data, target_ohe, [], None
