@@ -185,12 +185,14 @@ class TrainArgs:
         self.num_steps, self.sample_rate = steps, 2000
 
 
-def train_steps_per_s(method, model_name, B, C, T, rate, device, steps, warmup, barrier, rank,
-                      use_graph=True):
-    """Full training step (train_model.py:498-582): augment + forward + soft CE + backward +
-    clip + Adam + OneCycleLR, batch resident in HBM.  world > 1: one gradient all-reduce per step
-    (FlatGradSync around the hipGraph; DDP for the eager step)."""
-    args = TrainArgs(method, model_name, B, C, T, steps + warmup + 1)
+PROGRESS = {"leg": "", "step": -1}     # what the watchdog reports when a collective hangs
+
+
+def build_train_step(method, model_name, B, C, T, rate, device, total_steps, rank, use_graph=True):
+    """Model, optimiser, (captured) step function for the train legs.  Separate from the timed
+    loop so that every rank can report whether its capture worked BEFORE anyone enters a
+    gradient all-reduce (see ``agree``)."""
+    args = TrainArgs(method, model_name, B, C, T, total_steps)
     x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=rate, seed=100 + rank)
     batch = (torch.from_numpy(x).to(device), torch.from_numpy(labels), torch.from_numpy(frames), wav,
              torch.ones(B, dtype=torch.long), torch.arange(B))
@@ -211,19 +213,52 @@ def train_steps_per_s(method, model_name, B, C, T, rate, device, steps, warmup, 
         step = lambda: g.step(batch, 0, sc)                                  # noqa: E731
     else:
         step = lambda: tm.train_step(args, model, batch, device, opt, sched, crit, 0, sc)  # noqa: E731
-    for _ in range(warmup):
+    return step, {"model": model_name, "method": method, "batch_per_gpu": B, "shape": [B, C, T],
+                  "hipgraph": bool(graphed)}
+
+
+def run_train_steps(step, info, steps, warmup, barrier, tag):
+    PROGRESS["leg"] = tag
+    for i in range(warmup):
+        PROGRESS["step"] = i - warmup
         step()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        PROGRESS["step"] = i
         loss = step()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    return {"steps_per_s": steps / dt, "ms_per_step": 1e3 * dt / steps, "loss": float(loss),
-            "model": model_name, "method": method, "batch_per_gpu": B, "shape": [B, C, T],
-            "hipgraph": bool(graphed)}
+    PROGRESS["leg"] = ""
+    return dict(info, steps_per_s=steps / dt, ms_per_step=1e3 * dt / steps, loss=float(loss))
+
+
+def train_steps_per_s(method, model_name, B, C, T, rate, device, steps, warmup, barrier, rank,
+                      use_graph=True, agree=None, tag="train"):
+    """Full training step (train_model.py:498-582): augment + forward + soft CE + backward +
+    clip + Adam + OneCycleLR, batch resident in HBM.  world > 1: one gradient all-reduce per step
+    (FlatGradSync around the hipGraph; DDP for the eager step).
+
+    ``agree(ok) -> bool`` (N>1): logical AND over ranks.  A rank whose graph capture fails must
+    not fall back to the eager step alone while the others wait in the captured step's
+    all-reduce, so the decision is taken together, after the capture and before the first step."""
+    err = None
+    try:
+        step, info = build_train_step(method, model_name, B, C, T, rate, device, steps + warmup + 1,
+                                      rank, use_graph)
+    except Exception as e:          # noqa: BLE001
+        if not use_graph:
+            raise
+        err, step = e, None
+        print(f"[bench] rank {rank}: graphed {tag} step could not be built: {e!r}", file=sys.stderr)
+    ok = agree(err is None) if agree is not None else err is None
+    if not ok:
+        step, info = build_train_step(method, model_name, B, C, T, rate, device, steps + warmup + 1,
+                                      rank, use_graph=False)
+        info["graph_error"] = repr(err)[:300] if err is not None else "another rank failed to capture"
+    return run_train_steps(step, info, steps, warmup, barrier, tag)
 
 
 def potes_kernel_times(device, B=256, T=5000, iters=100):
@@ -390,6 +425,22 @@ def measured_traffic(method, B, C, T):
     return None, None
 
 
+def launch_ranks(n, argv):
+    """Start ``python -m torch.distributed.run --nproc-per-node n bench.py <argv>`` as a child,
+    stream its stdout/stderr through, return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -408,6 +459,12 @@ def main():
                     help="cProfile the host side of the timed steps to stderr (diagnostic)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher.  Nothing in this process has
+        # touched the GPU yet (imports only), and it never will: the N ranks are CHILDREN
+        # (torch.distributed.run, one process per GPU), rank 0's JSON line is relayed and the
+        # child's exit code is ours.  No exec of a GPU-initialised process anywhere.
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -493,51 +550,73 @@ def main():
                                "(in-order stream, queue kept full), divided by 200"},
     }
 
-    # train step/s (second half of BASELINE.json's metric): 1D-CNN, bs 256 per GPU, DDP if N>1
-    train = None
+    # train step/s (second half of BASELINE.json's metric): 1D-CNN, bs 256 per GPU; N>1: one
+    # gradient all-reduce per step.  N>1 also runs BASELINE.json configs[4]'s per-rank workload
+    # (durmixmagwarp(0.2,4) + ResNet9-1D, bs 256 per GPU -> global 2048 at N=8).
     guard = None
     if not a.no_train and world > 1:
-        # The N>1 train leg is the one part of this file that cannot be rehearsed on a one-GPU
-        # box with RCCL.  If it ever hangs (a collective waiting for a rank that failed), the
-        # headline line must still come out: after 180 s every rank gives up, rank 0 prints the
-        # result it has, and the processes exit without waiting for the stuck call.
+        # The N>1 train legs are the one part of this file that cannot be rehearsed with RCCL on
+        # a one-GPU box.  If a collective hangs (a rank died, mismatched calls), nobody may wait
+        # for ever and nobody may report success: after 240 s every rank says where it was on
+        # stderr, rank 0 still prints the line it has (marked with the error) and the process
+        # exits NON-ZERO without waiting for the stuck call.
         import threading
 
         def give_up():
+            print(f"[bench] rank {rank}: train leg {PROGRESS['leg']!r} stuck at step "
+                  f"{PROGRESS['step']} (collective pending?) after 240 s; giving up",
+                  file=sys.stderr, flush=True)
             if rank == 0:
-                result["train"] = {"error": "train leg did not finish within 180 s"}
+                result["error"] = (f"train leg {PROGRESS['leg']!r} did not finish within 240 s "
+                                   f"(step {PROGRESS['step']}); process exits with code 3")
                 print(strict_json(result), flush=True)
-            os._exit(0)
-        guard = threading.Timer(180.0, give_up)
+            os._exit(3)
+        guard = threading.Timer(240.0, give_up)
         guard.daemon = True
         guard.start()
+
+    def agree(ok):
+        if dist is None:
+            return ok
+        t = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def max_over_ranks(tr):
+        if dist is not None:
+            t = torch.tensor([tr["ms_per_step"]], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tr["ms_per_step"] = float(t.item())
+            tr["steps_per_s"] = 1e3 / tr["ms_per_step"]
+        tr["global_batch"] = tr["batch_per_gpu"] * world
+        tr["samples_per_s"] = tr["steps_per_s"] * tr["global_batch"]
+        return tr
+
     if not a.no_train:
         n_tr, w_tr = max(20, a.steps // 4), max(5, a.warmup // 2)
+        # An exception here is the same code failing on every rank (a rank-local capture failure
+        # is settled inside train_steps_per_s through ``agree``): record it, keep the headline.
         try:
-            try:
-                train = train_steps_per_s(a.method, "Potes", B, C, T, rate, device, n_tr, w_tr,
-                                          barrier, rank)
-            except Exception as e:      # same code on every rank: all ranks fall back together
-                print(f"[bench] graphed train step failed on rank {rank}: {e!r}; eager step instead",
-                      file=sys.stderr)
-                train = train_steps_per_s(a.method, "Potes", B, C, T, rate, device, n_tr, w_tr,
-                                          barrier, rank, use_graph=False)
-                train["graph_error"] = repr(e)[:300]
+            train = train_steps_per_s(a.method, "Potes", B, C, T, rate, device, n_tr, w_tr,
+                                      barrier, rank, agree=agree)
             if world == 1 and "graph_error" not in train:
                 eager = train_steps_per_s(a.method, "Potes", B, C, T, rate, device, n_tr, w_tr,
                                           barrier, rank, use_graph=False)
                 train["eager_steps_per_s"] = eager["steps_per_s"]
-            if dist is not None:
-                t = torch.tensor([train["ms_per_step"]], device=device, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                train["ms_per_step"] = float(t.item())
-                train["steps_per_s"] = 1e3 / train["ms_per_step"]
-            train["global_batch"] = B * world
-            train["samples_per_s"] = train["steps_per_s"] * B * world
-        except Exception as e:          # the augmentation line above must still be printed
+            result["train"] = max_over_ranks(train)
+        except Exception as e:          # noqa: BLE001
             print(f"[bench] train leg failed on rank {rank}: {e!r}", file=sys.stderr)
-            train = {"error": repr(e)[:300]}
-        result["train"] = train
+            result["train"] = {"error": repr(e)[:300]}
+        if world > 1:
+            try:
+                cfg5 = train_steps_per_s("durmixmagwarp(0.2,4)", "resnet9", 256, 4, 5000, rate,
+                                         device, 10, 3, barrier, rank, agree=agree, tag="train_cfg5")
+                cfg5["config"] = "BASELINE.json configs[4]: durmixmagwarp(0.2,4) + ResNet9-1D, " \
+                                 f"bs 256 per GPU (global {256 * world}), one gradient all-reduce per step"
+                result["train_cfg5"] = max_over_ranks(cfg5)
+            except Exception as e:      # noqa: BLE001
+                print(f"[bench] cfg5 leg failed on rank {rank}: {e!r}", file=sys.stderr)
+                result["train_cfg5"] = {"error": repr(e)[:300]}
         if guard is not None:
             guard.cancel()
 

@@ -158,6 +158,18 @@ def displacement_sum(s1: np.ndarray, s2: np.ndarray, lam) -> int:
     return arg
 
 
+def displacement_objective(s1: np.ndarray, s2: np.ndarray, lam, d: int, method: str):
+    """J(d) of ONE candidate exactly as the loops above form it (augmentations.py:70-76, 84-90,
+    105-111, 119-125): numpy float32 sums.  Used by the tests to show that a displacement which
+    differs from the reference's is a near-tie of the reference's own objective."""
+    n1, n2 = len(s1), len(s2)
+    env = "(saloptenv" in method
+    if n1 > n2:
+        mid = np.maximum(s1[d:d + n2], s2) if env else s1[d:d + n2] * lam + s2 * (1 - lam)
+        return np.sum(s1[:d]) + np.sum(mid) + np.sum(s1[d + n2:])
+    return np.sum(np.maximum(s2[d:d + n1], s1) if env else s1 * lam + s2[d:d + n1] * (1 - lam))
+
+
 def salopt_displacements(sal1, sal2, f1, f2, lam_np, method: str) -> np.ndarray:
     """Displacement per heart state (0 where lengths agree); augmentations.py:210-287."""
     fn = displacement_env if "(saloptenv" in method else displacement_sum

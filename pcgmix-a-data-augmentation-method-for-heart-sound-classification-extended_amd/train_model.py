@@ -294,6 +294,18 @@ def shard_batch(batch, rank: int, world: int):
     return tuple(b[sl] for b in batch)
 
 
+def reseed_device_rng(args, device) -> None:
+    """train_model.py:565: the reference calls ``torch.cuda.manual_seed_all(args.seed_fix)`` before
+    every ``optimizer.step()``.  Its visible effect on a GPU is on the NEXT forward pass: the
+    device generator restarts from the same position every step, so every step (and, under
+    DataParallel, every replica) draws the same dropout masks.  Kept, for this process's device
+    (one process per GPU); host-only, no launch.  ``args.seed_fix`` is set by ``train_model``
+    (:217); loops that do not set it keep torch's running stream."""
+    seed = getattr(args, "seed_fix", None)
+    if seed is not None and device.type == "cuda":
+        torch.cuda.manual_seed(int(seed))
+
+
 def train_step(args, model, batch, device, optimizer, scheduler, criterion, epoch, step_counter,
                stats: Optional[dict] = None, sync: Optional["FlatGradSync"] = None):
     """One iteration of the reference's batch loop (train_model.py:498-582) without host syncs.
@@ -320,6 +332,7 @@ def train_step(args, model, batch, device, optimizer, scheduler, criterion, epoc
     if args.grad_clip and not isinstance(optimizer, ClipAdam):      # ClipAdam clips in its kernel
         nn.utils.clip_grad_value_([p for p in model.parameters() if p.grad is not None],
                                   clip_value=args.grad_clip)
+    reseed_device_rng(args, device)
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     if scheduler is not None:
@@ -360,6 +373,12 @@ class GraphedTrainStep:
         self.t[:, 0] = 1
         self.sync = sync
         self.bwd_seed = torch.full((), sync.backward_scale if sync else 1.0, device=device)
+        # The warm-up passes run the network on the all-zero placeholder batch: they must leave no
+        # trace.  Weights are not updated (no optimiser step); BatchNorm running statistics and
+        # num_batches_tracked, and the device RNG stream the dropout masks come from, are put
+        # back afterwards, so a graphed run starts from exactly the state an eager run starts from.
+        buffers = [(b, b.detach().clone()) for b in model.buffers()]
+        rng = torch.cuda.get_rng_state(device)
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):                   # warm-up off the capture (no weight update)
@@ -369,6 +388,10 @@ class GraphedTrainStep:
             if sync is not None:
                 sync.attach()
         torch.cuda.current_stream(device).wait_stream(side)
+        with torch.no_grad():
+            for b, saved in buffers:
+                b.copy_(saved)
+        torch.cuda.set_rng_state(rng, device)
         self.opt.zero_grad(set_to_none=True)
         if sync is not None and sync.world > 1:
             # no collective may be in flight while the graph is captured, and every rank must
@@ -429,6 +452,7 @@ class GraphedTrainStep:
             self.sync.reduce_and_bind()
             if self.args.grad_clip and not isinstance(self.opt, ClipAdam):
                 nn.utils.clip_grad_value_(self.sync.params, clip_value=self.args.grad_clip)
+        reseed_device_rng(self.args, self.device)
         self.opt.step()
         if self.sched is not None:
             self.sched.step()

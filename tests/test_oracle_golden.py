@@ -47,3 +47,28 @@ def test_oracle_ce_soft():
     t = np.eye(2)[rs.randint(0, 2, 16)] * 0.7 + 0.15
     ref = -(torch.log_softmax(torch.from_numpy(logits), 1) * torch.from_numpy(t)).sum(1).mean()
     assert abs(O.ce_soft(logits, t) - float(ref)) < 1e-6
+
+
+@pytest.mark.parametrize("path", golden_files("salopt_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_oracle_displacement_objective_is_what_the_search_maximises(path):
+    """``displacement_objective`` (used by the GPU tests to prove near-ties) evaluated at every
+    candidate reproduces the reference's recorded arg-max: first strict maximum."""
+    g = load_golden(path)
+    lam_np = np.full((1, 1), np.float32(g["lam"]), dtype=np.float32)
+    fr, checked = g["frames"], 0
+    for i in range(len(fr)):
+        j = g["mix"][i]
+        for k in range(4):
+            n1, n2 = fr[i, k + 1] - fr[i, k], fr[j, k + 1] - fr[j, k]
+            if n1 == n2:
+                assert g["disp"][i, k] == 0
+                continue
+            s1, s2 = g["sal"][i][fr[i, k]:fr[i, k + 1]], g["sal"][j][fr[j, k]:fr[j, k + 1]]
+            vals = [O.displacement_objective(s1, s2, lam_np, d, g["method"]) for d in range(abs(n1 - n2) + 1)]
+            best, arg = float("-inf"), 0
+            for d, v in enumerate(vals):
+                if v > best:
+                    best, arg = v, d
+            assert arg == g["disp"][i, k]
+            checked += 1
+    assert checked > 10

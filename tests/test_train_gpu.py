@@ -341,3 +341,94 @@ def test_train_model_driver_two_ranks_graphed(device, tmp_path):
         assert torch.equal(a, b)
     assert r0["loss"][-1] < r0["loss"][0]
     assert len(glob.glob(str(tmp_path / "*" / "model.pth"))) == 1
+
+
+def _cfg5_rank(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)                       # rehearsal: both ranks share the one GPU
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, C, T = 256, 4, 5000
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=2000, seed=40 + rank)
+    batch = (torch.from_numpy(x).to(dev), torch.from_numpy(labels), torch.from_numpy(frames), wav,
+             torch.ones(B, dtype=torch.long), torch.arange(B))
+    args = make_args(model="resnet9", method="durmixmagwarp(0.2,4)", batch_size=B, sig_len=T,
+                     num_steps=12, sample_rate=2000)
+    out = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(rank)                         # rank 0's initial weights must win
+        net = tm.build_model(args).to(dev).train()
+        opt, sched = tm.make_optimizer(args, net)
+        crit = tm.SELCLoss(labels, 2, es=args.num_epochs + 1, device=dev)
+        sc = tm.step_counter_class()
+        sync = tm.FlatGradSync(net, dev)
+        start = [p.detach().clone() for p in net.parameters()]
+        if mode == "eager":
+            losses = [float(tm.train_step(args, net, batch, dev, opt, sched, crit, 0, sc, sync=sync))
+                      for _ in range(3)]
+        else:
+            g = tm.GraphedTrainStep(args, net, opt, sched, crit, dev, B, C, T, sync=sync)
+            losses = [float(g.step(batch, 0, sc)) for _ in range(3)]
+        torch.cuda.synchronize()
+        out[mode] = {"losses": losses, "params": [p.detach().cpu() for p in net.parameters()],
+                     "moved": any(not torch.equal(a, b) for a, b in zip(start, net.parameters())),
+                     "bn_mean": net.conv1[1].running_mean.detach().cpu()}
+    torch.save(out, os.path.join(out_dir, f"cfg5_rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cfg5_per_rank_workload_two_ranks(device, tmp_path):
+    """BASELINE.json configs[4], per-rank workload at full size: durmixmagwarp(0.2,4) on
+    (256,4,5000) + ResNet9-1D, gradients averaged by ONE flat all-reduce per step
+    (``FlatGradSync``; replaces nn.DataParallel, reference train_model.py:385).  Two gloo ranks
+    share this box's GPU, each with its own batch; eager step and captured step.  Replicas must
+    stay bit-identical (same start, same averaged gradients, same optimiser state) while their
+    BatchNorm statistics stay per rank, as under DataParallel."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_cfg5_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(str(tmp_path / "cfg5_rank0.pt"), weights_only=True)
+    r1 = torch.load(str(tmp_path / "cfg5_rank1.pt"), weights_only=True)
+    for mode in ("eager", "graph"):
+        a, b = r0[mode], r1[mode]
+        assert a["moved"] and b["moved"]
+        assert all(np.isfinite(a["losses"])) and all(np.isfinite(b["losses"]))
+        for p, q in zip(a["params"], b["params"]):
+            assert torch.equal(p, q), mode
+        assert not torch.equal(a["bn_mean"], b["bn_mean"])      # per-rank statistics
+        assert a["losses"] != b["losses"]                       # different shards
+    # the captured step reproduces the eager one (same seeds, no dropout in ResNet9)
+    assert np.allclose(r0["eager"]["losses"], r0["graph"]["losses"], rtol=2e-3, atol=1e-4), \
+        (r0["eager"]["losses"], r0["graph"]["losses"])
+
+
+def test_bench_self_launches_two_ranks(device):
+    """`python bench.py --gpus 2` from a bare shell (no WORLD_SIZE): bench.py starts the ranks
+    itself as child processes before touching the GPU, relays rank 0's line and returns the
+    child's exit code.  Rehearsed with gloo: both ranks share this box's one GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PCGMIX_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20",
+                          "--warmup", "3"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and "error" not in d
+    assert abs(d["value"] - 2 * 256 * 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-6
+    assert d["train"]["global_batch"] == 512 and d["train"]["steps_per_s"] > 0
+    assert d["train_cfg5"]["global_batch"] == 512 and d["train_cfg5"]["model"] == "resnet9"
+    assert np.isfinite(d["train_cfg5"]["loss"])
