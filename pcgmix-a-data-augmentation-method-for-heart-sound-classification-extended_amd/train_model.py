@@ -488,14 +488,21 @@ def train_epoch(args, model, train_loader, device, optimizer, scheduler, criteri
 @torch.no_grad()
 def test_data_accuracy(args, model, test_loader, device, criterion=None):
     """Evaluation as train_model.py:591-670: per recording, average the softmax of its heart
-    cycles and take the argmax; accuracy / sensitivity / specificity over recordings.  The
-    per-recording mean is a segmented sum on the device (index_add), not a Python dict of
-    ``.item()`` values."""
+    cycles and take the argmax (:623-633); with '(class_majority)' in ``args.method`` the
+    recording's class is the majority of its cycles' arg-max votes, a 0/1 tie going to class 1
+    (:634-647).  Accuracy / sensitivity / specificity / precision / recall / F1 over recordings,
+    ROC-AUC of the mean class-1 probability.  The per-recording sums are segmented sums on the
+    device (index_add), not a Python dict of ``.item()`` values.
+
+    Returns a dict (the reference appends the same numbers to its ``performance`` object).
+    Under '(class_majority)' the reference never collects the mean probabilities and its own
+    ``roc_auc_score`` line (:667) raises IndexError; here ``rocauc`` is None on that branch."""
     model.eval()
     rec_ids: dict = {}
     rec_label: dict = {}
     parts = []
-    loss_sum, n = 0.0, 0
+    loss_sum = torch.zeros((), device=device, dtype=torch.float64)
+    n = 0
     for data, target, _frames, wav, _sq, _idx in test_loader:
         data = data.to(device)
         out = model(data)
@@ -504,18 +511,28 @@ def test_data_accuracy(args, model, test_loader, device, criterion=None):
             rec_label.setdefault(rec_ids.setdefault(w, len(rec_ids)), t)   # first cycle's label
         ids = torch.tensor([rec_ids[w] for w in wav], device=device)
         parts.append((ids, prob))
-        if criterion is not None:
-            loss_sum += float(criterion(out, F.one_hot(target, args.num_classes).to(device),
-                                        None, None, "test")) * len(target)
+        if criterion is not None:               # :608-609, accumulated on the device
+            loss_sum += criterion(out, F.one_hot(target, args.num_classes).to(device),
+                                  None, None, "test").double() * len(target)
         n += len(target)
     R = len(rec_ids)
+    majority = "(class_majority)" in getattr(args, "method", "")
     acc_p = torch.zeros(R, args.num_classes, device=device)
     acc_n = torch.zeros(R, device=device)
+    votes = torch.zeros(R, args.num_classes, device=device, dtype=torch.long)
     for ids, prob in parts:
         acc_p.index_add_(0, ids, prob)
         acc_n.index_add_(0, ids, torch.ones_like(ids, dtype=torch.float))
+        if majority:
+            votes.index_add_(0, ids, F.one_hot(prob.argmax(1), args.num_classes))
     mean_p = (acc_p / acc_n[:, None]).cpu().numpy()
-    pred = mean_p.argmax(1)
+    if majority:
+        pred = np.zeros(R, dtype=np.int64)
+        for r, c in enumerate(votes.cpu().numpy()):
+            c = np.trim_zeros(c, "b") if c.any() else c[:1]          # what np.bincount returns
+            pred[r] = 1 if (len(c) == 2 and c[0] == c[1]) else int(np.argmax(c))
+    else:
+        pred = mean_p.argmax(1)
     lab = np.asarray([rec_label[i] for i in range(R)])
     tp = int(((pred == 1) & (lab == 1)).sum()); tn = int(((pred == 0) & (lab == 0)).sum())
     fp = int(((pred == 1) & (lab == 0)).sum()); fn = int(((pred == 0) & (lab == 1)).sum())
@@ -523,7 +540,7 @@ def test_data_accuracy(args, model, test_loader, device, criterion=None):
     rec = tp / max(1, tp + fn)
     # ROC-AUC of the class-1 mean probability (Mann-Whitney U with average ranks for ties)
     auc = None
-    if 0 < lab.sum() < R:
+    if 0 < lab.sum() < R and not majority:
         score = mean_p[:, 1]
         order = np.argsort(score, kind="mergesort")
         ranks = np.empty(R)
@@ -533,10 +550,10 @@ def test_data_accuracy(args, model, test_loader, device, criterion=None):
             ranks[tie] = ranks[tie].mean()
         n1 = int(lab.sum())
         auc = float((ranks[lab == 1].sum() - n1 * (n1 + 1) / 2) / (n1 * (R - n1)))
-    return {"accuracy": 100.0 * (tp + tn) / max(1, R), "sensitivity": 100.0 * rec,
+    return {"accuracy": 100.0 * float((pred == lab).sum()) / max(1, R), "sensitivity": 100.0 * rec,
             "specificity": 100.0 * tn / max(1, tn + fp), "precision": prec, "recall": rec,
             "f1": 2 * prec * rec / max(1e-12, prec + rec), "rocauc": auc, "recordings": R,
-            "loss": loss_sum / max(1, n) if criterion is not None else None}
+            "loss": float(loss_sum) / max(1, n) if criterion is not None else None}
 
 
 def train_model(args, dataset, device, use_graph: bool = True, log=print):

@@ -77,8 +77,10 @@ def _reference_import_names():
     return names
 
 
-def import_reference():
-    """Returns a namespace with the reference modules used on the hot path."""
+def import_reference(extra=()):
+    """Returns a namespace with the reference modules used on the hot path (plus ``extra``
+    module names, e.g. ``("train_model",)`` — it imports too: its only CUDA-only statement is
+    inside ``SELCLoss.__init__``, train_model.py:60, which the golden scripts never call)."""
     import pandas as pd
 
     sys.dont_write_bytecode = True
@@ -90,7 +92,7 @@ def import_reference():
     try:
         mods = {}
         for name in ("utils", "models", "models2d", "saliency", "augmentations",
-                     "augmentations2d"):
+                     "augmentations2d") + tuple(extra):
             mods[name] = importlib.import_module(name)
     finally:
         pd.read_csv = real_read_csv

@@ -241,8 +241,8 @@ def main():
     m = ref.models2d.ResNet9(num_classes=2).eval()
     out["resnet2d_logits"] = m(torch.from_numpy(x2d[:4]), depth=0, pass_part="second").detach().numpy()
     out["resnet2d_nparams"] = np.int64(sum(p.numel() for p in m.parameters()))
-    # CELoss is defined in train_model.py, which cannot be imported without CUDA-only
-    # side effects; the formula (train_model.py:45-54) is checked against torch in tests.
+    # CELoss, train_epoch and test_data_accuracy (train_model.py) are recorded by
+    # make_golden_train.py -> train_ref.npz.
     np.savez_compressed(os.path.join(HERE, "models_seed7.npz"), x1d=xa, x2d=x2d[:4], **out)
     print("models_seed7.npz written")
 

@@ -229,3 +229,24 @@ def test_train_model_driver_two_ranks(tmp_path):
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)
     assert len(glob.glob(str(tmp_path / "*" / "model.pth"))) == 1
+
+
+# ---- reference-recorded goldens (tests/golden/train_ref.npz <- the reference's train_model.py) ----
+def test_celoss_matches_reference_golden():
+    import train_replay
+    train_replay.check_celoss(torch.device("cpu"))
+
+
+def test_train_epoch_reproduces_reference_trajectory_cpu():
+    """train_epoch here == the reference's train_epoch (train_model.py:490-589) run on the same
+    10 batches: per-step loss, lr, mean loss, accuracy, every parameter after step 10."""
+    import train_replay
+    res = train_replay.trajectory(torch.device("cpu"), "epoch")
+    train_replay.check_trajectory(res, loss_tol=2e-6, param_tol=2e-5)
+
+
+def test_evaluation_matches_reference_golden_cpu():
+    """test_data_accuracy (mean-probability vote and '(class_majority)') == the reference's
+    train_model.py:591-670 on a synthetic 12-recording loader."""
+    import train_replay
+    train_replay.check_evaluation(torch.device("cpu"))
