@@ -79,23 +79,51 @@ def make_device_batch(B, C, T, rate, seed, device):
     return x, data, tgt, torch.from_numpy(frames), labels, wav
 
 
-def run_augment_steps(method, data, tgt, frames, wav, device, steps, warmup, barrier):
+def run_augment_steps(method, data, tgt, frames, wav, device, steps, warmup, barrier,
+                      host_labels=None):
+    """``steps`` calls of the drop-in ``augment()`` through the reference's positional signature
+    (``host_labels``: the keyword extension that spares the label read-back, for the split of the
+    step time reported under extra.host_split)."""
     args, sc = Args(method), StepCounter()
+    kw = {} if host_labels is None else {"host_labels": host_labels}
     for _ in range(warmup):
-        augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "")
+        augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "", **kw)
         sc.add()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "")
+        out = augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "", **kw)
         sc.add()
     torch.cuda.synchronize()
     barrier()
     return time.perf_counter() - t0, out
 
 
-def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200, per_launch=False):
+def exact_mix_bytes(frames, mix, C, T):
+    """Bytes one launch of the splice kernel must move for THIS batch: every own element read
+    once and every output element written once (8*C*T per sample) plus the partner row inside
+    the blended ranges only, sum_k min(len_k(b), len_k(mix[b])) elements per channel row
+    (augmentations.py:294-304).  The contract's 12*C*T counts the whole partner
+    row; the kernel never reads the part of it that is not blended."""
+    frames = np.asarray(frames, dtype=np.int64)
+    lens = np.diff(frames, axis=1)
+    blended = int(np.minimum(lens, lens[np.asarray(mix)]).sum())
+    return 4.0 * C * (2.0 * frames.shape[0] * T + blended)
+
+
+def mix_kernel_name(B, C, T, warp):
+    """Name of the instantiation pcgmix_mix_warp_f32 launches for this problem (asked from the
+    library: the choice of lane width and unroll lives there)."""
+    import ctypes
+    from pcgmix_amd import _lib
+    vec, unroll = ctypes.c_int(), ctypes.c_int()
+    _lib.check(_lib.load().pcgmix_mix_variant(B, C, T, int(bool(warp)), 1, ctypes.byref(vec),
+                                              ctypes.byref(unroll)), "pcgmix_mix_variant")
+    return f"pcgmix::mix_warp_kernel<{vec.value}, {'true' if warp else 'false'}, {unroll.value}>"
+
+
+def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200, per_launch=False, info=None):
     """The fused kernel alone, launched back to back from one prepared plan (no host prologue
     between launches): the figure to compare with rocprofv3's per-kernel average."""
     if B * C * T > 64_000_000:          # saturating batches: random payload made on device
@@ -105,6 +133,9 @@ def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200, per_launch=
         x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=rate, seed=0)
         data = torch.from_numpy(x).to(device)
     plan = hostprep.make_plan(method, labels, frames, wav, 1, B, C)
+    if info is not None:
+        info["exact_bytes"] = exact_mix_bytes(frames, plan.mix, C, T)
+        info["kernel"] = mix_kernel_name(B, C, T, plan.knots is not None)
     with torch.cuda.device(device):
         dev, offs = augmentations.upload_plan(plan, frames, device)
     base = dev.data_ptr()
@@ -410,19 +441,51 @@ def cfg4_spectrogram(device, steps=8, warmup=2, B=256, T=5000):
 
 
 def measured_traffic(method, B, C, T):
-    """HBM bytes per launch of the splice kernel from the committed rocprofv3 PMC passes
-    (profiles/r*_mix_kernel_summary.json; FETCH_SIZE x2 + WRITE_SIZE, see that file) — only when
-    it was collected on exactly this workload, else None."""
+    """HBM-side bytes per launch of the splice kernel as rocprofv3's PMC passes counted them
+    (profiles/r*_mix_roofline.json: FETCH_SIZE doubled per the guide's gfx950 correction +
+    WRITE_SIZE, separate --pmc passes, collected by profiles/mix_pmc_probe.py) — read from the
+    committed file, NOT measured in this run, and only for exactly this workload; else None."""
     import glob
-    want = f"{method} ({B},{C},{T}) float32"
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mix_kernel_summary.json")), reverse=True):
+    key = f"{method} ({B},{C},{T})"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mix_roofline.json")), reverse=True):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if d.get("workload", "").startswith(want):
-            return d["hbm_bytes_per_launch"]["total"], os.path.basename(path)
+        w = d.get("workloads", {}).get(key)
+        if w and w.get("hbm_bytes_per_launch"):
+            return w["hbm_bytes_per_launch"], f"file profiles/{os.path.basename(path)} " \
+                                              f"(collected at {d.get('collected_at', '?')})"
     return None, None
+
+
+def roofline_entry(method, B, C, T, kern_ms, info):
+    """Roofline object of one splice launch.  ``achieved``/``frac`` use the bytes THIS batch needs
+    (own read + write + partner read inside blended ranges, ``exact_mix_bytes``); the contract's
+    12*C*T model, which counts the whole partner row, is reported beside it."""
+    exact = info["exact_bytes"]
+    model = 12.0 * C * T * B
+    achieved = exact / (kern_ms * 1e-3) / 1e9
+    traffic, src = measured_traffic(method, B, C, T)
+    working_set = 8.0 * B * C * T
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+           "kernel": info["kernel"], "kernel_ms": kern_ms,
+           "algorithmic_bytes_per_launch": exact,
+           "bytes_definition": "4*C*(2*B*T + sum_b sum_k min(len_k(b), len_k(partner b))): own read "
+                               "+ write + partner read inside blended ranges, this batch",
+           "contract_model_12CT": {"bytes_per_launch": model,
+                                   "achieved": model / (kern_ms * 1e-3) / 1e9,
+                                   "frac": model / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "working_set_bytes": working_set,
+           "residency": ("input + output fit the 256 MiB Infinity Cache: back-to-back launches are "
+                         "served on-die, this is NOT an HBM-rate measurement (see the saturating "
+                         "legs in extra)") if working_set < 256 * 2**20 else
+                        "input + output exceed the 256 MiB Infinity Cache: HBM-rate measurement",
+           "achievable_copy_GBs": 6290.0}
+    if traffic:
+        out["frac_on_counter_bytes"] = traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return out
 
 
 def launch_ranks(n, argv):
@@ -526,11 +589,13 @@ def main():
     # duration plus the dispatch gap; rocprofv3's per-dispatch mean agrees with it within 5 %
     # (profiles/).  Also reported, not used: the median of event pairs recorded around every
     # single launch (each pair adds 2-6 us of marker overhead, different from box to box).
+    kinfo = {}
     per_launch_pair_ms, kern_ms = kernel_back_to_back_ms(a.method, B, C, T, rate, device,
-                                                         per_launch=True)
-    alg_bytes = 12.0 * C * T * B                     # read own + read partner + write, fp32
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic, traffic_src = measured_traffic(a.method, B, C, T)
+                                                         per_launch=True, info=kinfo)
+    roof = roofline_entry(a.method, B, C, T, kern_ms, kinfo)
+    roof["per_launch_event_pair_ms"] = per_launch_pair_ms
+    roof["timing"] = ("HIP events on the launch stream around 200 back-to-back launches "
+                      "(in-order stream, queue kept full), divided by 200")
     result = {
         "metric": "augmented PCG samples/s", "value": value, "unit": "samples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -540,14 +605,7 @@ def main():
                                f"({B},{C},{T}) float32 per GPU (BASELINE.json configs[1])",
                    "batch_per_gpu": B, "channels": C, "sig_len": T, "method": a.method,
                    "parallelism": f"dp{world}"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": traffic_src,
-                     "kernel": "pcgmix::mix_warp_kernel<4,false,2>", "kernel_ms": kern_ms,
-                     "per_launch_event_pair_ms": per_launch_pair_ms,
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "timing": "HIP events on the launch stream around 200 back-to-back launches "
-                               "(in-order stream, queue kept full), divided by 200"},
+        "roofline": roof,
     }
 
     # train step/s (second half of BASELINE.json's metric): 1D-CNN, bs 256 per GPU; N>1: one
@@ -634,9 +692,17 @@ def main():
 
         if not a.no_extra:
             def kernel_leg(m, b, c, t):
-                ms = kernel_back_to_back_ms(m, b, c, t, rate, device, iters=50 if b > 1000 else 200)
-                gbs = 12.0 * b * c * t / (ms * 1e-3) / 1e9
-                return {"kernel_ms": ms, "GBs": gbs, "frac_of_8TBs": gbs / HBM_PEAK_GBS}
+                ki = {}
+                ms = kernel_back_to_back_ms(m, b, c, t, rate, device, iters=50 if b > 1000 else 200,
+                                            info=ki)
+                r = roofline_entry(m, b, c, t, ms, ki)
+                return {"kernel_ms": ms, "kernel": r["kernel"], "GBs": r["achieved"],
+                        "frac_of_8TBs": r["frac"], "bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                        "GBs_12CT_model": r["contract_model_12CT"]["achieved"],
+                        "frac_12CT_model": r["contract_model_12CT"]["frac"],
+                        "traffic": r["traffic"], "traffic_source": r["traffic_source"],
+                        "frac_on_counter_bytes": r.get("frac_on_counter_bytes"),
+                        "infinity_cache_resident": r["working_set_bytes"] < 256 * 2**20}
             for tag, (m, b, c, t) in {
                 "mix_256x1x5000": ("durratiomixup", 256, 1, 5000),
                 "magwarp_256x1x5000": ("durmixmagwarp(0.2,4)", 256, 1, 5000),
@@ -656,6 +722,28 @@ def main():
                 ("augment_magwarp_256x4x5000", "durmixmagwarp(0.2,4)", (data, tgt, frames, wav)),
             ):
                 leg(tag, lambda m=m, dd=dd, tt=tt, ff=ff, ww=ww: augment_leg(m, dd, tt, ff, ww))
+            def host_split():
+                """Where a strict-signature step goes: the same loop with the labels handed over
+                on the host (no read-back, no host wait), the read-back on its own (D2H of the
+                one-hot matrix + stream sync through torch, for scale), and the kernel."""
+                n = max(a.steps, 200)
+                d_strict, _ = run_augment_steps(a.method, data, tgt, frames, wav, device, n, 20, barrier)
+                d_host, _ = run_augment_steps(a.method, data, tgt, frames, wav, device, n, 20, barrier,
+                                              host_labels=labels)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    augmentations.labels_from_ohe(tgt)
+                d_rb = time.perf_counter() - t0
+                return {"strict_signature_us": 1e6 * d_strict / n,
+                        "host_labels_no_readback_us": 1e6 * d_host / n,
+                        "readback_inside_step_us": 1e6 * (d_strict - d_host) / n,
+                        "torch_readback_alone_us": 1e6 * d_rb / n,
+                        "kernel_us": 1e3 * kern_ms,
+                        "note": "host_labels_no_readback is pure host + launch cost (the GPU keeps "
+                                "up: kernel < host); strict adds the label read-back the "
+                                "reference's signature forces (augmentations.py:501)"}
+            leg("host_split", host_split)
             leg("potes_stack", lambda: potes_kernel_times(device))
             leg("secondary_kernels", lambda: secondary_kernel_times(device))
             leg("cfg3_salopt", lambda: cfg3_salopt(device))

@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 8
+#define PCGMIX_ABI_VERSION 9
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -332,6 +332,54 @@ int pcgmix_splice_same_label_ohe_f32(const float* x, float* y, const int64_t* ta
                                      void* dev_idx, int64_t* mix_out, int B, int C, int T,
                                      pcgmix_stream_t stream);
 long long pcgmix_splice_staging_bytes(int B, int C, int n_knots);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-device step context + the whole fired step of a plain PCGmix method in ONE call.
+ *                                                                            [host + device]
+ * What the reference's augment() does between the probability gate and the returned tensor for
+ * durratiomixup / durmixmagwarp with same-label partners (augmentations.py:874-928, 941-977):
+ * label recovery from the one-hot matrix (:501), the partner permutation (:500-514), boundary
+ * packing, the per-sample splice loop (:909-917, 969-977) and magnitude_warp (:674-683).
+ *
+ * The context owns what the step needs besides the batch: a ring of pinned staging buffers with
+ * device twins (a slot is reused only after the kernel that read it has finished), host-mapped
+ * memory for the label read-back, the spline operators per (T, n_knots).  It is created on
+ * `device`; calls may come with any device current.  One context per device and host thread.
+ *
+ * pcgmix_augment_plain_f32:
+ *   x, y            device (B, C, T); y must not alias x
+ *   target_ohe_dev  device int64 (B, num_classes) one-hot as the reference passes it, or NULL when
+ *   labels_host     host int64 (B) class labels are given instead (no read-back, no host wait)
+ *   frames          HOST int64 (B, 5), as the reference's loader yields them
+ *   lam             float32(lambda) drawn by the caller from numpy's global stream (:659-666)
+ *   knots           HOST float64 (B, n_knots, C) as numpy.random.normal drew them (:677), or NULL
+ *   mix_out         HOST int64 (B) out: the partner permutation (bit-identical to CPython's)
+ * Order of work: the label arg-max kernel is enqueued FIRST (it writes int32 labels into
+ * host-mapped memory and releases a flag word); boundaries are validated and packed, knots staged
+ * and MT19937 seeded while the GPU gets there; then the host spins on the flag (the one wait
+ * the reference's signature forces; falls back to hipStreamSynchronize after 2 ms), draws the
+ * permutation, issues ONE hipMemcpyAsync and the fused kernel.  Must not be called on a
+ * capturing stream when target_ohe_dev is used (hipErrorStreamCaptureUnsupported).
+ * Returns 0; -1 frames not monotone / negative, -2 cycle end beyond T (splice not enqueued); or
+ * a hipError_t.
+ *
+ * pcgmix_ctx_gate: random.Random(step).uniform(0, 1) (augmentations.py:869-870, 936-937); the
+ * seeded generator is kept, so the step call for the same `step` does not seed a second time.
+ */
+typedef struct pcgmix_ctx pcgmix_ctx;
+int pcgmix_ctx_create(int device, pcgmix_ctx** out);
+void pcgmix_ctx_destroy(pcgmix_ctx* ctx);
+double pcgmix_ctx_gate(pcgmix_ctx* ctx, uint64_t step);
+int pcgmix_augment_plain_f32(pcgmix_ctx* ctx, const float* x, float* y,
+                             const int64_t* target_ohe_dev, int num_classes,
+                             const int64_t* labels_host, const int64_t* frames, uint64_t step,
+                             float lam, const double* knots, int n_knots, int64_t* mix_out,
+                             int B, int C, int T, pcgmix_stream_t stream);
+
+/* Which instantiation of the splice kernel pcgmix_mix_warp_f32 launches for this problem:
+ * vec = 4 (16-byte lanes; needs T % 4 == 0 and 16-byte aligned x, y) or 1, unroll = quads per
+ * lane (1, 2, 4).  For reporting: the kernel's name is mix_warp_kernel<vec, warp, unroll>. */
+int pcgmix_mix_variant(int B, int C, int T, int warp, int aligned16, int* vec, int* unroll);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm (training mode) + ReLU + MaxPool of a ResNet9 block, channels innermost.  [device]

@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -65,6 +65,13 @@ SIGNATURES = {
                                                   _c_float, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr,
                                                   _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_splice_staging_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
+    "pcgmix_ctx_create": (_c_int, [_c_int, ctypes.POINTER(_ptr)]),
+    "pcgmix_ctx_destroy": (None, [_ptr]),
+    "pcgmix_ctx_gate": (ctypes.c_double, [_ptr, ctypes.c_uint64]),
+    "pcgmix_augment_plain_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _ptr, ctypes.c_uint64,
+                                          _c_float, _ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr]),
+    "pcgmix_mix_variant": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_int),
+                                    ctypes.POINTER(_c_int)]),
     "pcgmix_bnrp_workspace_floats": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int]),
     "pcgmix_bnrp_fwd_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float, _ptr, _ptr, _ptr,
                                      _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr]),

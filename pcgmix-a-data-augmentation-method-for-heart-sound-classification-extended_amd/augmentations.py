@@ -28,6 +28,7 @@ from . import _lib, hostprep
 from .hostprep import MixPlan
 
 _OP_CACHE: dict = {}      # (device index, T, n_knots) -> device tensor with the spline operator
+_RECIPES: dict = {}       # method string -> plain recipe | None (general plan path) | False (passthrough)
 
 
 def _raw_stream(device: torch.device) -> int:
@@ -218,72 +219,98 @@ def apply_plan(plan: MixPlan, data: torch.Tensor, frames: np.ndarray,
 
 _SPLICE_ERRORS = {-1: _PACK_ERRORS[1], -2: _PACK_ERRORS[2], -3: _PACK_ERRORS[3]}
 
+_CTX: dict = {}           # device index -> pcgmix_ctx* (per-device step context, never freed)
+_c_float = ctypes.c_float
+_get_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
-def splice_plain(recipe, data: torch.Tensor, labels, frames: np.ndarray, step: int,
+
+def step_context(index: int) -> int:
+    """The library's per-device step context (pinned staging ring + device twins + label
+    read-back memory + spline operators), created on first use."""
+    ctx = _CTX.get(index)
+    if ctx is None:
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(lib.pcgmix_ctx_create(index, ctypes.byref(h)), "pcgmix_ctx_create")
+        ctx = _CTX[index] = h.value
+    return ctx
+
+
+def _frames_ptr(frames, B: int):
+    """(address, keep-alive) of the (B,5) int64 boundaries on the host.  The reference's loader
+    yields a contiguous CPU int64 tensor (dataloader_physionet.py:151-172): its storage is used as
+    it is; anything else goes through numpy."""
+    if isinstance(frames, torch.Tensor) and frames.dtype == torch.int64 and not frames.is_cuda \
+            and frames.is_contiguous():
+        if frames.shape != (B, 5):
+            raise ValueError("labels/frames do not match the batch size")
+        return frames.data_ptr(), frames
+    arr = _as_numpy_frames(frames)
+    if arr.shape != (B, 5):
+        raise ValueError("labels/frames do not match the batch size")
+    return arr.ctypes.data, arr
+
+
+def splice_plain(recipe, data: torch.Tensor, labels, frames, step: int,
                  out: Optional[torch.Tensor] = None, target_ohe: Optional[torch.Tensor] = None):
     """One fired step of a plain splice (``hostprep.plain_recipe``) through
-    ``pcgmix_splice_same_label_f32``: the partner draw, validation, packing, the single H2D copy and
-    the launch happen inside the library; Python only draws lambda (and the warp knots) from
-    numpy's global stream exactly where the reference does (augmentations.py:661-663, 677) and
-    picks the staging slot.  ``data`` is (B, C, T) — the 2D path passes (B, F, W).
-    ``labels`` = host class labels, or None with ``target_ohe`` = the device one-hot int64 matrix
-    (read back inside the library call).  Returns (out, mix_indices)."""
+    ``pcgmix_augment_plain_f32``: label read-back, partner draw, validation, packing, the single
+    H2D copy and the launch happen inside the library, on staging the library owns; Python only
+    draws lambda (and the warp knots) from numpy's global stream exactly where the reference
+    does (augmentations.py:661-663, 677) and allocates the output.  ``data`` is (B, C, T) — the
+    2D path passes (B, F, W).  ``labels`` = host class labels, or None with ``target_ohe`` = the
+    device one-hot int64 matrix.  Returns (out, mix_indices)."""
     _name, _p, alpha, sigma, n_knots = recipe
     B, C, T = data.shape
-    device = data.device
-    ohe = None
+    idx = data.device.index
+    ohe_ptr, n_cls, lab_ptr = None, 0, None
     if labels is None:
         ohe = target_ohe.detach()
-        if not (ohe.is_cuda and ohe.dtype == torch.int64 and ohe.dim() == 2 and ohe.is_contiguous()):
-            labels, ohe = labels_from_ohe(target_ohe), None
-    if ohe is None:
+        if ohe.is_cuda and ohe.dtype == torch.int64 and ohe.dim() == 2 and ohe.is_contiguous():
+            if ohe.shape[0] != B:
+                raise ValueError("labels/frames do not match the batch size")
+            ohe_ptr, n_cls = ohe.data_ptr(), ohe.shape[1]
+        else:
+            labels = labels_from_ohe(target_ohe)
+    if ohe_ptr is None:
         labels = np.ascontiguousarray(np.asarray(labels).reshape(-1), dtype=np.int64)
-    if (ohe.shape[0] if ohe is not None else labels.shape[0]) != B or frames.shape != (B, 5):
-        raise ValueError("labels/frames do not match the batch size")
+        if labels.shape[0] != B:
+            raise ValueError("labels/frames do not match the batch size")
+        lab_ptr = labels.ctypes.data
+    fr_ptr, fr_keep = _frames_ptr(frames, B)
     if alpha > 0.0:
         np.random.seed(step)                      # global stream, as the reference
-        lam32 = np.float32(np.random.beta(alpha, alpha))
+        lam = np.random.beta(alpha, alpha)        # c_float rounds like np.float32 (:903)
     else:
-        lam32 = np.float32(1.0)
-    knots = None
+        lam = 1.0
+    knots = knots_ptr = None
     if n_knots:
         knots = np.random.normal(loc=1.0, scale=sigma, size=(B, n_knots, C))
-    lib = _lib.load()
-    nbytes = lib.pcgmix_splice_staging_bytes(B, C, n_knots)
+        knots_ptr = knots.ctypes.data
+    if out is None:
+        out = torch.empty_like(data)
+    elif out.shape != data.shape or out.dtype != data.dtype or not out.is_contiguous() \
+            or out.data_ptr() == data.data_ptr():
+        raise ValueError("out must be a distinct contiguous tensor shaped like data")
     mix = np.empty(B, dtype=np.int64)
-    with torch.cuda.device(device):
-        op_ptr = spline_operator(device, T, n_knots).data_ptr() if n_knots else None
-        ring = _RINGS.setdefault(device.index, _StagingRing())
-        slot, pinned = ring.stage(nbytes)
-        dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        if out is None:
-            out = torch.empty_like(data)
-        elif out.shape != data.shape or out.dtype != data.dtype or not out.is_contiguous() \
-                or out.data_ptr() == data.data_ptr():
-            raise ValueError("out must be a distinct contiguous tensor shaped like data")
-        stream = torch.cuda.current_stream(device)
-        knots_ptr = knots.ctypes.data if knots is not None else None
-        if ohe is not None:
-            key = (device.index, torch.int64)
-            lab = _LABEL_PINNED.get(key)
-            if lab is None or lab.numel() < ohe.numel():
-                lab = _LABEL_PINNED[key] = torch.empty(max(4096, ohe.numel()), dtype=torch.int64,
-                                                       pin_memory=True)
-            err = lib.pcgmix_splice_same_label_ohe_f32(
-                data.data_ptr(), out.data_ptr(), ohe.data_ptr(), ohe.shape[1], lab.data_ptr(),
-                frames.ctypes.data, step, ctypes.c_float(lam32), knots_ptr, op_ptr, n_knots,
-                pinned.data_ptr(), dev.data_ptr(), mix.ctypes.data, B, C, T,
-                ctypes.c_void_p(stream.cuda_stream))
-        else:
-            err = lib.pcgmix_splice_same_label_f32(
-                data.data_ptr(), out.data_ptr(), labels.ctypes.data, frames.ctypes.data, step,
-                ctypes.c_float(lam32), knots_ptr, op_ptr, n_knots, pinned.data_ptr(),
-                dev.data_ptr(), mix.ctypes.data, B, C, T, ctypes.c_void_p(stream.cuda_stream))
+    stream = _get_raw_stream(idx) if _get_raw_stream is not None \
+        else torch.cuda.current_stream(data.device).cuda_stream
+    err = _lib.load().pcgmix_augment_plain_f32(
+        _CTX.get(idx) or step_context(idx), data.data_ptr(), out.data_ptr(), ohe_ptr, n_cls, lab_ptr,
+        fr_ptr, step, _c_float(lam), knots_ptr, n_knots, mix.ctypes.data, B, C, T, stream)
+    if err:
         if err < 0:
-            raise ValueError(_SPLICE_ERRORS.get(err, f"pcgmix_splice_same_label_f32 error {err}"))
-        _lib.check(err, "pcgmix_splice_same_label_f32")
-        ring.sent(slot, stream)
+            raise ValueError(_SPLICE_ERRORS.get(err, f"pcgmix_augment_plain_f32 error {err}"))
+        _lib.check(err, "pcgmix_augment_plain_f32")
     return out, mix
+
+
+def gate_passes(recipe, method: str, step: int, index: int) -> bool:
+    """Probability gate of a plain method: ``Random(step).uniform(0,1) < p`` (augmentations.py:
+    869-872), drawn in the step context so that the fired step reuses the seeded generator."""
+    if recipe[1] >= 1.0:
+        return True
+    return _lib.load().pcgmix_ctx_gate(_CTX.get(index) or step_context(index), step) < recipe[1]
 
 
 def blend_targets(target_ohe: torch.Tensor, plan: MixPlan) -> torch.Tensor:
@@ -346,17 +373,21 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
     augmentations.py:501); results are identical."""
     method = args.method
     step = int(step_counter.count)
-    if hostprep.select_method(method, is2d=False) is None:
+    recipe = _RECIPES.get(method, _RECIPES)
+    if recipe is _RECIPES:                        # first sight of this method string
+        recipe = hostprep.plain_recipe(method, False) \
+            if hostprep.select_method(method, is2d=False) is not None else False
+        _RECIPES[method] = recipe
+    if recipe is False:                           # not one of ours: passthrough (:731-732)
         return data, target_ohe, [], None
     _check_data(data, 3)
     B, C, T = data.shape
-    frames_np = _as_numpy_frames(frames)
-    recipe = hostprep.plain_recipe(method, False)
     if recipe is not None and B > 0:              # the common case: one library call
-        if recipe[1] < 1.0 and not hostprep.gate_fires(method, step):
+        if not gate_passes(recipe, method, step, data.device.index):
             return data, target_ohe, [], None
-        out, mix = splice_plain(recipe, data, host_labels, frames_np, step, target_ohe=target_ohe)
+        out, mix = splice_plain(recipe, data, host_labels, frames, step, target_ohe=target_ohe)
         return out, target_ohe, mix, None
+    frames_np = _as_numpy_frames(frames)
     labels = (lambda: labels_from_ohe(target_ohe)) if host_labels is None else np.asarray(host_labels)
     sal = None
     if "(salopt" in method and B > 0:

@@ -14,8 +14,8 @@ applied to every frequency row, so the same kernel runs with C = F rows and T = 
 from __future__ import annotations
 
 from . import hostprep
-from .augmentations import (_as_numpy_frames, _check_data, apply_plan, labels_from_ohe,
-                            splice_plain)
+from .augmentations import (_as_numpy_frames, _check_data, apply_plan, gate_passes,
+                            labels_from_ohe, splice_plain)
 
 
 def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RESULTS_ARGS,
@@ -28,14 +28,14 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
         raise NotImplementedError("saliency-guided mixing of spectrograms is out of scope")
     _check_data(data, 4)
     B, Cc, F, W = data.shape
-    frames_np = _as_numpy_frames(frames)
     recipe = hostprep.plain_recipe(method, True)
     if recipe is not None and B > 0:              # durratiomixup: one library call
-        if recipe[1] < 1.0 and not hostprep.gate_fires(method, step):
+        if not gate_passes(recipe, method, step, data.device.index):
             return data, target_ohe, [], None
-        out, mix = splice_plain(recipe, data.view(B, Cc * F, W), host_labels, frames_np, step,
+        out, mix = splice_plain(recipe, data.view(B, Cc * F, W), host_labels, frames, step,
                                 target_ohe=target_ohe)
         return out.view(B, Cc, F, W), target_ohe, mix, None
+    frames_np = _as_numpy_frames(frames)
     labels = (lambda: labels_from_ohe(target_ohe)) if host_labels is None else host_labels
     plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, Cc * F, is2d=True, n_cols=W)
     if not plan.fired:

@@ -1,8 +1,15 @@
-// pcgmix_host.hip — host-only entry points of libpcgmix_hip.so (no device code).
+// pcgmix_host.hip — host-side entry points of libpcgmix_hip.so: the reference's host RNG streams
+// restated in C, plan packing, and the per-device step context (pinned staging ring, device
+// scratch ring, label read-back) behind pcgmix_augment_plain_f32.  The only device code here is
+// the one-block label arg-max that feeds the read-back.
 #include <hip/hip_runtime.h>
+#include <immintrin.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "pcgmix_kernels.h"
@@ -367,4 +374,289 @@ extern "C" long long pcgmix_splice_staging_bytes(int B, int C, int n_knots) {
   if (B < 0 || C < 0 || n_knots < 0) return 0;
   const long long n_int_pad = ((long long)B * 6 + 1) & ~1ll;
   return n_int_pad * 4 + (long long)B * n_knots * C * 8;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Per-device step context.  Everything the per-step prologue of a plain PCGmix method needs
+// besides the batch itself lives here, allocated once: a ring of pinned staging buffers with
+// their device twins and one event per slot (a slot is reused only after the kernel that read
+// its device twin has finished), host-mapped memory for the label read-back, and the constant
+// spline operators per (T, n_knots).  One context per device and host thread; not thread-safe.
+namespace {
+
+constexpr int kSlots = 8;
+
+struct Slot {
+  char* pinned = nullptr;
+  char* dev = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;
+  bool busy = false;
+};
+
+// Class labels from a one-hot (B, K) int64 matrix: first maximum per row (torch.max / np.argmax
+// semantics, augmentations.py:501), written to host-mapped memory, then a system-scope release
+// of `token` into the flag word the host spins on.  One block: B is a few hundred.
+__global__ __launch_bounds__(256) void label_argmax_kernel(const int64_t* __restrict__ ohe, int K,
+                                                           int B, int32_t* __restrict__ lab,
+                                                           uint32_t* flag, uint32_t token) {
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int64_t* row = ohe + (size_t)b * K;
+    int best = 0;
+    int64_t bv = row[0];
+    for (int c = 1; c < K; ++c) {
+      const int64_t v = row[c];
+      if (v > bv) { bv = v; best = c; }
+    }
+    lab[b] = best;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+}  // namespace
+
+struct pcgmix_ctx {
+  int device = 0;
+  Slot slot[kSlots];
+  int next = 0;
+  int32_t* lab = nullptr;          // host-mapped, coherent
+  size_t lab_cap = 0;
+  uint32_t* flag = nullptr;        // host-mapped, coherent
+  uint32_t token = 0;
+  std::map<std::pair<int, int>, double*> ops;   // (T, n_knots) -> device operator
+  uint64_t gate_step = ~0ull;      // generator seeded for this step (pcgmix_ctx_gate), reusable
+  PyRandom* seeded = nullptr;
+};
+
+extern "C" int pcgmix_ctx_create(int device, pcgmix_ctx** out) {
+  if (!out) return hipErrorInvalidValue;
+  int prev = 0;
+  hipError_t e = hipGetDevice(&prev);
+  if (e != hipSuccess) return (int)e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return (int)e;
+  pcgmix_ctx* c = new pcgmix_ctx();
+  c->device = device;
+  c->seeded = static_cast<PyRandom*>(::operator new(sizeof(PyRandom)));
+  e = hipHostMalloc(reinterpret_cast<void**>(&c->flag), 64, hipHostMallocMapped | hipHostMallocCoherent);
+  if (e == hipSuccess) {
+    *c->flag = 0;
+    for (int i = 0; i < kSlots && e == hipSuccess; ++i)
+      e = hipEventCreateWithFlags(&c->slot[i].ev, hipEventDisableTiming);
+  }
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) { delete c; return (int)e; }
+  *out = c;
+  return hipSuccess;
+}
+
+extern "C" void pcgmix_ctx_destroy(pcgmix_ctx* c) {
+  if (!c) return;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (auto& s : c->slot) {
+    if (s.pinned) (void)hipHostFree(s.pinned);
+    if (s.dev) (void)hipFree(s.dev);
+    if (s.ev) (void)hipEventDestroy(s.ev);
+  }
+  if (c->lab) (void)hipHostFree(c->lab);
+  if (c->flag) (void)hipHostFree(c->flag);
+  for (auto& kv : c->ops) (void)hipFree(kv.second);
+  ::operator delete(c->seeded);
+  (void)hipSetDevice(prev);
+  delete c;
+}
+
+// random.Random(step).uniform(0, 1) with the seeded generator kept in the context, so that the
+// step call that follows a passed gate does not initialise MT19937 a second time.
+extern "C" double pcgmix_ctx_gate(pcgmix_ctx* c, uint64_t step) {
+  if (!c) return 2.0;
+  new (c->seeded) PyRandom(step);
+  c->gate_step = step;
+  PyRandom r = *c->seeded;
+  return 0.0 + (1.0 - 0.0) * r.random();
+}
+
+namespace {
+
+hipError_t slot_reserve(Slot& s, size_t nbytes) {
+  if (s.busy) {                               // the kernel that read this slot must be done
+    hipError_t e = hipEventSynchronize(s.ev);
+    if (e != hipSuccess) return e;
+    s.busy = false;
+  }
+  if (s.cap >= nbytes) return hipSuccess;
+  size_t cap = 8192;
+  while (cap < nbytes) cap <<= 1;
+  if (s.pinned) (void)hipHostFree(s.pinned);
+  if (s.dev) (void)hipFree(s.dev);
+  s.pinned = s.dev = nullptr;
+  s.cap = 0;
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&s.pinned), cap, hipHostMallocDefault);
+  if (e != hipSuccess) return e;
+  if ((e = hipMalloc(reinterpret_cast<void**>(&s.dev), cap)) != hipSuccess) return e;
+  s.cap = cap;
+  return hipSuccess;
+}
+
+hipError_t spline_op_device(pcgmix_ctx* c, int T, int n_knots, const double** out) {
+  auto it = c->ops.find({T, n_knots});
+  if (it != c->ops.end()) { *out = it->second; return hipSuccess; }
+  const int n = pcgmix_spline_operator_size(n_knots);
+  std::vector<double> host((size_t)n);
+  int err = pcgmix_spline_operator_f64(T, n_knots, host.data());
+  if (err) return (hipError_t)err;
+  double* d = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), sizeof(double) * n);
+  if (e != hipSuccess) return e;
+  if ((e = hipMemcpy(d, host.data(), sizeof(double) * n, hipMemcpyHostToDevice)) != hipSuccess) {
+    (void)hipFree(d);
+    return e;
+  }
+  c->ops[{T, n_knots}] = d;
+  *out = d;
+  return hipSuccess;
+}
+
+}  // namespace
+
+extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
+                                        const int64_t* target_ohe_dev, int num_classes,
+                                        const int64_t* labels_host, const int64_t* frames,
+                                        uint64_t step, float lam, const double* knots,
+                                        int n_knots, int64_t* mix_out, int B, int C, int T,
+                                        pcgmix_stream_t stream) {
+  if (!c || !x || !y || !frames || !mix_out || B <= 0 || C <= 0 || T <= 0 ||
+      (!target_ohe_dev && !labels_host) || (target_ohe_dev && num_classes <= 0) ||
+      (knots && n_knots < 2))
+    return hipErrorInvalidValue;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int cur = 0;
+  hipError_t e = hipGetDevice(&cur);
+  if (e != hipSuccess) return (int)e;
+  if (cur != c->device && (e = hipSetDevice(c->device)) != hipSuccess) return (int)e;
+  struct Restore {
+    int cur, dev;
+    ~Restore() { if (cur != dev) (void)hipSetDevice(cur); }
+  } restore{cur, c->device};
+
+  // 1. start the label read-back first: everything below up to step 4 does not need the labels
+  //    and runs while the GPU finishes what precedes this call on `stream`
+  const bool readback = labels_host == nullptr;
+  if (readback) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+      return hipErrorStreamCaptureUnsupported;     // a host wait cannot be captured
+    if (c->lab_cap < (size_t)B) {
+      if (c->lab) (void)hipHostFree(c->lab);
+      c->lab = nullptr;
+      c->lab_cap = 0;
+      size_t cap = 1024;
+      while (cap < (size_t)B) cap <<= 1;
+      e = hipHostMalloc(reinterpret_cast<void**>(&c->lab), cap * sizeof(int32_t),
+                        hipHostMallocMapped | hipHostMallocCoherent);
+      if (e != hipSuccess) return (int)e;
+      c->lab_cap = cap;
+    }
+    ++c->token;
+    if (c->token == 0) c->token = 1;
+    hipLaunchKernelGGL(label_argmax_kernel, dim3(1), dim3(256), 0, s, target_ohe_dev, num_classes,
+                       B, c->lab, c->flag, c->token);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  }
+
+  // 2. staging slot, boundaries validated and packed, knots copied, generator seeded
+  const size_t n_int = (size_t)B * 6, n_int_pad = (n_int + 1) & ~(size_t)1;
+  const size_t nk = knots ? (size_t)B * n_knots * C : 0;
+  const size_t nbytes = n_int_pad * 4 + nk * sizeof(double);
+  Slot& sl = c->slot[c->next];
+  c->next = (c->next + 1) % kSlots;
+  if ((e = slot_reserve(sl, nbytes)) != hipSuccess) return (int)e;
+  int32_t* st = reinterpret_cast<int32_t*>(sl.pinned);
+  int bad = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t* r = frames + (size_t)b * 5;
+    if (r[0] < 0) bad = bad ? bad : -1;
+    for (int k = 0; k < 4; ++k)
+      if (r[k + 1] < r[k]) bad = bad ? bad : -1;
+    if (r[4] > T) bad = bad ? bad : -2;
+    for (int k = 0; k < 5; ++k) st[b * 5 + k] = (int32_t)r[k];
+  }
+  const double* op_dev = nullptr;
+  const double* knots_dev = nullptr;
+  if (knots) {
+    if ((e = spline_op_device(c, T, n_knots, &op_dev)) != hipSuccess) return (int)e;
+    std::memcpy(sl.pinned + n_int_pad * 4, knots, nk * sizeof(double));
+    knots_dev = reinterpret_cast<const double*>(sl.dev + n_int_pad * 4);
+  }
+  if (c->gate_step != step) {
+    new (c->seeded) PyRandom(step);
+    c->gate_step = step;
+  }
+
+  // 3. wait for the labels (the one host wait the reference's signature forces,
+  //    augmentations.py:501): spin on the flag word the kernel releases; if it does not show up
+  //    within 2 ms fall back to a stream synchronisation
+  std::vector<int64_t> lab64;
+  const int64_t* labels = labels_host;
+  if (readback) {
+    const uint32_t want = c->token;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(c->flag, __ATOMIC_ACQUIRE) != want) {
+      _mm_pause();
+      if ((++spins & 1023u) == 0 &&
+          std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return (int)e;
+        if (__atomic_load_n(c->flag, __ATOMIC_ACQUIRE) != want) return hipErrorUnknown;
+      }
+    }
+    lab64.resize((size_t)B);
+    for (int b = 0; b < B; ++b) lab64[(size_t)b] = c->lab[b];
+    labels = lab64.data();
+  }
+  if (bad) return bad;                       // malformed boundaries: nothing else is enqueued
+
+  // 4. groups of equal label in order of first appearance (augmentations.py:500-510), each
+  //    permuted by a fresh Random(step).sample: one initialisation, state copied per group
+  std::vector<int64_t> keys;
+  std::vector<std::vector<int64_t>> members;
+  for (int b = 0; b < B; ++b) {
+    size_t g = 0;
+    while (g < keys.size() && keys[g] != labels[b]) ++g;
+    if (g == keys.size()) {
+      keys.push_back(labels[b]);
+      members.emplace_back();
+    }
+    members[g].push_back(b);
+  }
+  std::vector<int64_t> pool;
+  int32_t* mixp = st + (size_t)B * 5;
+  for (const auto& idx : members) {
+    const size_t n = idx.size();
+    PyRandom rng = *c->seeded;
+    pool = idx;
+    for (size_t i = 0; i < n; ++i) {                 // sample(population, k = n): pool branch
+      const uint64_t j = rng.randbelow((uint64_t)(n - i));
+      mix_out[idx[i]] = pool[j];
+      mixp[idx[i]] = (int32_t)pool[j];
+      pool[j] = pool[n - i - 1];
+    }
+  }
+
+  // 5. one H2D copy, the launch, the slot's event behind it
+  if ((e = hipMemcpyAsync(sl.dev, sl.pinned, nbytes, hipMemcpyHostToDevice, s)) != hipSuccess)
+    return (int)e;
+  const int32_t* d = reinterpret_cast<const int32_t*>(sl.dev);
+  const int err = pcgmix_mix_warp_f32(x, y, d, d + (size_t)B * 5, nullptr, lam, knots_dev, op_dev,
+                                      knots ? n_knots : 0, nullptr, B, C, T, stream);
+  if (err) return err;
+  if ((e = hipEventRecord(sl.ev, s)) != hipSuccess) return (int)e;
+  sl.busy = true;
+  return hipSuccess;
 }

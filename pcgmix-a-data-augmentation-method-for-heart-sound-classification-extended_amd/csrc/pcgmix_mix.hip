@@ -281,7 +281,30 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
   }
 }
 
+// Elements of one sample's plane per block: 1024 * U.  Fatter blocks amortise the block
+// prologue (dependent index loads, spline records) and keep more loads in flight per lane;
+// thinner ones waste fewer lanes on the last chunk of a short plane.  Chosen from measurements
+// on MI355X ("Block shape"); PCGMIX_MIX_UNROLL overrides it for tuning runs.
+static int choose_unroll(long long B, long long plane, bool warp) {
+  int U = plane >= 8192 ? 2 : 1;
+  if (warp && plane >= 16384 && B * plane >= (64LL << 20)) U = 4;
+  if (const char* env = getenv("PCGMIX_MIX_UNROLL")) {
+    const int v = atoi(env);
+    if (v == 1 || v == 2 || v == 4) U = v;
+  }
+  return U;
+}
+
 }  // namespace pcgmix
+
+extern "C" int pcgmix_mix_variant(int B, int C, int T, int warp, int aligned16, int* vec,
+                                  int* unroll) {
+  if (B < 0 || C <= 0 || T <= 0 || !vec || !unroll) return hipErrorInvalidValue;
+  const bool vec4 = (T % 4 == 0) && aligned16;
+  *vec = vec4 ? 4 : 1;
+  *unroll = vec4 ? pcgmix::choose_unroll(B, (long long)C * T, warp != 0) : 1;
+  return hipSuccess;
+}
 
 extern "C" int pcgmix_mix_warp_f32(const float* x, float* y, const int32_t* frames,
                                    const int32_t* mix_idx, const int32_t* off, float lam,
@@ -299,16 +322,7 @@ extern "C" int pcgmix_mix_warp_f32(const float* x, float* y, const int32_t* fram
 
   const bool vec4 = (T % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-  // Elements of one sample's plane per block: 1024 * U.  Fatter blocks amortise the block
-  // prologue (dependent index loads, spline records) and keep more loads in flight per lane;
-  // thinner ones waste fewer lanes on the last chunk of a short plane.  Chosen from measurements
-  // on MI355X ("Block shape"); PCGMIX_MIX_UNROLL overrides it for tuning runs.
-  int U = plane >= 8192 ? 2 : 1;
-  if (warp && plane >= 16384 && (long long)B * plane >= (64LL << 20)) U = 4;
-  if (const char* env = getenv("PCGMIX_MIX_UNROLL")) {
-    const int v = atoi(env);
-    if (v == 1 || v == 2 || v == 4) U = v;
-  }
+  const int U = choose_unroll(B, plane, warp);
   const int epb = kThreads * 4 * U;
   const unsigned chunks = (unsigned)((plane + epb - 1) / epb);
   size_t lds = 0;

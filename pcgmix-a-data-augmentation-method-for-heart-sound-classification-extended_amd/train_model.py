@@ -425,7 +425,7 @@ class GraphedTrainStep:
         step = int(step_counter.count)
         recipe = hostprep.plain_recipe(args.method, False)
         if recipe is not None and B > 0:                # plain splice: one library call
-            fired = recipe[1] >= 1.0 or hostprep.gate_fires(args.method, step)
+            fired = augmentations.gate_passes(recipe, args.method, step, data.device.index)
             plan = hostprep.MixPlan(fired=False)
             if fired:
                 augmentations.splice_plain(recipe, data, target.numpy(), frames_np, step, out=self.x)
