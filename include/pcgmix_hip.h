@@ -176,10 +176,23 @@ int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames, const int32_
  * Log-mel front end.                                                    [host tables + device]
  *
  * Replaces the offline librosa pipeline of databuilder.ipynb cell 6:19-23, 81-101, 127-142
- * (melspectrogram -> power_to_db(ref=max) -> (x-mean)/std -> crop to the cycle -> zero-pad
- * to W columns) per heart cycle, on device.  librosa 0.9.2 semantics restated (centred frames
- * with reflect padding, periodic Hann of n_fft, float64 transform, power 2, Slaney mel scale and
- * normalisation, amin 1e-10, top_db 80); parity with librosa itself is unpinned.
+ * (melspectrogram -> power_to_db(ref=np.max) -> (x-mean)/std -> slice the cycle's columns ->
+ * zero-pad to W columns), on device.  librosa 0.9.2 semantics restated (centred frames, periodic
+ * Hann of n_fft, float64 transform rounded to complex64, power 2, Slaney mel scale and
+ * normalisation, amin 1e-10, top_db 80); parity with librosa itself is UNPINNED (librosa is not
+ * available offline and the reference stores no spectrogram).  One point of that restatement is
+ * open and therefore a parameter: `pad_mode` of the centred frames, 0 = zeros (numpy 'constant')
+ * or 1 = 'reflect'.
+ *
+ * Two granularities:
+ *   pcgmix_logmel_f32             one transform per heart-cycle item of a batch; `ref` is the
+ *                                 item's own maximum (what a per-batch transform of cut cycles
+ *                                 can see).
+ *   pcgmix_logmel_recordings_f32  the reference's order of operations: ONE transform over each
+ *                                 whole recording, `ref` = the recording's maximum (cell 6:93),
+ *                                 then cycle c keeps the recording's columns
+ *                                 [round(f0*n_frames/len(y)), round(f4*n_frames/len(y)))
+ *                                 (cell 6:101, 134), zero-padded to W after normalisation.
  *
  * pcgmix_logmel_tables builds, on the host, everything that does not depend on the data: the
  * windowed DFT matrix in matrix-core operand order, the mel filter bank and each filter's
@@ -197,7 +210,32 @@ long long pcgmix_logmel_tables_size(int n_fft, int n_mels);
 int pcgmix_logmel_tables(int n_fft, int n_mels, float fmin, float fmax, float sr, void* out /* host */);
 int pcgmix_logmel_f32(const float* x, const int32_t* frames, const void* tables, float* spec,
                       int32_t* frames_out, int B, int T, int n_fft, int hop, int n_mels,
-                      float mean, float std, int W, pcgmix_stream_t stream);
+                      float mean, float std, int W, int pad_mode, pcgmix_stream_t stream);
+
+/* Per-recording front end.  All pointers device.  The column bookkeeping (which is integer work
+ * on a handful of numbers per cycle: n_frames = 1 + len/hop, Python round()) is the caller's; the
+ * kernels take it as descriptor tables:
+ *   y            recordings back to back, float32
+ *   rec_off      int64 (R): first sample of recording r in y;  rec_len int32 (R): its length
+ *   tiles        int32 (n_tiles, 4): {recording, first frame, frames in this tile
+ *                (<= pcgmix_logmel_tile_frames()), absolute scratch column of that first frame};
+ *                the tiles of a recording cover its frames 0 .. n_frames-1 once
+ *   cycles       int32 (n_cycles, 4): {recording, absolute scratch column of the cycle's first
+ *                column, number of columns kept (clipped to W), 0}
+ *   db_scratch   float32 (n_mels, scratch_cols) workspace: un-referenced dB of every frame
+ *   ref_pow      uint32 (R) workspace: bit pattern of the recording's maximum mel power
+ *   spec         float32 (n_cycles, n_mels, W) out
+ * Three launches: zero ref_pow; transform + mel + dB per tile (f64 matrix cores), maximum folded
+ * in with an unsigned atomicMax (non-negative floats order like their bit patterns: the result is
+ * order-independent); slice / reference / clip / normalise / pad per cycle.
+ */
+int pcgmix_logmel_tile_frames(void);
+int pcgmix_logmel_recordings_f32(const float* y, const int64_t* rec_off, const int32_t* rec_len,
+                                 int R, const int32_t* tiles, int n_tiles, const int32_t* cycles,
+                                 int n_cycles, const void* tables, float* db_scratch,
+                                 long long scratch_cols, uint32_t* ref_pow, float* spec, int n_fft,
+                                 int hop, int n_mels, float mean, float std, int W, int pad_mode,
+                                 pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Potes 1D-CNN convolutional branch, fused.                                         [device]

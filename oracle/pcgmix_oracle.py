@@ -394,26 +394,46 @@ def mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
     return weights
 
 
+def _mel_db(y: np.ndarray, n_fft, hop, basis, pad_mode):
+    """librosa.feature.melspectrogram(center=True, power=2) of one signal followed by the
+    un-referenced part of power_to_db: returns (mel power (n_mels, n_frames) float32, 10*log10(
+    max(amin, .)) of it).  ``pad_mode``: numpy.pad mode of the centred frames ('constant' or
+    'reflect'; which one librosa 0.9.2 defaults to is the open point of this restatement)."""
+    n_frames = 1 + len(y) // hop
+    n = np.arange(n_fft)
+    window = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)
+    yp = np.pad(y, n_fft // 2, mode=pad_mode)
+    idx = np.arange(n_fft)[:, None] + hop * np.arange(n_frames)[None, :]
+    S = np.fft.rfft(window[:, None] * yp[idx], axis=0).astype(np.complex64)
+    P = np.abs(S) ** 2.0
+    mel = np.einsum("ft,mf->mt", P, basis, optimize=True)
+    return mel, 10.0 * np.log10(np.maximum(1e-10, mel))
+
+
+def stft_complex(y: np.ndarray, n_fft=136, hop=34, pad_mode="constant") -> np.ndarray:
+    """The STFT stage alone, float64 (before librosa's complex64 rounding): cross-checked against
+    torch.stft in tests/test_oracle_golden.py for both pad modes."""
+    n_frames = 1 + len(y) // hop
+    n = np.arange(n_fft)
+    window = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)
+    yp = np.pad(y.astype(np.float64), n_fft // 2, mode=pad_mode)
+    idx = np.arange(n_fft)[:, None] + hop * np.arange(n_frames)[None, :]
+    return np.fft.rfft(window[:, None] * yp[idx], axis=0)
+
+
 def logmel(x: np.ndarray, frames: np.ndarray, n_fft=136, hop=34, n_mels=128, fmin=25.0,
-           fmax=1000.0, sr=2000.0, mean=LOGMEL_MEAN, std=LOGMEL_STD, W=128):
+           fmax=1000.0, sr=2000.0, mean=LOGMEL_MEAN, std=LOGMEL_STD, W=128, pad_mode="constant"):
     """x (B,T) float32 heart cycles, frames (B,5) -> (spec (B,n_mels,W) float32, frames_spec).
-    Per item: centred STFT (reflect padding, periodic Hann, float64 FFT rounded to complex64),
-    power, Slaney mel, power_to_db(ref=np.max over THIS item, amin 1e-10, top_db 80),
+    Per item: centred STFT (``pad_mode`` padding, periodic Hann, float64 FFT rounded to
+    complex64), power, Slaney mel, power_to_db(ref=np.max over THIS item, amin 1e-10, top_db 80),
     (x-mean)/std, keep columns < round(f4*n_frames/T), zero-fill up to W."""
     B, T = x.shape
     n_frames = 1 + T // hop
-    n = np.arange(n_fft)
-    window = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)
     basis = mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
     out = np.zeros((B, n_mels, W), dtype=np.float32)
     fspec = np.zeros_like(frames)
     for b in range(B):
-        yp = np.pad(x[b], n_fft // 2, mode="reflect")
-        idx = np.arange(n_fft)[:, None] + hop * np.arange(n_frames)[None, :]
-        S = np.fft.rfft(window[:, None] * yp[idx], axis=0).astype(np.complex64)
-        P = np.abs(S) ** 2.0
-        mel = np.einsum("ft,mf->mt", P, basis, optimize=True)
-        db = 10.0 * np.log10(np.maximum(1e-10, mel))
+        mel, db = _mel_db(x[b], n_fft, hop, basis, pad_mode)
         db -= 10.0 * np.log10(np.maximum(1e-10, np.max(mel)))
         db = np.maximum(db, db.max() - 80.0)
         db = ((db - mean) / std).astype(np.float32)
@@ -421,3 +441,27 @@ def logmel(x: np.ndarray, frames: np.ndarray, n_fft=136, hop=34, n_mels=128, fmi
         c4 = min(int(fspec[b, 4]), W)
         out[b, :, :c4] = db[:, :c4]
     return out, fspec
+
+
+def logmel_recording(y: np.ndarray, boundaries, seg_starts, n_fft=136, hop=34, n_mels=128,
+                     fmin=25.0, fmax=1000.0, sr=2000.0, mean=LOGMEL_MEAN, std=LOGMEL_STD, W=128,
+                     pad_mode="constant"):
+    """databuilder.ipynb cell 6:81-101, 127-142 for ONE recording y: mel spectrogram of the whole
+    recording, power_to_db(ref=np.max) over the whole recording (:93), (x-mean)/std (:99), column
+    boundaries round(f*n_frames/len(y)) (:101); per cycle starting at boundary index i: columns
+    [fs[i], fs[i+4]) (:134), zero-padded on the right to W columns (:141-142; a slice wider than
+    W is cut at W here — the reference would store the wider image).
+    Returns (specs (n_cycles, n_mels, W) float32, frames_spec (n_cycles, 5) cycle-relative)."""
+    basis = mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    mel, db = _mel_db(y, n_fft, hop, basis, pad_mode)
+    db -= 10.0 * np.log10(np.maximum(1e-10, np.max(mel)))
+    db = np.maximum(db, db.max() - 80.0)
+    db = ((db - mean) / std).astype(np.float32)
+    fs = [round(int(f) * db.shape[1] / len(y)) for f in boundaries]
+    specs = np.zeros((len(seg_starts), n_mels, W), dtype=np.float32)
+    rel = np.zeros((len(seg_starts), 5), dtype=np.int64)
+    for j, i in enumerate(seg_starts):
+        sl = db[:, fs[i]:fs[i + 4]][:, :W]
+        specs[j, :, :sl.shape[1]] = sl
+        rel[j] = np.asarray(fs[i:i + 5]) - fs[i]
+    return specs, rel

@@ -37,7 +37,11 @@ SIGNATURES = {
     "pcgmix_logmel_tables_size": (ctypes.c_longlong, [_c_int, _c_int]),
     "pcgmix_logmel_tables": (_c_int, [_c_int, _c_int, _c_float, _c_float, _c_float, _ptr]),
     "pcgmix_logmel_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
-                                   _c_int, _c_float, _c_float, _c_int, _ptr]),
+                                   _c_int, _c_float, _c_float, _c_int, _c_int, _ptr]),
+    "pcgmix_logmel_tile_frames": (_c_int, []),
+    "pcgmix_logmel_recordings_f32": (_c_int, [_ptr, _ptr, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr,
+                                              _ptr, ctypes.c_longlong, _ptr, _ptr, _c_int, _c_int,
+                                              _c_int, _c_float, _c_float, _c_int, _c_int, _ptr]),
     "pcgmix_potes_out_len": (_c_int, [_c_int]),
     "pcgmix_potes_bwd_blocks": (_c_int, [_c_int, _c_int]),
     "pcgmix_potes_stack_fwd_f32": (_c_int, [_ptr] * 6 + [_c_int, _c_int, _ptr]),

@@ -1,12 +1,18 @@
-// pcgmix_logmel.hip — per-cycle STFT -> log-mel front end on gfx950.
+// pcgmix_logmel.hip — STFT -> log-mel front end on gfx950.
 //
 // Replaces the offline librosa pipeline of databuilder.ipynb cell 6:81-101, 127-142
 // (melspectrogram(n_fft = 4*hop, hop, n_mels, fmin, fmax) -> power_to_db(ref=max) ->
 // (x - mean)/std -> keep the cycle's columns -> zero-pad to W), librosa 0.9.2 semantics restated:
-// centred frames with reflect padding, periodic Hann of n_fft, float64 transform rounded to
-// complex64, |.|^2 in float32, Slaney mel filter bank (float32 weights), float32 dB with
-// amin = 1e-10 and top_db = 80.  One difference is inherent to doing this per batch item: `ref`
-// is the maximum over the item's own spectrogram, not over the whole recording.
+// centred frames (edge padding selectable: zeros = numpy 'constant', or 'reflect' — which of the
+// two librosa 0.9.2 defaults to could not be checked offline), periodic Hann of n_fft, float64
+// transform rounded to complex64, |.|^2 in float32, Slaney mel filter bank (float32 weights),
+// float32 dB with amin = 1e-10 and top_db = 80.
+// Two granularities:
+//   per cycle      (pcgmix_logmel_f32)  one STFT per heart-cycle item, `ref` = the item's own
+//                  maximum — what a per-batch transform of already cut cycles can see;
+//   per recording  (pcgmix_logmel_recordings_f32)  the reference's own order of operations: one
+//                  STFT over the WHOLE recording, `ref` = the recording's maximum, then every
+//                  cycle's columns are sliced out of it (cell 6:93, 101, 134) and zero-padded.
 //
 // The STFT is a GEMM and librosa evaluates it in float64 — so it runs on the f64 matrix cores
 // (v_mfma_f64_16x16x4_f64).  The input is real and the periodic Hann window is symmetric
@@ -67,32 +73,66 @@ struct MelLayout {  // byte offsets into dynamic LDS
   int xrow, ps, img, melw, total;
   int nfp, xr;
 };
-__host__ __device__ inline MelLayout mel_layout(int T, int n_fft, int hop, int n_mels, int W) {
+// n_frames = frames one block transforms: 1 + T/hop of a heart-cycle item, or the tile size of
+// the per-recording pass; img_rows = n_mels when the block keeps a dB image in LDS, 0 otherwise.
+__host__ __device__ inline MelLayout mel_layout(int n_frames, int n_fft, int hop, int n_mels,
+                                                int W, bool image = true) {
   const MelTables tb = mel_tables(n_fft, n_mels);
-  const int n_frames = 1 + T / hop;
   MelLayout L;
   L.nfp = ((n_frames + 16 * kNGroup - 1) / (16 * kNGroup)) * (16 * kNGroup);  // frames, padded
   L.xr = (L.nfp - 1) * hop + n_fft + 8;      // padded-row samples the GEMM may touch
-  if (L.xr < T + n_fft) L.xr = T + n_fft;
   L.xr = (L.xr + 3) & ~3;
   int o = 0;
   L.xrow = o; o += L.xr * 4;                    // reflect-padded waveform, zero beyond (float)
   L.ps = o;   o += tb.m_tiles * 16 * L.nfp * 4; // power spectrogram [bin][frame]        (float)
-  L.img = o;  o += n_mels * W * 4;              // dB image                              (float)
+  L.img = o;  o += (image ? n_mels * W : 0) * 4;  // dB image                            (float)
   L.melw = o; o += n_mels * 8 * 4;              // per band: klo, khi, 4 weights (+2 pad) (32 B)
   L.total = o;
   return L;
 }
 
+constexpr int kPadConstant = 0, kPadReflect = 1;
+constexpr int kTileFrames = 128;   // frames per block of the per-recording pass
+
+// RECORD = false: one block per heart-cycle item b of x (B, T); image to `spec`.
+// RECORD = true : one block per tile of a recording (`tiles[b]` = {recording, first frame, frames
+//                 in this tile, absolute scratch column of the first frame}); un-referenced dB
+//                 columns to the scratch `spec` (n_mels, scratch_cols), the tile's maximum mel
+//                 power folded into ref_pow[recording] (non-negative floats order like their bit
+//                 patterns, so an unsigned atomicMax is a float max).
+template <bool RECORD>
 __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ frames,
-    const unsigned char* __restrict__ tables, float* __restrict__ spec,
+    const long long* __restrict__ rec_off, const int32_t* __restrict__ rec_len,
+    const int4* __restrict__ tiles, const unsigned char* __restrict__ tables,
+    float* __restrict__ spec, unsigned* __restrict__ ref_pow, long long scratch_cols,
     int32_t* __restrict__ frames_out, int B, int T, int n_fft, int hop, int n_mels, float mean,
-    float stdv, int W) {
+    float stdv, int W, int pad_mode) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ float red[kMelWaves];
   const MelTables tb = mel_tables(n_fft, n_mels);
-  const MelLayout L = mel_layout(T, n_fft, hop, n_mels, W);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_bins = tb.n_bins, pad = n_fft / 2;
+  // what this block transforms: `n_frames` centred frames of the signal xg[0..len), the first
+  // one centred on sample s0 + pad
+  const float* xg;
+  int len, s0, n_frames, rec = 0;
+  long long out_col = 0;
+  if (RECORD) {
+    const int4 tl = tiles[b];
+    rec = tl.x;
+    xg = x + rec_off[rec];
+    len = rec_len[rec];
+    s0 = tl.y * hop - pad;
+    n_frames = tl.z;
+    out_col = tl.w;
+  } else {
+    xg = x + (size_t)b * T;
+    len = T;
+    s0 = -pad;
+    n_frames = 1 + T / hop;  // centred: 1 + (T + 2*pad - n_fft) / hop
+  }
+  const MelLayout L = mel_layout(RECORD ? kTileFrames : n_frames, n_fft, hop, n_mels, W, !RECORD);
   const double* afrag = reinterpret_cast<const double*>(tables);
   const float* wts = reinterpret_cast<const float*>(tables + tb.off_wts);
   const int32_t* krange = reinterpret_cast<const int32_t*>(tables + tb.off_krange);
@@ -101,14 +141,6 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   float* img = reinterpret_cast<float*>(smem + L.img);
   float* melw = reinterpret_cast<float*>(smem + L.melw);
 
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_bins = tb.n_bins, pad = n_fft / 2;
-  const int n_frames = 1 + T / hop;  // centred: 1 + (T + 2*pad - n_fft) / hop
-
-  // reflect-padded row (numpy.pad mode='reflect': the edge sample is not repeated), zero beyond.
-  // The body is a straight coalesced copy (all loads independent, issued back to back); only the
-  // 2*pad edge samples take the mirrored index.
-  const float* xg = x + (size_t)b * T;
   // per-band filter span and its first 4 weights -> LDS (global latency overlaps the row copy)
   for (int m = tid; m < n_mels; m += kMelThreads) {
     const int klo = krange[2 * m], khi = krange[2 * m + 1];
@@ -118,16 +150,21 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
     for (int j = 0; j < 4; ++j)
       melw[8 * m + 2 + j] = (klo + j <= khi) ? wts[m * n_bins + klo + j] : 0.f;
   }
-  for (int i = tid; i < T; i += kMelThreads) xrow[pad + i] = xg[i];
-  for (int i = tid; i < pad; i += kMelThreads) {
-    int sl = pad - i;                       // left edge: index -(i - pad)
-    sl = sl >= T ? T - 1 : sl;
-    xrow[i] = xg[sl];
-    int sr = 2 * (T - 1) - (T + i);         // right edge: index T + i mirrored about T - 1
-    sr = sr < 0 ? 0 : sr;
-    xrow[pad + T + i] = xg[sr];
+  // The padded row: LDS index i holds signal sample s = s0 + i.  Outside [0, len): zero
+  // (numpy.pad 'constant') or the mirror image about the edge sample (numpy.pad 'reflect': the
+  // edge sample itself is not repeated).  Every load goes to a clamped in-range address and is
+  // unconditional (a predicated load would serialise the requests); the pad rule is a select.
+  // Samples that only frames beyond n_frames would touch are zero.
+  const int need = (n_frames - 1) * hop + n_fft;     // samples the valid frames touch
+  for (int i = tid; i < L.xr; i += kMelThreads) {
+    const int sidx = s0 + i;
+    int src = sidx < 0 ? -sidx : (sidx >= len ? 2 * (len - 1) - sidx : sidx);
+    src = src < 0 ? 0 : (src > len - 1 ? len - 1 : src);
+    float v = xg[src];
+    const bool inside = sidx >= 0 && sidx < len;
+    if (i >= need || (!inside && pad_mode == kPadConstant)) v = 0.f;
+    xrow[i] = v;
   }
-  for (int i = T + n_fft + tid; i < L.xr; i += kMelThreads) xrow[i] = 0.f;
   __syncthreads();
 
   // ---- STFT power on the f64 matrix cores -----------------------------------------------------
@@ -180,8 +217,9 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   }
   __syncthreads();
 
-  // ---- mel projection, dB, item maximum --------------------------------------------------------
-  float vmax = -INFINITY;  // max over the item of 10*log10(max(amin, S)), all n_frames columns
+  // ---- mel projection, dB, maximum ------------------------------------------------------------
+  float vmax = -INFINITY;  // cycle mode: max over the item of 10*log10(max(amin, S)), all columns
+  float pmax = 0.f;        // recording mode: max mel power of this tile's valid frames
   // wave -> mel band (its filter span and weights are wave-uniform, fetched once per band),
   // lane -> frame: the power-spectrogram reads and the image writes are unit-stride in LDS
   for (int m = wave; m < n_mels; m += kMelWaves) {
@@ -203,9 +241,26 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
         for (int k = klo; k <= khi; ++k) accm = fmaf(wts[m * n_bins + k], ps[k * L.nfp + t], accm);
       }
       const float db = 10.0f * log10f(fmaxf(1e-10f, accm));  // power_to_db, amin = 1e-10
-      vmax = fmaxf(vmax, db);
-      if (t < W) img[m * W + t] = db;
+      if (RECORD) {
+        pmax = fmaxf(pmax, accm);
+        spec[(size_t)m * scratch_cols + out_col + t] = db;    // 256-byte runs per wave
+      } else {
+        vmax = fmaxf(vmax, db);
+        if (t < W) img[m * W + t] = db;
+      }
     }
+  }
+  if (RECORD) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, o, 64));
+    if (lane == 0) red[wave] = pmax;
+    __syncthreads();
+    if (tid == 0) {
+      float p = red[0];
+      for (int i = 1; i < kMelWaves; ++i) p = fmaxf(p, red[i]);
+      atomicMax(ref_pow + rec, __float_as_uint(p));
+    }
+    return;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
@@ -248,6 +303,32 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
       if (t < col_end) v = (fmaxf(img[i] - ref_db, floor_db) - mean) / inv_guard;
       out[i] = v;
     }
+  }
+}
+
+__global__ void zero_u32_kernel(unsigned* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
+// Second pass of the per-recording front end: cycle c keeps columns [col0, col0 + n) of its
+// recording's dB spectrogram (cell 6:134), referenced to the recording's maximum, clipped at
+// -80 dB (power_to_db top_db), normalised, zero-padded to W columns after normalisation
+// (cell 6:99, 141-142).  cycles[c] = {recording, absolute scratch column, n columns, unused}.
+__global__ __launch_bounds__(256) void logmel_slice_kernel(
+    const float* __restrict__ db, long long scratch_cols, const unsigned* __restrict__ ref_pow,
+    const int4* __restrict__ cycles, float* __restrict__ spec, int n_mels, float mean, float stdv,
+    int W) {
+  const int4 cy = cycles[blockIdx.x];
+  const float ref_db = 10.0f * log10f(fmaxf(1e-10f, __uint_as_float(ref_pow[cy.x])));
+  const float floor_db = (ref_db - ref_db) - 80.0f;
+  const int n = cy.z < 0 ? 0 : (cy.z > W ? W : cy.z);
+  float* out = spec + (size_t)blockIdx.x * n_mels * W;
+  for (int i = threadIdx.x; i < n_mels * W; i += blockDim.x) {
+    const int m = i / W, t = i - m * W;
+    float v = 0.f;
+    if (t < n) v = (fmaxf(db[(size_t)m * scratch_cols + cy.y + t] - ref_db, floor_db) - mean) / stdv;
+    out[i] = v;
   }
 }
 
@@ -333,23 +414,59 @@ extern "C" int pcgmix_logmel_tables(int n_fft, int n_mels, float fmin, float fma
 
 extern "C" int pcgmix_logmel_f32(const float* x, const int32_t* frames, const void* tables,
                                  float* spec, int32_t* frames_out, int B, int T, int n_fft,
-                                 int hop, int n_mels, float mean, float std, int W,
+                                 int hop, int n_mels, float mean, float std, int W, int pad_mode,
                                  pcgmix_stream_t stream) {
   using namespace pcgmix;
   if (!x || !frames || !tables || !spec) return hipErrorInvalidValue;
   if (B < 0 || T < 2 || n_fft < 2 || (n_fft & 1) || hop < 1 || n_mels < 1 || W < 1 ||
-      !(std != 0.f) || n_fft / 2 >= T)
+      !(std != 0.f) || n_fft / 2 >= T || (pad_mode != kPadConstant && pad_mode != kPadReflect))
     return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
-  const MelLayout L = mel_layout(T, n_fft, hop, n_mels, W);
+  const MelLayout L = mel_layout(1 + T / hop, n_fft, hop, n_mels, W);
   if (L.total > 158 * 1024) return hipErrorInvalidValue;
   static unsigned long long lds_ok = 0;
-  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(logmel_kernel), &lds_ok,
+  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(logmel_kernel<false>), &lds_ok,
                                      158 * 1024))
     return (int)e;
-  hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)B), dim3(kMelThreads), (size_t)L.total,
-                     reinterpret_cast<hipStream_t>(stream), x, frames,
-                     static_cast<const unsigned char*>(tables), spec, frames_out, B, T, n_fft, hop,
-                     n_mels, mean, std, W);
+  hipLaunchKernelGGL(logmel_kernel<false>, dim3((unsigned)B), dim3(kMelThreads), (size_t)L.total,
+                     reinterpret_cast<hipStream_t>(stream), x, frames, nullptr, nullptr, nullptr,
+                     static_cast<const unsigned char*>(tables), spec, nullptr, 0LL, frames_out, B, T,
+                     n_fft, hop, n_mels, mean, std, W, pad_mode);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pcgmix_logmel_tile_frames(void) { return pcgmix::kTileFrames; }
+
+extern "C" int pcgmix_logmel_recordings_f32(
+    const float* y, const int64_t* rec_off, const int32_t* rec_len, int R, const int32_t* tiles,
+    int n_tiles, const int32_t* cycles, int n_cycles, const void* tables, float* db_scratch,
+    long long scratch_cols, uint32_t* ref_pow, float* spec, int n_fft, int hop, int n_mels,
+    float mean, float std, int W, int pad_mode, pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!y || !rec_off || !rec_len || !tiles || !cycles || !tables || !db_scratch || !ref_pow ||
+      !spec)
+    return hipErrorInvalidValue;
+  if (R < 1 || n_tiles < 1 || n_cycles < 0 || scratch_cols < 1 || n_fft < 2 || (n_fft & 1) ||
+      hop < 1 || n_mels < 1 || W < 1 || !(std != 0.f) ||
+      (pad_mode != kPadConstant && pad_mode != kPadReflect))
+    return hipErrorInvalidValue;
+  const MelLayout L = mel_layout(kTileFrames, n_fft, hop, n_mels, W, false);
+  if (L.total > 158 * 1024) return hipErrorInvalidValue;
+  static unsigned long long lds_ok = 0;
+  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(logmel_kernel<true>), &lds_ok,
+                                     158 * 1024))
+    return (int)e;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, ref_pow, R);
+  static_assert(sizeof(long long) == sizeof(int64_t), "rec_off is read as long long");
+  hipLaunchKernelGGL(logmel_kernel<true>, dim3((unsigned)n_tiles), dim3(kMelThreads),
+                     (size_t)L.total, s, y, nullptr, reinterpret_cast<const long long*>(rec_off),
+                     rec_len, reinterpret_cast<const int4*>(tiles),
+                     static_cast<const unsigned char*>(tables), db_scratch, ref_pow, scratch_cols,
+                     nullptr, n_tiles, 0, n_fft, hop, n_mels, mean, std, W, pad_mode);
+  if (n_cycles > 0)
+    hipLaunchKernelGGL(logmel_slice_kernel, dim3((unsigned)n_cycles), dim3(256), 0, s, db_scratch,
+                       scratch_cols, ref_pow, reinterpret_cast<const int4*>(cycles), spec, n_mels,
+                       mean, std, W);
   return (int)hipGetLastError();
 }

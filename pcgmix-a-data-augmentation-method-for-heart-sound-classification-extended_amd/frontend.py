@@ -5,8 +5,27 @@ The reference builds its 128x128 log-mel images offline with librosa
 (dataloader_physionet2d.py:22-32).  Here the transform runs per batch on the GPU
 (``pcgmix_logmel_f32``) from the 2 kHz heart-cycle waveform, with the reference's settings:
 hop = int(2000*2.2/128) = 34, n_fft = 4*hop = 136, 128 mel bands from 25 Hz to 1 kHz, dB
-relative to the item's maximum, 80 dB floor, fixed mean/std normalisation, the cycle's columns
-kept and zero-filled up to 128.  Parity with librosa itself is unpinned.
+relative to the maximum, 80 dB floor, fixed mean/std normalisation, the cycle's columns kept and
+zero-filled up to 128.  Parity with librosa itself is UNPINNED: librosa is not
+available offline and the reference stores no spectrogram.
+
+Two entry points:
+
+``logmel``             per heart-cycle item of a batch (already cut cycles, e.g. the time-series
+                       loader's output): one transform per item, dB relative to the item's own
+                       maximum.
+``logmel_recordings``  the reference's own order of operations (cell 6:81-101, 127-142): one
+                       transform over each WHOLE recording, dB relative to the recording's
+                       maximum, then every cycle's columns ``[round(f0*n/len), round(f4*n/len))``
+                       are sliced out and zero-padded.  Cycles cut this way differ from ``logmel``
+                       of the same samples at the cycle edges (neighbouring samples instead of
+                       padding) and in the dB reference.
+
+``pad_mode`` ('constant' = zeros, or 'reflect') is the padding of the centred frames at the
+signal's ends.  Which one librosa 0.9.2's ``melspectrogram`` defaults to could not be verified
+offline; 'constant' (librosa's default since its 0.9 series, to the best of our knowledge) is
+the default here and 'reflect' (the 0.8 default) is selectable.  It only affects the first and
+last two frames of a signal.
 """
 from __future__ import annotations
 
@@ -57,10 +76,23 @@ def logmel_tables(device: torch.device, n_fft: int, n_mels: int, sample_rate: fl
     return blob
 
 
+PAD_MODES = {"constant": 0, "reflect": 1}
+DEFAULT_PAD_MODE = "constant"
+
+
+def _pad_code(pad_mode: str) -> int:
+    try:
+        return PAD_MODES[pad_mode]
+    except KeyError:
+        raise ValueError(f"pad_mode must be one of {sorted(PAD_MODES)}, got {pad_mode!r}") from None
+
+
 def logmel(x: torch.Tensor, frames, sample_rate: int = 2000, n_mels: int = SPEC_FRAMES,
-           width: int = SPEC_FRAMES, mean: float = TRAIN_MEAN, std: float = TRAIN_STD):
+           width: int = SPEC_FRAMES, mean: float = TRAIN_MEAN, std: float = TRAIN_STD,
+           pad_mode: str = DEFAULT_PAD_MODE):
     """x: float32 device tensor (B, T) or (B, 1, T); frames: (B,5) host boundaries.
     Returns (spec (B,1,n_mels,width) on device, frames_spec int64 (B,5) host array)."""
+    pad_code = _pad_code(pad_mode)
     if x.dim() == 3:
         if x.shape[1] != 1:
             raise ValueError("log-mel takes one channel per item")
@@ -78,6 +110,81 @@ def logmel(x: torch.Tensor, frames, sample_rate: int = 2000, n_mels: int = SPEC_
         stream = _raw_stream(x.device)
         _lib.check(lib.pcgmix_logmel_f32(x.data_ptr(), fr.data_ptr(), tables.data_ptr(),
                                          spec.data_ptr(), None, B, T, n_fft, hop, n_mels,
-                                         ctypes.c_float(mean), ctypes.c_float(std), width,
+                                         ctypes.c_float(mean), ctypes.c_float(std), width, pad_code,
                                          ctypes.c_void_p(stream)), "pcgmix_logmel_f32")
     return spec, spec_frames(frames_np, T, hop)
+
+
+def recording_plan(lengths, boundaries, seg_starts, hop: int, width: int, tile_frames: int):
+    """Integer bookkeeping of the per-recording front end (host, O(cycles)): for recording r of
+    ``lengths[r]`` samples, ``boundaries[r]`` are its heart-state boundaries in samples
+    (databuilder.ipynb cell 6:51-52) and ``seg_starts[r]`` the indices i of the boundaries at which
+    a heart cycle starts (cell 6:57-72): cycle = boundaries[i : i+5].
+
+    Returns dict(rec_off, rec_len, tiles (n_tiles,4), cycles (n_cycles,4), scratch_cols,
+    frames_spec (n_cycles,5) cycle-relative column boundaries as cell 6:130, rec_of_cycle).
+    ``frames_spec = round(f * n_frames / len(y))`` with Python's round-half-even, cell 6:101."""
+    rec_off, tiles, cycles, fspec, rec_of = [], [], [], [], []
+    off = col = 0
+    for r, n in enumerate(lengths):
+        n = int(n)
+        n_frames = 1 + n // hop
+        rec_off.append(off)
+        for f0 in range(0, n_frames, tile_frames):
+            tiles.append((r, f0, min(tile_frames, n_frames - f0), col + f0))
+        b = np.asarray(boundaries[r], dtype=np.int64)
+        cols = np.rint(b * n_frames / float(n)).astype(np.int64)          # cell 6:101
+        for i in seg_starts[r]:
+            c = cols[i:i + 5]
+            keep = int(min(max(c[4] - c[0], 0), width, n_frames - c[0]))
+            cycles.append((r, col + int(c[0]), max(keep, 0), 0))
+            fspec.append(c - c[0])                                         # cell 6:130
+            rec_of.append(r)
+        off += n
+        col += n_frames
+    return {"rec_off": np.asarray(rec_off, dtype=np.int64),
+            "rec_len": np.asarray(lengths, dtype=np.int32),
+            "tiles": np.asarray(tiles, dtype=np.int32).reshape(-1, 4),
+            "cycles": np.asarray(cycles, dtype=np.int32).reshape(-1, 4),
+            "scratch_cols": int(col),
+            "frames_spec": np.asarray(fspec, dtype=np.int64).reshape(-1, 5),
+            "rec_of_cycle": np.asarray(rec_of, dtype=np.int64)}
+
+
+def logmel_recordings(y: torch.Tensor, lengths, boundaries, seg_starts, sample_rate: int = 2000,
+                      n_mels: int = SPEC_FRAMES, width: int = SPEC_FRAMES, mean: float = TRAIN_MEAN,
+                      std: float = TRAIN_STD, pad_mode: str = DEFAULT_PAD_MODE):
+    """The reference's per-recording log-mel (databuilder.ipynb cell 6:81-101, 127-142) on device.
+
+    y: float32 device tensor, the recordings back to back (sum(lengths) samples);
+    lengths / boundaries / seg_starts: see ``recording_plan``.
+    Returns (spec (n_cycles,1,n_mels,width) on device, frames_spec int64 (n_cycles,5) host,
+    rec_of_cycle int64 (n_cycles,) host)."""
+    pad_code = _pad_code(pad_mode)
+    if y.dim() != 1 or y.dtype != torch.float32 or not y.is_contiguous() or not y.is_cuda:
+        raise ValueError("y must be a contiguous float32 1-D device tensor")
+    if int(np.sum(lengths)) != y.numel():
+        raise ValueError("lengths do not add up to the number of samples in y")
+    n_fft, hop = stft_params(sample_rate)
+    if min(int(n) for n in lengths) <= n_fft // 2:
+        raise ValueError("a recording is shorter than half a transform window")
+    lib = _lib.load()
+    plan = recording_plan(lengths, boundaries, seg_starts, hop, width, lib.pcgmix_logmel_tile_frames())
+    n_cycles = plan["cycles"].shape[0]
+    dev = y.device
+    with torch.cuda.device(dev):
+        tables = logmel_tables(dev, n_fft, n_mels, sample_rate)
+        rec_off = upload_array(plan["rec_off"], dev)
+        rec_len = upload_array(plan["rec_len"], dev)
+        tiles = upload_array(plan["tiles"], dev)
+        cycles = upload_array(plan["cycles"] if n_cycles else np.zeros((1, 4), np.int32), dev)
+        scratch = torch.empty((n_mels, plan["scratch_cols"]), dtype=torch.float32, device=dev)
+        ref_pow = torch.empty(len(lengths), dtype=torch.int32, device=dev)
+        spec = torch.empty((n_cycles, 1, n_mels, width), dtype=torch.float32, device=dev)
+        _lib.check(lib.pcgmix_logmel_recordings_f32(
+            y.data_ptr(), rec_off.data_ptr(), rec_len.data_ptr(), len(lengths), tiles.data_ptr(),
+            plan["tiles"].shape[0], cycles.data_ptr(), n_cycles, tables.data_ptr(), scratch.data_ptr(),
+            plan["scratch_cols"], ref_pow.data_ptr(), spec.data_ptr() if n_cycles else scratch.data_ptr(),
+            n_fft, hop, n_mels, ctypes.c_float(mean), ctypes.c_float(std), width, pad_code,
+            ctypes.c_void_p(_raw_stream(dev))), "pcgmix_logmel_recordings_f32")
+    return spec, plan["frames_spec"], plan["rec_of_cycle"]

@@ -72,3 +72,30 @@ def test_oracle_displacement_objective_is_what_the_search_maximises(path):
             assert arg == g["disp"][i, k]
             checked += 1
     assert checked > 10
+
+
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+def test_oracle_stft_stage_matches_torch_stft(pad_mode):
+    """The log-mel restatement is unpinned against librosa (absent offline); its STFT stage at
+    least is cross-checked against an independent implementation, torch.stft in float64, for both
+    paddings of the centred frames."""
+    import torch
+    y = np.random.RandomState(0).randn(5000).astype(np.float32)
+    S = O.stft_complex(y, 136, 34, pad_mode)
+    win = torch.hann_window(136, periodic=True, dtype=torch.float64)
+    T = torch.stft(torch.from_numpy(y).double(), 136, 34, 136, win, center=True, pad_mode=pad_mode,
+                   return_complex=True).numpy()
+    assert S.shape == T.shape == (69, 148)
+    assert np.abs(S - T).max() <= 1e-11
+
+
+def test_oracle_recording_level_logmel_is_consistent():
+    """logmel_recording of a recording that IS one cycle starting at sample 0 equals the
+    per-cycle restatement (same padding, same maximum); column boundaries use Python's round."""
+    rs = np.random.RandomState(2)
+    y = rs.randn(5000).astype(np.float32)
+    fr = np.array([0, 300, 900, 1200, 4100])
+    a, rel = O.logmel_recording(y, fr, [0])
+    b, fs = O.logmel(y[None, :], fr[None, :])
+    assert np.array_equal(rel[0], fs[0]) and np.array_equal(a[0], b[0])
+    assert rel[0, 4] == round(4100 * 148 / 5000)

@@ -69,8 +69,7 @@ def trajectory(device, mode):
         losses, lrs = [], []
         for b in batches:
             lrs.append(opt.param_groups[0]["lr"])
-            losses.append(step(b))
-        losses = [float(v) for v in losses]
+            losses.append(float(step(b)))       # the captured step returns its static loss tensor
     assert sc.count == train_cases.TRAJ_STEPS
     return np.asarray(losses), np.asarray(lrs), {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}, extras
 
