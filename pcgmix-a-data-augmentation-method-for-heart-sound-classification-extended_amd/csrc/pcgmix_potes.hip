@@ -89,10 +89,14 @@ __device__ __forceinline__ void lds_load8(const float* p, float (&v)[8]) {  // p
 // 16-byte reads of a 12-float window starting at float4 index 2g become E[g], O[g], E[g+1]:
 // consecutive lanes read consecutive 16 bytes.  With the plain layout the windows start 32 bytes
 // apart and every ds_read_b128 is a 2-way bank conflict (64 banks x 4 B, 16 lanes per group).
+// s1g (forward kernel only, may be nullptr): global plane (8, P1) of this row that receives the
+// same pool/ReLU selector byte for the positions q in [own_lo, own_hi) — what the mask-based
+// backward kernels read instead of recomputing this layer.
 template <bool SWZ>
 __device__ __forceinline__ void layer1_t(const PotesWeights& W, const float* xs, float* a1s,
                                          uint8_t* sel, int qlo, int nq, int P1, int xplane,
-                                         int aplane) {
+                                         int aplane, uint8_t* __restrict__ s1g = nullptr,
+                                         int own_lo = 0, int own_hi = 0) {
   const int groups = nq / 4;
   for (int item = threadIdx.x; item < kC1 * groups; item += kPotThreads) {
     const int ci = item / groups, g = item - ci * groups;
@@ -158,6 +162,13 @@ __device__ __forceinline__ void layer1_t(const PotesWeights& W, const float* xs,
     }
     if (SWZ) {
       *reinterpret_cast<f4*>(a1s + ci * 2 * aplane + (g & 1) * aplane + 4 * (g >> 1)) = out;
+      if (s1g) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = qlo + 4 * g + u;
+          if (q >= own_lo && q < own_hi) s1g[(size_t)ci * P1 + q] = (uint8_t)((sels >> (8 * u)) & 0xffu);
+        }
+      }
     } else {
       *reinterpret_cast<f4*>(a1s + ci * nq + 4 * g) = out;
       if (sel) *reinterpret_cast<uint32_t*>(sel + ci * nq + 4 * g) = sels;
@@ -178,10 +189,15 @@ constexpr int kFwdTP = 252;                     // pooled outputs per block (4 p
 constexpr int kFwdNQ = 2 * kFwdTP + 4;          // 508
 constexpr int kFwdNX = 4 * kFwdTP + 12;         // 1020
 
+// SAVE: also write what the mask-based backward kernels need so that they do not recompute the
+// forward: m2 (N, 4, ceil(P2/4)) — per pooled output 2 bits (0 = ReLU-dead, 1 = first conv output
+// of the pooled pair won, 2 = second), four outputs per byte — and, if s1 != nullptr, s1
+// (N, 8, P1) — the same selector for the first layer, one byte per pooled position.
+template <bool SAVE>
 __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
-    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ h2, int N,
-    int T) {
+    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ h2,
+    uint8_t* __restrict__ m2, uint8_t* __restrict__ s1, int N, int T) {
   __shared__ PotesWeights W;
   // swizzled planes (see layer1_t): x = 255 float4 -> E 128 + O 128; a1 = 127 float4 per channel
   // -> E 64 + O 64 per channel (+4 floats: lane 63 of conv2 reads E[64] of the last channel)
@@ -200,7 +216,15 @@ __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
     }
   }
   __syncthreads();
-  layer1_t<true>(W, xs, a1s, nullptr, qlo, kFwdNQ, d.P1, kXPlane, kAPlane);
+  if (SAVE && s1) {
+    // every first-layer position is stored by exactly one tile; the last tile also owns the
+    // two or three positions beyond 2*P2 that still feed the last pooled outputs
+    const int own_hi = blockIdx.x == gridDim.x - 1 ? d.P1 : min(2 * p0 + 2 * kFwdTP, d.P1);
+    layer1_t<true>(W, xs, a1s, nullptr, qlo, kFwdNQ, d.P1, kXPlane, kAPlane,
+                   s1 + (size_t)n * kC1 * d.P1, 2 * p0, own_hi);
+  } else {
+    layer1_t<true>(W, xs, a1s, nullptr, qlo, kFwdNQ, d.P1, kXPlane, kAPlane);
+  }
   __syncthreads();
   // conv 8->4 k5 + ReLU + pool 2: wave = output channel, lane = 4 consecutive pooled outputs
   // co is wave-uniform: its 40 weights come through the scalar cache into SGPRs instead of
@@ -262,6 +286,16 @@ __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
 #pragma unroll
   for (int u = 0; u < 4; ++u) o[u] = fmaxf(fmaxf(c[2 * u], 0.f), fmaxf(c[2 * u + 1], 0.f));
   if (4 * lane >= kFwdTP) return;                  // lane 63: outputs owned by the next tile
+  if (SAVE && p < d.P2) {
+    uint32_t code = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                   // the backward's routing rule, verbatim
+      const float ra = fmaxf(c[2 * u], 0.f), rb = fmaxf(c[2 * u + 1], 0.f);
+      const uint32_t sc = rb > ra ? 2u : (ra > 0.f ? 1u : 0u);
+      if (p + u < d.P2) code |= sc << (2 * u);
+    }
+    m2[((size_t)n * kC2 + co) * ((d.P2 + 3) / 4) + (p >> 2)] = (uint8_t)code;
+  }
   if (p + 3 < d.P2 && (d.P2 & 3) == 0) {
     *reinterpret_cast<f4*>(dst) = o;
   } else {
@@ -945,8 +979,30 @@ extern "C" int pcgmix_potes_stack_fwd_f32(const float* x, const float* w1, const
   if (N == 0) return hipSuccess;
   const PotesDims d = potes_dims(T);
   dim3 grid((unsigned)((d.P2 + kFwdTP - 1) / kFwdTP), (unsigned)N), block(kPotThreads);
-  hipLaunchKernelGGL(potes_fwd_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), x, w1,
-                     b1, w2, b2, h2, N, T);
+  hipLaunchKernelGGL(potes_fwd_kernel<false>, grid, block, 0, reinterpret_cast<hipStream_t>(stream),
+                     x, w1, b1, w2, b2, h2, nullptr, nullptr, N, T);
+  return (int)hipGetLastError();
+}
+
+extern "C" long long pcgmix_potes_mask_bytes(int N, int T, int layer) {
+  if (N <= 0 || T < 14) return 0;
+  const pcgmix::PotesDims d = pcgmix::potes_dims(T);
+  return layer == 2 ? (long long)N * pcgmix::kC2 * ((d.P2 + 3) / 4)
+                    : (layer == 1 ? (long long)N * pcgmix::kC1 * d.P1 : 0);
+}
+
+extern "C" int pcgmix_potes_stack_fwd_save_f32(const float* x, const float* w1, const float* b1,
+                                               const float* w2, const float* b2, float* h2,
+                                               uint8_t* m2, uint8_t* s1, int N, int T,
+                                               pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!x || !w1 || !b1 || !w2 || !b2 || !h2 || !m2 || N < 0 || T < 14 || N > 65535)
+    return hipErrorInvalidValue;
+  if (N == 0) return hipSuccess;
+  const PotesDims d = potes_dims(T);
+  dim3 grid((unsigned)((d.P2 + kFwdTP - 1) / kFwdTP), (unsigned)N), block(kPotThreads);
+  hipLaunchKernelGGL(potes_fwd_kernel<true>, grid, block, 0, reinterpret_cast<hipStream_t>(stream),
+                     x, w1, b1, w2, b2, h2, m2, s1, N, T);
   return (int)hipGetLastError();
 }
 
