@@ -266,6 +266,32 @@ int pcgmix_potes_stack_input_grad_f32(const float* x, const float* grad_h2, cons
 int pcgmix_potes_stack_bwd_f32(const float* x, const float* grad_h2, const float* w1,
                                const float* b1, const float* w2, const float* b2, float* partial,
                                float* grads, int N, int T, pcgmix_stream_t stream);
+/* The same three passes with the forward's ReLU / max-pool routing SAVED instead of recomputed
+ * (what autograd keeps for nn.ReLU / nn.MaxPool1d in models.py:359-365, at 2 bits or a byte per
+ * position instead of the activations):
+ *   m2   uint8 (N, 4, ceil(P2/4))  second layer: per pooled output 2 bits — 0 ReLU-dead, 1 the
+ *        first conv output of the pooled pair won, 2 the second; four outputs per byte
+ *   s1   uint8 (N, 8, P1)          first layer: the same selector, one byte per pooled position;
+ *        only the input gradient needs it (pass NULL to the forward otherwise)
+ *   sizes in bytes: pcgmix_potes_mask_bytes(N, T, layer = 2 or 1)
+ *   pcgmix_potes_stack_fwd_save_f32        the forward above + m2 (+ s1)
+ *   pcgmix_potes_stack_bwd_mask_f32        weight gradients: recomputes layer 1 only
+ *   pcgmix_potes_stack_input_grad_mask_f32 dL/dx from grad_h2, m2, s1 and the weights alone:
+ *                                          no forward recompute at all
+ * Gradients flow exactly where the forward's maxima were (the recomputing kernels re-derive the
+ * routing with a different summation order and can differ at exact near-ties).
+ */
+long long pcgmix_potes_mask_bytes(int N, int T, int layer);
+int pcgmix_potes_stack_fwd_save_f32(const float* x, const float* w1, const float* b1,
+                                    const float* w2, const float* b2, float* h2, uint8_t* m2,
+                                    uint8_t* s1, int N, int T, pcgmix_stream_t stream);
+int pcgmix_potes_stack_bwd_mask_f32(const float* x, const float* grad_h2, const uint8_t* m2,
+                                    const float* w1, const float* b1, const float* w2,
+                                    const float* b2, float* partial, float* grads, int N, int T,
+                                    pcgmix_stream_t stream);
+int pcgmix_potes_stack_input_grad_mask_f32(const float* grad_h2, const uint8_t* m2,
+                                           const uint8_t* s1, const float* w1, const float* w2,
+                                           float* grad_x, int N, int T, pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Skinny linear layer forward (the Potes head's `dimreduc`, models.py:376, 430).    [device]

@@ -47,6 +47,10 @@ SIGNATURES = {
     "pcgmix_potes_stack_fwd_f32": (_c_int, [_ptr] * 6 + [_c_int, _c_int, _ptr]),
     "pcgmix_potes_stack_bwd_f32": (_c_int, [_ptr] * 8 + [_c_int, _c_int, _ptr]),
     "pcgmix_potes_stack_input_grad_f32": (_c_int, [_ptr] * 7 + [_c_int, _c_int, _ptr]),
+    "pcgmix_potes_mask_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
+    "pcgmix_potes_stack_fwd_save_f32": (_c_int, [_ptr] * 8 + [_c_int, _c_int, _ptr]),
+    "pcgmix_potes_stack_bwd_mask_f32": (_c_int, [_ptr] * 9 + [_c_int, _c_int, _ptr]),
+    "pcgmix_potes_stack_input_grad_mask_f32": (_c_int, [_ptr] * 6 + [_c_int, _c_int, _ptr]),
     "pcgmix_skinny_linear_splits": (_c_int, [_c_int, _c_int]),
     "pcgmix_skinny_linear_fwd_f32": (_c_int, [_ptr] * 5 + [_c_int, _c_int, _c_int, _ptr]),
     "pcgmix_adam_clip_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, ctypes.c_longlong, _c_float, _c_float,

@@ -325,8 +325,12 @@ __device__ __forceinline__ int potes_bwd_tiles(const PotesDims& d) {
   return (d.P2 + 2 + kBwdTP - 1) / kBwdTP;
 }
 
+// MASK: the second layer's ReLU/pool routing comes from the forward's m2 bytes instead of being
+// recomputed (no conv2 pass, one barrier phase less): dz2 = route(gh2, m2).
+template <bool MASK>
 __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ gh2, const float* __restrict__ w1,
+    const float* __restrict__ x, const float* __restrict__ gh2, const uint8_t* __restrict__ m2,
+    const float* __restrict__ w1,
     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
     float* __restrict__ partial /* gridDim.x * 212 */, int N, int T) {
   __shared__ PotesWeights W;
@@ -363,6 +367,8 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
   // not paid twice per item with only two resident blocks per CU.
   constexpr int kXPer = (kBwdNX + 4 + kPotThreads - 1) / kPotThreads;   // 3
   float xr[kXPer], gr[2];
+  uint32_t mr[2] = {0u, 0u};
+  const int m2s = (d.P2 + 3) / 4;
   auto prefetch = [&](long long it) {
     const int n = (int)(it / tiles), p0 = (int)(it - (long long)n * tiles) * kBwdTP;
     const int xlo = 2 * (2 * p0 - 5) - 1;
@@ -376,6 +382,10 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
     for (int u = 0; u < 2; ++u) {
       const int pe = p0 - 2 + 2 * lane + u;
       gr[u] = (pe >= 0 && pe < d.P2) ? gh2[((size_t)n * kC2 + wave) * d.P2 + pe] : 0.f;
+      if (MASK)
+        mr[u] = (pe >= 0 && pe < d.P2)
+                    ? (m2[((size_t)n * kC2 + wave) * m2s + (pe >> 2)] >> (2 * (pe & 3))) & 3u
+                    : 0u;
     }
   };
   if ((long long)blockIdx.x < work) prefetch(blockIdx.x);
@@ -391,11 +401,20 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
       if (u < kBwdNX + 4) xs[u] = xr[j];
     }
     const float g_cur[2] = {gr[0], gr[1]};
+    if (MASK) {   // dz2 on the extended range straight from the saved routing (wave = co)
+      f4 dz;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        dz[2 * u] = mr[u] == 1u ? g_cur[u] : 0.f;
+        dz[2 * u + 1] = mr[u] == 2u ? g_cur[u] : 0.f;
+      }
+      *reinterpret_cast<f4*>(dz2s + wave * kDz2Row + 4 * lane) = dz;
+    }
     if (item + gridDim.x < work) prefetch(item + gridDim.x);
     __syncthreads();
     layer1(W, xs, a1s, sel1, qlo, kBwdNQ, d.P1);
     __syncthreads();
-    {  // conv2 + ReLU + pool on the extended range -> dz2 = dL/dz2 (wave = co, 2 pooled per lane)
+    if (!MASK) {  // conv2 + ReLU + pool on the extended range -> dz2 = dL/dz2 (wave = co, 2 pooled per lane)
       const int co = __builtin_amdgcn_readfirstlane(wave);
       float aw[8], za[2], zb[2];
       za[0] = za[1] = zb[0] = zb[1] = b2[co];
@@ -428,7 +447,7 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
       }
       *reinterpret_cast<f4*>(dz2s + co * kDz2Row + 4 * lane) = dz;
     }
-    __syncthreads();
+    if (!MASK) __syncthreads();
     {  // back through conv2 to the owned a1 positions q = 2p0+r, then pool1/ReLU1 -> dz1
        // wave w -> channels 2w, 2w+1; lane -> r0 = 4*lane .. +3
       const int r0 = 4 * lane;
@@ -671,6 +690,110 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_kernel(
         for (int k = 0; k < kK; ++k) {
           acc0 = fmaf(dw[4 - k], w[k], acc0);        // v0+5-k   -> offset 4-k from v0+1
           acc1 = fmaf(dw[5 - k], w[k], acc1);        // v0+1+5-k
+        }
+      }
+      const int u = 4 * p0 + v0;
+      float* dst = gx + (size_t)n * T + u;
+      if (u < T) dst[0] = acc0;
+      if (u + 1 < T) dst[1] = acc1;
+    }
+  }
+}
+
+// The same gradient from the forward's saved routing (m2, s1) instead of a recomputed forward:
+// neither x nor the activations are needed — dz2 = route(gh2, m2), dL/da1 = conv2^T dz2,
+// dz1 = route(dL/da1, s1), dL/dx = conv1^T dz1.  Half the multiply-adds of the kernel above and
+// two barrier phases instead of four.  Same tile geometry.
+__global__ __launch_bounds__(kPotThreads) void potes_input_grad_mask_kernel(
+    const float* __restrict__ gh2, const uint8_t* __restrict__ m2, const uint8_t* __restrict__ s1,
+    const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ gx, int N,
+    int T) {
+  __shared__ float w1s[kNW1];
+  constexpr int kDz2Row = kBwdNJ + 12;
+  __shared__ __align__(16) float dz2s[kC2 * kDz2Row];
+  __shared__ __align__(16) float dz1s[kC1 * kBwdNIpad];
+  const PotesDims d = potes_dims(T);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y, p0 = blockIdx.x * kInTP;
+  const int m2s = (d.P2 + 3) / 4;
+  for (int i = threadIdx.x; i < kNW1; i += kPotThreads) w1s[i] = w1[i];
+  // first-layer selectors of this lane's 4 positions q = 2p0-2+4*lane+u for its two channels:
+  // issued now, consumed after the first barrier
+  uint32_t sc[2][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = 4 * lane + u, q = 2 * p0 - 2 + r;
+      sc[c][u] = (r < kInNR && q >= 0 && q < d.P1)
+                     ? s1[((size_t)n * kC1 + 2 * wave + c) * d.P1 + q] : 0u;
+    }
+  {  // dz2 at pe = p0-3+2*lane+u (wave = co); the 12-float pad of each row stays zero
+    const int co = wave;
+    f4 dz;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pe = p0 - 3 + 2 * lane + u;
+      float g = 0.f;
+      uint32_t code = 0u;
+      if (pe >= 0 && pe < d.P2) {
+        g = gh2[((size_t)n * kC2 + co) * d.P2 + pe];
+        code = (m2[((size_t)n * kC2 + co) * m2s + (pe >> 2)] >> (2 * (pe & 3))) & 3u;
+      }
+      dz[2 * u] = code == 1u ? g : 0.f;
+      dz[2 * u + 1] = code == 2u ? g : 0.f;
+    }
+    *reinterpret_cast<f4*>(dz2s + co * kDz2Row + 4 * lane) = dz;
+    if (lane < 3) *reinterpret_cast<f4*>(dz2s + co * kDz2Row + kBwdNJ + 4 * lane) = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  {  // dL/da1 at q = 2p0-2+r (r < 251), through pool1/ReLU1 -> dz1 at i = 4p0-4+2r(+1)
+    const int r0 = 4 * lane;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ci = __builtin_amdgcn_readfirstlane(2 * wave + c);
+      float da1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int co = 0; co < kC2; ++co) {
+        float dw[12], w[kK];
+        lds_load12(dz2s + co * kDz2Row + r0, dw);   // dz2 index r+5-k
+#pragma unroll
+        for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci) * kK + k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < kK; ++k) da1[u] = fmaf(dw[u + 5 - k], w[k], da1[u]);
+      }
+      float out[8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        out[2 * u] = sc[c][u] == 1u ? da1[u] : 0.f;
+        out[2 * u + 1] = sc[c][u] == 2u ? da1[u] : 0.f;
+      }
+      f4* dst = reinterpret_cast<f4*>(dz1s + ci * kBwdNIpad + 8 * lane);
+      dst[0] = f4{out[0], out[1], out[2], out[3]};
+      dst[1] = f4{out[4], out[5], out[6], out[7]};
+    }
+  }
+  __syncthreads();
+  {  // transposed conv1: dx[u] = sum_ci sum_k dz1[ci][u+1-k] * w1[ci][k]; dz1 index v+5-k
+    const int v0 = 2 * threadIdx.x;
+    if (v0 < kInNU) {
+      float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < kC1; ++ci) {
+        float dw[6], w[kK];
+#pragma unroll
+        for (int j = 0; j < 6; j += 2) {
+          dw[j] = dz1s[ci * kBwdNIpad + v0 + 1 + j];
+          dw[j + 1] = dz1s[ci * kBwdNIpad + v0 + 2 + j];
+        }
+#pragma unroll
+        for (int k = 0; k < kK; ++k) w[k] = w1s[ci * kK + k];
+#pragma unroll
+        for (int k = 0; k < kK; ++k) {
+          acc0 = fmaf(dw[4 - k], w[k], acc0);
+          acc1 = fmaf(dw[5 - k], w[k], acc1);
         }
       }
       const int u = 4 * p0 + v0;
@@ -1029,9 +1152,38 @@ extern "C" int pcgmix_potes_stack_bwd_f32(const float* x, const float* grad_h2, 
     return hipErrorInvalidValue;
   const int G = pcgmix_potes_bwd_blocks(N, T);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(potes_bwd_kernel, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2, w1,
-                     b1, w2, b2, partial, N, T);
+  hipLaunchKernelGGL(potes_bwd_kernel<false>, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2,
+                     nullptr, w1, b1, w2, b2, partial, N, T);
   hipLaunchKernelGGL(potes_reduce_kernel, dim3(kNGrad), dim3(kPotThreads), 0, s, partial, grads, G);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pcgmix_potes_stack_bwd_mask_f32(const float* x, const float* grad_h2,
+                                               const uint8_t* m2, const float* w1, const float* b1,
+                                               const float* w2, const float* b2, float* partial,
+                                               float* grads, int N, int T, pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!x || !grad_h2 || !m2 || !w1 || !b1 || !w2 || !b2 || !partial || !grads || N <= 0 || T < 14)
+    return hipErrorInvalidValue;
+  const int G = pcgmix_potes_bwd_blocks(N, T);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(potes_bwd_kernel<true>, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2,
+                     m2, w1, b1, w2, b2, partial, N, T);
+  hipLaunchKernelGGL(potes_reduce_kernel, dim3(kNGrad), dim3(kPotThreads), 0, s, partial, grads, G);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pcgmix_potes_stack_input_grad_mask_f32(const float* grad_h2, const uint8_t* m2,
+                                                      const uint8_t* s1, const float* w1,
+                                                      const float* w2, float* grad_x, int N, int T,
+                                                      pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!grad_h2 || !m2 || !s1 || !w1 || !w2 || !grad_x || N < 0 || N > 65535 || T < 14)
+    return hipErrorInvalidValue;
+  if (N == 0) return hipSuccess;
+  dim3 grid((unsigned)((T + kInNU - 1) / kInNU), (unsigned)N), block(kPotThreads);
+  hipLaunchKernelGGL(potes_input_grad_mask_kernel, grid, block, 0,
+                     reinterpret_cast<hipStream_t>(stream), grad_h2, m2, s1, w1, w2, grad_x, N, T);
   return (int)hipGetLastError();
 }
 

@@ -21,10 +21,18 @@ from . import _lib
 
 class PotesStackFunction(torch.autograd.Function):
     """conv(1->8,k5,p1)+ReLU+pool2 -> conv(8->4,k5,p1)+ReLU+pool2 on (N,T) rows as ONE HIP kernel
-    forward and one (+ a 212-block reduction) backward: ``pcgmix_potes_stack_{fwd,bwd}_f32``
-    (csrc/pcgmix_potes.hip).  The backward recomputes the forward per tile from the saved input,
-    so nothing but the input row is kept for it.  The input gradient (saliency maps) has its own
-    kernel, ``pcgmix_potes_stack_input_grad_f32``, run only when the input requires it."""
+    forward and one (+ a 212-block reduction) backward (csrc/pcgmix_potes.hip).
+
+    ``use_masks`` (default): when a gradient will be needed the forward also stores where its
+    ReLUs were alive and which element won each max-pool (2 bits per second-layer output; a byte
+    per first-layer position if the input gradient is needed) — what autograd keeps for
+    nn.ReLU/nn.MaxPool1d, minus the activations.  The weight-gradient backward then recomputes
+    only the first layer from the saved input (``pcgmix_potes_stack_bwd_mask_f32``), and the input
+    gradient (saliency maps) recomputes nothing (``pcgmix_potes_stack_input_grad_mask_f32``).
+    ``use_masks = False``: the kernels that recompute the whole forward per tile and keep nothing
+    but the input row (``pcgmix_potes_stack_{bwd,input_grad}_f32``)."""
+
+    use_masks = True
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
@@ -34,15 +42,27 @@ class PotesStackFunction(torch.autograd.Function):
         w1c, b1c, w2c, b2c = (t.detach().contiguous() for t in (w1, b1, w2, b2))
         h2 = torch.empty((N, 4, P2), dtype=torch.float32, device=x.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        _lib.check(lib.pcgmix_potes_stack_fwd_f32(x.data_ptr(), w1c.data_ptr(), b1c.data_ptr(),
-                                                  w2c.data_ptr(), b2c.data_ptr(), h2.data_ptr(),
-                                                  N, T, stream), "pcgmix_potes_stack_fwd_f32")
-        ctx.save_for_backward(x, w1c, b1c, w2c, b2c)
+        need_x = ctx.needs_input_grad[0]
+        m2 = s1 = None
+        if PotesStackFunction.use_masks and N > 0 and any(ctx.needs_input_grad):
+            m2 = torch.empty(lib.pcgmix_potes_mask_bytes(N, T, 2), dtype=torch.uint8, device=x.device)
+            if need_x:
+                s1 = torch.empty(lib.pcgmix_potes_mask_bytes(N, T, 1), dtype=torch.uint8,
+                                 device=x.device)
+            _lib.check(lib.pcgmix_potes_stack_fwd_save_f32(
+                x.data_ptr(), w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(),
+                h2.data_ptr(), m2.data_ptr(), s1.data_ptr() if s1 is not None else None, N, T,
+                stream), "pcgmix_potes_stack_fwd_save_f32")
+        else:
+            _lib.check(lib.pcgmix_potes_stack_fwd_f32(x.data_ptr(), w1c.data_ptr(), b1c.data_ptr(),
+                                                      w2c.data_ptr(), b2c.data_ptr(), h2.data_ptr(),
+                                                      N, T, stream), "pcgmix_potes_stack_fwd_f32")
+        ctx.save_for_backward(x, w1c, b1c, w2c, b2c, m2, s1)
         return h2
 
     @staticmethod
     def backward(ctx, grad_h2):
-        x, w1, b1, w2, b2 = ctx.saved_tensors
+        x, w1, b1, w2, b2, m2, s1 = ctx.saved_tensors
         N, T = x.shape
         lib = _lib.load()
         g = grad_h2.contiguous()
@@ -50,17 +70,28 @@ class PotesStackFunction(torch.autograd.Function):
         gx = gw1 = gb1 = gw2 = gb2 = None
         if ctx.needs_input_grad[0]:                    # saliency: d score / d input
             gx = torch.empty_like(x)
-            _lib.check(lib.pcgmix_potes_stack_input_grad_f32(
-                x.data_ptr(), g.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
-                b2.data_ptr(), gx.data_ptr(), N, T, stream), "pcgmix_potes_stack_input_grad_f32")
+            if s1 is not None:
+                _lib.check(lib.pcgmix_potes_stack_input_grad_mask_f32(
+                    g.data_ptr(), m2.data_ptr(), s1.data_ptr(), w1.data_ptr(), w2.data_ptr(),
+                    gx.data_ptr(), N, T, stream), "pcgmix_potes_stack_input_grad_mask_f32")
+            else:
+                _lib.check(lib.pcgmix_potes_stack_input_grad_f32(
+                    x.data_ptr(), g.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                    b2.data_ptr(), gx.data_ptr(), N, T, stream), "pcgmix_potes_stack_input_grad_f32")
         if any(ctx.needs_input_grad[1:]):
             G = lib.pcgmix_potes_bwd_blocks(N, T)
             partial = torch.empty((G, 212), dtype=torch.float32, device=x.device)
             grads = torch.empty(212, dtype=torch.float32, device=x.device)
-            _lib.check(lib.pcgmix_potes_stack_bwd_f32(x.data_ptr(), g.data_ptr(), w1.data_ptr(),
-                                                      b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                                                      partial.data_ptr(), grads.data_ptr(), N, T,
-                                                      stream), "pcgmix_potes_stack_bwd_f32")
+            if m2 is not None:
+                _lib.check(lib.pcgmix_potes_stack_bwd_mask_f32(
+                    x.data_ptr(), g.data_ptr(), m2.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                    w2.data_ptr(), b2.data_ptr(), partial.data_ptr(), grads.data_ptr(), N, T, stream),
+                    "pcgmix_potes_stack_bwd_mask_f32")
+            else:
+                _lib.check(lib.pcgmix_potes_stack_bwd_f32(
+                    x.data_ptr(), g.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                    b2.data_ptr(), partial.data_ptr(), grads.data_ptr(), N, T, stream),
+                    "pcgmix_potes_stack_bwd_f32")
             gw1, gb1 = grads[0:40].view(8, 1, 5), grads[40:48]
             gw2, gb2 = grads[48:208].view(4, 8, 5), grads[208:212]
         return gx, gw1, gb1, gw2, gb2

@@ -10,6 +10,16 @@ from pcgmix_amd import models
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[True, False], ids=["masks", "recompute"])
+def backward_kind(request):
+    """Both backward families: from the forward's saved ReLU/pool routing (default), and the
+    kernels that recompute the forward per tile."""
+    old = models.PotesStackFunction.use_masks
+    models.PotesStackFunction.use_masks = request.param
+    yield request.param
+    models.PotesStackFunction.use_masks = old
+
+
 def make(T, device, seed=0):
     torch.manual_seed(seed)
     m = models.CNN_potes_TS(4, 2, "PhysioNet", sig_len=None if T == 2500 else T).to(device)
@@ -34,7 +44,7 @@ def test_forward_matches_torch(B, T, device):
 
 
 @pytest.mark.parametrize("B,T", [(8, 2500), (4, 5000), (3, 1037), (2, 1030), (6, 526), (2, 270), (1, 23)])
-def test_weight_gradients_match_torch(B, T, device):
+def test_weight_gradients_match_torch(B, T, backward_kind, device):
     """dL/d{w1,b1,w2,b2} of a random linear functional of the stack output (dropout off)."""
     m = make(T, device, seed=1).eval()
     x = torch.randn(B, 4, T, device=device)
@@ -50,7 +60,7 @@ def test_weight_gradients_match_torch(B, T, device):
         assert float((a - b).abs().max()) <= 2e-4 * scale, (name, float((a - b).abs().max()), scale)
 
 
-def test_training_step_equivalence(device):
+def test_training_step_equivalence(backward_kind, device):
     """One Adam step with the fused stack == one with the torch stack (dropout disabled)."""
     outs = []
     for fused in (True, False):
@@ -74,7 +84,7 @@ def test_training_step_equivalence(device):
 
 
 @pytest.mark.parametrize("B,T", [(8, 2500), (4, 5000), (3, 1037), (2, 1030), (6, 526), (2, 270), (1, 23), (2, 14)])
-def test_input_gradient_matches_torch(B, T, device):
+def test_input_gradient_matches_torch(B, T, backward_kind, device):
     """dL/dx through the fused stack == through the torch stack (saliency maps differentiate the
     class score with respect to the input, saliency.py:52-61)."""
     m = make(T, device, seed=3).eval()
@@ -113,3 +123,27 @@ def test_skinny_linear_matches_torch(B, K, device):
     g_f = torch.autograd.grad((z_f * r).sum(), [x2, lin.weight, lin.bias])
     for a, b in zip(g_f, g_t):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()) + 1e-7)
+
+
+def test_saved_masks_equal_recomputed_routing(device):
+    """The forward with masks returns the same activations as the plain forward, and the two
+    backward families agree with each other far below the torch tolerance (they can only differ
+    where a ReLU/pool decision is an exact near-tie under another summation order)."""
+    m = make(5000, device, seed=4).eval()
+    c1, c2 = m.cnn1[0][0], m.cnn1[1][0]
+    params = [c1.weight, c1.bias, c2.weight, c2.bias]
+    x = torch.randn(64, 5000, device=device)
+    res = {}
+    old = models.PotesStackFunction.use_masks
+    try:
+        for kind in (True, False):
+            models.PotesStackFunction.use_masks = kind
+            xi = x.clone().requires_grad_(True)
+            h = models.PotesStackFunction.apply(xi, *params)
+            r = torch.randn(h.shape, device=device, generator=torch.Generator(device).manual_seed(1))
+            res[kind] = (h.detach(), torch.autograd.grad((h * r).sum(), [xi] + params))
+    finally:
+        models.PotesStackFunction.use_masks = old
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-6)
