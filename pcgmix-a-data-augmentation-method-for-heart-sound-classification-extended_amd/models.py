@@ -19,6 +19,16 @@ import torch.nn.functional as F
 from . import _lib
 
 
+_WARNED: set = set()
+
+
+def _warn_once(msg: str) -> None:
+    if msg not in _WARNED:
+        _WARNED.add(msg)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 class PotesStackFunction(torch.autograd.Function):
     """conv(1->8,k5,p1)+ReLU+pool2 -> conv(8->4,k5,p1)+ReLU+pool2 on (N,T) rows as ONE HIP kernel
     forward and one (+ a 212-block reduction) backward (csrc/pcgmix_potes.hip).
@@ -231,11 +241,20 @@ class CNN_potes(nn.Module):
         self.fused = True       # use the fused HIP conv stack on a HIP device (see _fused)
 
     def _fused(self, x: torch.Tensor) -> bool:
-        """The hand-written HIP stack applies to the reference configuration (layers [8,4]) on a
-        HIP device."""
+        """The hand-written HIP stack applies to the reference configuration (layers [8,4], float32)
+        on a HIP device.  Host tensors (CPU-side tests, gloo rehearsals) and an explicit
+        ``self.fused = False`` take torch's ops; a DEVICE tensor that cannot take the HIP kernels
+        does so too, but says so — a GPU run must not lose its kernels without a word."""
+        if not (self.fused and x.is_cuda):
+            return False
         c1, c2 = self.cnn1[0][0], self.cnn1[1][0]
-        return (self.fused and x.is_cuda and x.dtype == torch.float32
-                and c1.out_channels == 8 and c2.out_channels == 4 and x.shape[-1] >= 14)
+        ok = (x.dtype == torch.float32 and c1.out_channels == 8 and c2.out_channels == 4
+              and x.shape[-1] >= 14)
+        if not ok:
+            _warn_once(f"CNN_potes: input {tuple(x.shape)} {x.dtype} / layers "
+                       f"[{c1.out_channels},{c2.out_channels}] cannot use the fused HIP conv stack "
+                       "(needs float32, layers [8,4], T >= 14): running torch/MIOpen ops instead")
+        return ok
 
     def _fused_head(self, x: torch.Tensor) -> bool:
         return (self._fused(x) and self.dimreduc.out_features == 20
@@ -413,6 +432,10 @@ def conv_bn_relu_pool(h, weight4, conv_bias, padding, bn, training: bool, pool):
             ph, pw = (1, 1) if pool is None else ((pool, pool) if isinstance(pool, int) else pool)
             return BNReLUPoolFunction.apply(h, bn.weight, beta, bn.running_mean, bn.running_var,
                                             float(bn.momentum), float(bn.eps), int(ph), int(pw))
+        if FUSED_BN and training and h.is_cuda:
+            _warn_once(f"conv_bn_relu_pool: activation {tuple(h.shape)} {h.dtype} cannot use the HIP "
+                       "BatchNorm+ReLU+pool kernels (needs float32 channels_last, C % 4 == 0, "
+                       "256 % (C/4) == 0): running torch ops instead")
         h = F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, beta, True, bn.momentum,
                          bn.eps)
     else:
