@@ -452,8 +452,10 @@ int pcgmix_mix_variant(int B, int C, int T, int warp, int aligned16, int* vec, i
  * models2d.py:13-19) and their autograd.  y is the convolution output stored NHWC: (B, H, W, C)
  * row-major (H = 1 for the 1D network), C % 4 == 0 and 256 % (C / 4) == 0 (64 ... 1024).
  *   forward : batch mean / biased variance per channel -> z (B, H/ph, W/pw, C) =
- *             maxpool_{ph x pw}(relu(gamma * (y - mean) / sqrt(var + eps) + beta));  ph = pw = 1:
- *             no pooling.  mean, invstd (C each) are outputs kept for backward; running_mean /
+ *             maxpool_{ph x pw}(relu(gamma * (y - mean) / sqrt(var + eps) + beta)) [+ skip];
+ *             ph = pw = 1: no pooling.  skip (shape of z, or NULL): the residual connection of
+ *             res1 / res2 (models.py:577, 581: `out = self.res1(out) + out`) added in the same
+ *             pass; its gradient is dz itself, so the backward below is unchanged.  mean, invstd (C each) are outputs kept for backward; running_mean /
  *             running_var (may be NULL) are updated in place with `momentum` (unbiased variance).
  *   backward: dz (shape of z) -> dx (shape of y), dgamma, dbeta (C each).  The ReLU mask and the
  *             pooling arg-max (first maximum) are recomputed from y.
@@ -462,9 +464,9 @@ int pcgmix_mix_variant(int B, int C, int T, int warp, int aligned16, int* vec, i
  */
 long long pcgmix_bnrp_workspace_floats(int B, int H, int W, int C);
 int pcgmix_bnrp_fwd_f32(const float* y, const float* gamma, const float* beta, float* running_mean,
-                        float* running_var, float momentum, float eps, float* z, float* mean,
-                        float* invstd, float* workspace, int B, int H, int W, int C, int ph, int pw,
-                        pcgmix_stream_t stream);
+                        float* running_var, float momentum, float eps, const float* skip, float* z,
+                        float* mean, float* invstd, float* workspace, int B, int H, int W, int C,
+                        int ph, int pw, pcgmix_stream_t stream);
 int pcgmix_bnrp_bwd_f32(const float* y, const float* dz, const float* gamma, const float* beta,
                         const float* mean, const float* invstd, float* dx, float* dgamma,
                         float* dbeta, float* workspace, int B, int H, int W, int C, int ph, int pw,

@@ -125,9 +125,13 @@ __global__ __launch_bounds__(kFinCh * 16) void bn_finalize_kernel(
 
 // relu(scale * y + shift) at the ph x pw window of pooled position (b, ho, wo), channel quad q;
 // returns the maximum and (through *arg) the index i * pw + j of its FIRST occurrence.
+// If `raw` is given it receives y itself at that first maximum (what the backward's xhat needs:
+// re-reading it by index is a dependent scalar gather per channel).
 __device__ __forceinline__ f4 window_max(const f4* __restrict__ y, const BnShape& s, long long b,
-                                         int ho, int wo, int q, f4 scale, f4 shift, int arg[4]) {
+                                         int ho, int wo, int q, f4 scale, f4 shift, int arg[4],
+                                         f4* raw = nullptr) {
   f4 best = {-1.f, -1.f, -1.f, -1.f};                 // relu output is >= 0: any value beats this
+  f4 vb = {0.f, 0.f, 0.f, 0.f};
   for (int i = 0; i < s.ph; ++i)
     for (int j = 0; j < s.pw; ++j) {
       const long long row = (b * s.H + (ho * s.ph + i)) * s.W + (wo * s.pw + j);
@@ -140,16 +144,18 @@ __device__ __forceinline__ f4 window_max(const f4* __restrict__ y, const BnShape
         if (r > best[e]) {
           best[e] = r;
           arg[e] = idx;
+          vb[e] = v[e];
         }
       }
     }
+  if (raw) *raw = vb;
   return best;
 }
 
 __global__ __launch_bounds__(kBnThreads) void bnrp_apply_kernel(
     const f4* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ mean, const float* __restrict__ invstd, f4* __restrict__ z,
-    BnShape s) {
+    const float* __restrict__ mean, const float* __restrict__ invstd, const f4* __restrict__ skip,
+    f4* __restrict__ z, BnShape s) {
   const int q = threadIdx.x % s.Q;                    // fixed per thread: strides are multiples of Q
   const f4 g = *reinterpret_cast<const f4*>(gamma + 4 * q), bt = *reinterpret_cast<const f4*>(beta + 4 * q);
   const f4 mu = *reinterpret_cast<const f4*>(mean + 4 * q), is = *reinterpret_cast<const f4*>(invstd + 4 * q);
@@ -163,7 +169,9 @@ __global__ __launch_bounds__(kBnThreads) void bnrp_apply_kernel(
     const int ho = (int)(t % s.Ho);
     const long long b = t / s.Ho;
     int arg[4];
-    z[o] = window_max(y, s, b, ho, wo, q, scale, shift, arg);
+    f4 v = window_max(y, s, b, ho, wo, q, scale, shift, arg);
+    if (skip) v += skip[o];                           // residual connection (models.py:577, 581)
+    z[o] = v;
   }
 }
 
@@ -187,16 +195,13 @@ __global__ __launch_bounds__(kBnThreads) void bnrp_bwd_reduce_kernel(
     const int ho = (int)(t % s.Ho);
     const long long b = t / s.Ho;
     int arg[4];
-    const f4 best = window_max(y, s, b, ho, wo, q, scale, shift, arg);
+    f4 vraw;
+    const f4 best = window_max(y, s, b, ho, wo, q, scale, shift, arg, &vraw);
     const f4 d = dz[o];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (best[e] > 0.f) {                            // ReLU passes the gradient at the arg-max
-        // xhat at the arg-max from its activation: a = gamma * xhat + beta
-        const int i = arg[e] / s.pw, j = arg[e] - i * s.pw;
-        const long long row = (b * s.H + (ho * s.ph + i)) * s.W + (wo * s.pw + j);
-        const float v = reinterpret_cast<const float*>(y)[(row * s.Q + q) * 4 + e];
-        const float xh = (v - mu[e]) * is[e];
+        const float xh = (vraw[e] - mu[e]) * is[e];   // xhat at the arg-max
         s1[e] += d[e];
         s2[e] = fmaf(d[e], xh, s2[e]);
       }
@@ -319,14 +324,14 @@ extern "C" long long pcgmix_bnrp_workspace_floats(int B, int H, int W, int C) {
 
 extern "C" int pcgmix_bnrp_fwd_f32(const float* y, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum,
-                                   float eps, float* z, float* mean, float* invstd,
-                                   float* workspace, int B, int H, int W, int C, int ph, int pw,
-                                   pcgmix_stream_t stream) {
+                                   float eps, const float* skip, float* z, float* mean,
+                                   float* invstd, float* workspace, int B, int H, int W, int C,
+                                   int ph, int pw, pcgmix_stream_t stream) {
   using namespace pcgmix;
   BnShape s;
   if (!y || !gamma || !beta || !z || !mean || !invstd || !workspace || !bn_shape(&s, B, H, W, C, ph, pw))
     return hipErrorInvalidValue;
-  if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(z) |
+  if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(skip) |
        reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
        reinterpret_cast<uintptr_t>(mean) | reinterpret_cast<uintptr_t>(invstd)) & 15)
     return hipErrorInvalidValue;
@@ -340,7 +345,7 @@ extern "C" int pcgmix_bnrp_fwd_f32(const float* y, const float* gamma, const flo
   const long long n_out = (long long)B * s.Ho * s.Wo * s.Q;
   hipLaunchKernelGGL(bnrp_apply_kernel, dim3(bn_blocks(n_out * 2)), dim3(kBnThreads), 0, st,
                      reinterpret_cast<const f4*>(y), gamma, beta, mean, invstd,
-                     reinterpret_cast<f4*>(z), s);
+                     reinterpret_cast<const f4*>(skip), reinterpret_cast<f4*>(z), s);
   return (int)hipGetLastError();
 }
 

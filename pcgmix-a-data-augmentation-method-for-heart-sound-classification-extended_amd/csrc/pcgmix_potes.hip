@@ -19,6 +19,7 @@
 // bounded by HBM, not MFMA work.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <cmath>
 
@@ -1090,7 +1091,12 @@ extern "C" int pcgmix_potes_bwd_blocks(int N, int T) {
   if (N <= 0 || T < 14) return 0;
   const pcgmix::PotesDims d = pcgmix::potes_dims(T);
   const long long work = (long long)N * ((d.P2 + 2 + pcgmix::kBwdTP - 1) / pcgmix::kBwdTP);  // = tiles
-  return (int)(work < 768 ? work : 768);  // 3 persistent blocks per CU (146 VGPRs: 3 waves per SIMD)
+  long long cap = 768;  // 3 persistent blocks per CU
+  if (const char* env = getenv("PCGMIX_POTES_BWD_BLOCKS")) {   // tuning runs
+    const long long v = atoll(env);
+    if (v >= 1 && v <= 65535) cap = v;
+  }
+  return (int)(work < cap ? work : cap);
 }
 
 extern "C" int pcgmix_potes_stack_fwd_f32(const float* x, const float* w1, const float* b1,

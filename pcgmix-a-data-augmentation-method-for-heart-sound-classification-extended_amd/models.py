@@ -355,8 +355,11 @@ class BNReLUPoolFunction(torch.autograd.Function):
                 and y.is_contiguous(memory_format=torch.channels_last))
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum, eps, ph, pw):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum, eps, ph, pw, skip=None):
         B, C, H, W = y.shape
+        if skip is not None and (skip.shape != (B, C, H // ph, W // pw) or skip.dtype != torch.float32
+                                 or not skip.is_contiguous(memory_format=torch.channels_last)):
+            raise ValueError("skip must be a float32 channels_last tensor shaped like the output")
         lib = _lib.load()
         dev = y.device
         z = torch.empty((B, C, H // ph, W // pw), dtype=torch.float32, device=dev,
@@ -370,10 +373,12 @@ class BNReLUPoolFunction(torch.autograd.Function):
             y.data_ptr(), g.data_ptr(), b.data_ptr(),
             running_mean.data_ptr() if running_mean is not None else None,
             running_var.data_ptr() if running_var is not None else None,
-            ctypes.c_float(momentum), ctypes.c_float(eps), z.data_ptr(), mean.data_ptr(),
+            ctypes.c_float(momentum), ctypes.c_float(eps),
+            skip.data_ptr() if skip is not None else None, z.data_ptr(), mean.data_ptr(),
             invstd.data_ptr(), ws.data_ptr(), B, H, W, C, ph, pw, stream), "pcgmix_bnrp_fwd_f32")
         ctx.save_for_backward(y, g, b, mean, invstd)
         ctx.pool = (ph, pw)
+        ctx.has_skip = skip is not None
         return z
 
     @staticmethod
@@ -393,10 +398,11 @@ class BNReLUPoolFunction(torch.autograd.Function):
             y.data_ptr(), dz.data_ptr(), g.data_ptr(), b.data_ptr(), mean.data_ptr(),
             invstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
             B, H, W, C, ph, pw, stream), "pcgmix_bnrp_bwd_f32")
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        # the residual input enters by a plain addition: its gradient is dz itself
+        return dx, dgamma, dbeta, None, None, None, None, None, None, (dz if ctx.has_skip else None)
 
 
-def conv_bn_relu_pool(h, weight4, conv_bias, padding, bn, training: bool, pool):
+def conv_bn_relu_pool(h, weight4, conv_bias, padding, bn, training: bool, pool, skip=None):
     """Conv -> BatchNorm -> ReLU [-> MaxPool] on a 4-D (channels_last) activation with the
     convolution's bias folded into the BatchNorm instead of added by a separate pass.
 
@@ -430,8 +436,10 @@ def conv_bn_relu_pool(h, weight4, conv_bias, padding, bn, training: bool, pool):
                 bn.running_mean.add_(conv_bias, alpha=bn.momentum / (1.0 - bn.momentum))
         if FUSED_BN and training and bn.track_running_stats and BNReLUPoolFunction.supported(h):
             ph, pw = (1, 1) if pool is None else ((pool, pool) if isinstance(pool, int) else pool)
+            if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
+                skip = skip.contiguous(memory_format=torch.channels_last)
             return BNReLUPoolFunction.apply(h, bn.weight, beta, bn.running_mean, bn.running_var,
-                                            float(bn.momentum), float(bn.eps), int(ph), int(pw))
+                                            float(bn.momentum), float(bn.eps), int(ph), int(pw), skip)
         if FUSED_BN and training and h.is_cuda:
             _warn_once(f"conv_bn_relu_pool: activation {tuple(h.shape)} {h.dtype} cannot use the HIP "
                        "BatchNorm+ReLU+pool kernels (needs float32 channels_last, C % 4 == 0, "
@@ -444,7 +452,7 @@ def conv_bn_relu_pool(h, weight4, conv_bias, padding, bn, training: bool, pool):
     h = F.relu(h, inplace=True)
     if pool is not None:
         h = F.max_pool2d(h, pool)
-    return h
+    return h if skip is None else h + skip
 
 
 class ResNet9_myrtle(nn.Module):
@@ -472,20 +480,22 @@ class ResNet9_myrtle(nn.Module):
     # (profiles/probes/resnet1d_layout_probe.py), logits equal to 1e-5.
     nhwc = True
 
-    def _block(self, seq, h):
+    def _block(self, seq, h, skip=None):
+        """One conv block; ``skip`` = the residual input added to the block's output (the add is
+        fused into the BatchNorm/ReLU kernel on the HIP path)."""
         if h.dim() == 3:
-            return seq(h)
+            return seq(h) if skip is None else seq(h) + skip
         pool = (1, seq[3].kernel_size) if len(seq) > 3 else None
         return conv_bn_relu_pool(h, seq[0].weight.unsqueeze(2), seq[0].bias, (0, seq[0].padding[0]),
-                                 seq[1], self.training, pool)
+                                 seq[1], self.training, pool, skip)
 
     def _stage1(self, out):
         out = self._block(self.conv2, self._block(self.conv1, out))
-        return self._block(self.res1[1], self._block(self.res1[0], out)) + out
+        return self._block(self.res1[1], self._block(self.res1[0], out), skip=out)   # res1(out) + out
 
     def _stage2(self, out):
         out = self._block(self.conv4, self._block(self.conv3, out))
-        return self._block(self.res2[1], self._block(self.res2[0], out)) + out
+        return self._block(self.res2[1], self._block(self.res2[0], out), skip=out)   # res2(out) + out
 
     def _pool_flat(self, out):
         if out.dim() == 3:

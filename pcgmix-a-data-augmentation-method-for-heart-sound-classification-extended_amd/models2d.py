@@ -35,27 +35,35 @@ class ResNet9_myrtle(nn.Module):
         # Values, state_dict keys and shapes are unchanged (a memory format, not a reshape).
         self.to(memory_format=torch.channels_last)
 
-    def _block(self, seq, h):
+    def _block(self, seq, h, skip=None):
         if not h.is_cuda:
-            return seq(h)
+            return seq(h) if skip is None else seq(h) + skip
         from .models import conv_bn_relu_pool               # bias folded into the BatchNorm
         pool = seq[3].kernel_size if len(seq) > 3 else None
         return conv_bn_relu_pool(h, seq[0].weight, seq[0].bias, seq[0].padding, seq[1],
-                                 self.training, pool)
+                                 self.training, pool, skip)
 
     def _stage1(self, out):
         out = self._block(self.conv2, self._block(self.conv1, out))
-        return self._block(self.res1[1], self._block(self.res1[0], out)) + out
+        return self._block(self.res1[1], self._block(self.res1[0], out), skip=out)   # res1(out) + out
 
     def _stage2(self, out):
         out = self._block(self.conv4, self._block(self.conv3, out))
-        return self._block(self.res2[1], self._block(self.res2[0], out)) + out
+        return self._block(self.res2[1], self._block(self.res2[0], out), skip=out)   # res2(out) + out
 
     def forward(self, out, depth=None, pass_part=None):
         if pass_part == "first" and depth == 0:
             return out
         if out.is_cuda and out.dim() == 4:
             out = out.contiguous(memory_format=torch.channels_last)
+            if out.shape[1] == 1 and out.is_contiguous():
+                # A one-channel image is both NCHW- and NHWC-dense, and torch resolves the tie to
+                # NCHW: conv1 then runs as an NCHW convolution, its 1 GB output comes back NCHW and
+                # is re-laid-out three times on the way to conv2 (1.4 ms of an 85 ms bs=256 step,
+                # profiles/r2_resnet2d_step_kernels.csv).  Stating the NHWC strides explicitly
+                # (same memory) makes the whole network channels_last from the first layer on.
+                B, _, H, W = out.shape
+                out = out.as_strided((B, 1, H, W), (H * W, 1, W, 1))
         if pass_part == "first":
             out = self._stage1(out)
             if depth == 1:
