@@ -378,7 +378,7 @@ def secondary_kernel_times(device, B=256, iters=50):
     return out
 
 
-def cfg3_salopt(device, steps=30, warmup=5, B=256, C=4, T=5000):
+def cfg3_salopt(device, steps=100, warmup=10, B=256, C=4, T=5000, reps=3):
     """BASELINE.json configs[2]: (saloptenv)durmixmagwarp(0.2,4) — saliency from a frozen copy of
     the 1D-CNN (one fwd+bwd through torch), then the three HIP kernels (saliency post-processing,
     displacement search, splice+warp) with no host round trip in between."""
@@ -387,12 +387,15 @@ def cfg3_salopt(device, steps=30, warmup=5, B=256, C=4, T=5000):
     _, data, tgt, frames, labels, wav = make_device_batch(B, C, T, 2000, 7, device)
     torch.manual_seed(4)
     saliency.set_saliency_model(models.CNN_potes_TS(4, 2, "PhysioNet", sig_len=T).to(device))
-    try:
-        dt, _ = run_augment_steps(method, data, tgt, frames, wav, device, steps, warmup, lambda: None)
+    try:    # a few repeats: the first one carries one-time costs (graph capture, pinned buffers)
+        dts = [run_augment_steps(method, data, tgt, frames, wav, device, steps, warmup, lambda: None)[0]
+               for _ in range(reps)]
     finally:
         saliency.set_saliency_model(None)
+    dt = sorted(dts)[len(dts) // 2]                       # median repeat
     return {"method": method, "shape": [B, C, T], "samples_per_s": B * steps / dt,
-            "ms_per_step": 1e3 * dt / steps, "saliency_model": "CNN_potes (frozen copy)"}
+            "ms_per_step": 1e3 * dt / steps, "ms_per_step_repeats": [1e3 * d / steps for d in dts],
+            "steps": steps, "saliency_model": "CNN_potes (frozen copy)"}
 
 
 def cfg4_spectrogram(device, steps=8, warmup=2, B=256, T=5000):

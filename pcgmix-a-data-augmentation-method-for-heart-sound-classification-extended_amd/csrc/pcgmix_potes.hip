@@ -97,10 +97,12 @@ template <bool SWZ>
 __device__ __forceinline__ void layer1_t(const PotesWeights& W, const float* xs, float* a1s,
                                          uint8_t* sel, int qlo, int nq, int P1, int xplane,
                                          int aplane, uint8_t* __restrict__ s1g = nullptr,
-                                         int own_lo = 0, int own_hi = 0) {
-  const int groups = nq / 4;
+                                         int own_lo = 0, int own_hi = 0, int g_first = 0) {
+  // groups g_first .. nq/4-1 of every channel (g_first > 0: the caller never reads the first
+  // 4*g_first positions and the remaining items fill whole rounds of the block)
+  const int groups = nq / 4 - g_first;
   for (int item = threadIdx.x; item < kC1 * groups; item += kPotThreads) {
-    const int ci = item / groups, g = item - ci * groups;
+    const int ci = item / groups, g = g_first + item - ci * groups;
     float xw[12], w[kK];
     if (SWZ) {
       const f4 a = *reinterpret_cast<const f4*>(xs + 4 * g),
@@ -178,8 +180,8 @@ __device__ __forceinline__ void layer1_t(const PotesWeights& W, const float* xs,
 }
 
 __device__ __forceinline__ void layer1(const PotesWeights& W, const float* xs, float* a1s,
-                                       uint8_t* sel, int qlo, int nq, int P1) {
-  layer1_t<false>(W, xs, a1s, sel, qlo, nq, P1, 0, 0);
+                                       uint8_t* sel, int qlo, int nq, int P1, int g_first = 0) {
+  layer1_t<false>(W, xs, a1s, sel, qlo, nq, P1, 0, 0, nullptr, 0, 0, g_first);
 }
 
 // ---------------------------------------------------------------------------------- forward
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
   constexpr int kDz2Row = kBwdNJ + 12;
   const PotesDims d = potes_dims(T);
   const int tiles = potes_bwd_tiles(d);
-  const long long work = (long long)N * tiles;
+  const unsigned work = (unsigned)N * (unsigned)tiles;     // N <= 65535 rows, tiles < 2^15
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   load_weights(&W, w1, b1, w2, b2);
   for (int i = threadIdx.x; i < kC2 * kDz2Row; i += kPotThreads) dz2s[i] = 0.f;
@@ -370,8 +372,8 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
   float xr[kXPer], gr[2];
   uint32_t mr[2] = {0u, 0u};
   const int m2s = (d.P2 + 3) / 4;
-  auto prefetch = [&](long long it) {
-    const int n = (int)(it / tiles), p0 = (int)(it - (long long)n * tiles) * kBwdTP;
+  auto prefetch = [&](unsigned it) {
+    const int n = (int)(it / (unsigned)tiles), p0 = (int)(it - (unsigned)n * (unsigned)tiles) * kBwdTP;
     const int xlo = 2 * (2 * p0 - 5) - 1;
     const float* xrow = x + (size_t)n * T;
 #pragma unroll
@@ -389,10 +391,10 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
                     : 0u;
     }
   };
-  if ((long long)blockIdx.x < work) prefetch(blockIdx.x);
+  if (blockIdx.x < work) prefetch(blockIdx.x);
 
-  for (long long item = blockIdx.x; item < work; item += gridDim.x) {
-    const int n = (int)(item / tiles), p0 = (int)(item - (long long)n * tiles) * kBwdTP;
+  for (unsigned item = blockIdx.x; item < work; item += gridDim.x) {
+    const int n = (int)(item / (unsigned)tiles), p0 = (int)(item - (unsigned)n * (unsigned)tiles) * kBwdTP;
     const int qlo = 2 * p0 - 5;
     (void)n;
     __syncthreads();  // previous item's LDS fully consumed
@@ -413,7 +415,10 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
     }
     if (item + gridDim.x < work) prefetch(item + gridDim.x);
     __syncthreads();
-    layer1(W, xs, a1s, sel1, qlo, kBwdNQ, d.P1);
+    // Without the conv2 recompute nothing reads a1s[0..3] / sel1[0..4] (the weight gradient reads
+    // a1 from index 4, the routing from index 5): 64 groups x 8 channels = exactly two rounds of
+    // the block instead of two and a 8-thread third.
+    layer1(W, xs, a1s, sel1, qlo, kBwdNQ, d.P1, MASK ? 1 : 0);
     __syncthreads();
     if (!MASK) {  // conv2 + ReLU + pool on the extended range -> dz2 = dL/dz2 (wave = co, 2 pooled per lane)
       const int co = __builtin_amdgcn_readfirstlane(wave);
@@ -1154,7 +1159,7 @@ extern "C" int pcgmix_potes_stack_bwd_f32(const float* x, const float* grad_h2, 
                                           float* partial, float* grads, int N, int T,
                                           pcgmix_stream_t stream) {
   using namespace pcgmix;
-  if (!x || !grad_h2 || !w1 || !b1 || !w2 || !b2 || !partial || !grads || N <= 0 || T < 14)
+  if (!x || !grad_h2 || !w1 || !b1 || !w2 || !b2 || !partial || !grads || N <= 0 || N > 65535 || T < 14)
     return hipErrorInvalidValue;
   const int G = pcgmix_potes_bwd_blocks(N, T);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1169,7 +1174,7 @@ extern "C" int pcgmix_potes_stack_bwd_mask_f32(const float* x, const float* grad
                                                const float* w2, const float* b2, float* partial,
                                                float* grads, int N, int T, pcgmix_stream_t stream) {
   using namespace pcgmix;
-  if (!x || !grad_h2 || !m2 || !w1 || !b1 || !w2 || !b2 || !partial || !grads || N <= 0 || T < 14)
+  if (!x || !grad_h2 || !m2 || !w1 || !b1 || !w2 || !b2 || !partial || !grads || N <= 0 || N > 65535 || T < 14)
     return hipErrorInvalidValue;
   const int G = pcgmix_potes_bwd_blocks(N, T);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
