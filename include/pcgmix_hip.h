@@ -166,10 +166,14 @@ int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames, float* sa
  *
  *   sal         device, (B, T) saliency maps
  *   disp        device, int32 (B, 4) out — feeds pcgmix_mix_warp_f32's `off`
+ *   workspace   device, pcgmix_salopt_workspace_bytes(B) bytes, 8-byte aligned: the candidates of
+ *               one (sample, state) are shared out over several blocks; their partial arg-maxima
+ *               meet here (greatest value, smallest displacement on ties = first strict maximum)
  *   B <= 65535, T <= 19000
  */
+long long pcgmix_salopt_workspace_bytes(int B);
 int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames, const int32_t* mix_idx,
-                           float lam, int mode, int32_t* disp, int B, int T,
+                           float lam, int mode, int32_t* disp, void* workspace, int B, int T,
                            pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

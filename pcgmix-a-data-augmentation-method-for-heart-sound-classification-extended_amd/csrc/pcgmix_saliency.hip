@@ -238,12 +238,20 @@ __device__ __forceinline__ float pw_sum(F elem, int n) {
   }
 }
 
-// One block per (state k, sample b); candidates d are strided over the lanes.
+// kDispSplit blocks per (state k, sample b): block z takes the candidates d = 256 z + lane,
+// + 1024, ...  The cost of a (sample, state) pair grows with the square of its length gap, and with
+// one block per pair the launch lasted as long as its single heaviest pair (one CU busy for 60 us
+// at bs=256 while most of the chip had finished: profiles/r2_cfg3_step_kernels.csv); four blocks
+// per pair cut the longest block by four.  Every block writes its first strict maximum (value,
+// displacement) to `part`; salopt_finalize_kernel picks the greatest value, smallest displacement
+// on ties — the first strict maximum of the reference's ascending scan (augmentations.py:76).
 // LDS: lng[nL] (the longer state's saliency), sht[nS] (the shorter one's).
+constexpr int kDispSplit = 4;
+
 template <int MODE>  // 0: envelope (max), 1: lambda-weighted sum
 __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
     const float* __restrict__ sal, const int32_t* __restrict__ frames,
-    const int32_t* __restrict__ mix_idx, float lam, float oml, int32_t* __restrict__ disp, int B,
+    const int32_t* __restrict__ mix_idx, float lam, float oml, float2* __restrict__ part, int B,
     int T) {
   extern __shared__ __align__(16) float smem[];
   __shared__ float best_v[kDispThreads / 64];
@@ -251,8 +259,9 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   // Sample index fastest, states ordered by expected work (diastole, systole, S1, S2): with the
   // state as the fast index and a batch that is a multiple of 4, round-robin dispatch handed every
   // diastole block (the long ones) to the same quarter of the CUs.
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, z = blockIdx.z;
   const int k = (0x2013 >> (4 * blockIdx.y)) & 3;   // blockIdx.y 0,1,2,3 -> state 3,1,0,2
+  float2* out = part + ((size_t)b * 4 + k) * kDispSplit + z;
   int m = mix_idx[b];
   m = (m < 0 || m >= B) ? b : m;
   int a1 = frames[b * 5 + k], e1 = frames[b * 5 + k + 1];
@@ -262,12 +271,12 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   a2 = a2 < 0 ? 0 : (a2 > T ? T : a2);
   e2 = e2 < a2 ? a2 : (e2 > T ? T : e2);
   const int n1 = e1 - a1, n2 = e2 - a2;
-  if (n1 == n2) {  // equal lengths: no search (augmentations.py:226-229)
-    if (threadIdx.x == 0) disp[b * 4 + k] = 0;
-    return;
-  }
   const bool own_longer = n1 > n2;
   const int nL = own_longer ? n1 : n2, nS = own_longer ? n2 : n1;
+  if (n1 == n2 || z * kDispThreads > nL - nS) {  // no search (:226-229) / no candidate for this block
+    if (threadIdx.x == 0) *out = float2{-INFINITY, __int_as_float(0x7fffffff)};
+    return;
+  }
   const float* gl = sal + (size_t)(own_longer ? b : m) * T + (own_longer ? a1 : a2);
   const float* gs = sal + (size_t)(own_longer ? m : b) * T + (own_longer ? a2 : a1);
   float* lng = smem;
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
 
   float bv = -INFINITY;
   int bd = 0x7fffffff;
-  for (int d = threadIdx.x; d <= nL - nS; d += kDispThreads) {
+  for (int d = z * kDispThreads + threadIdx.x; d <= nL - nS; d += kDispSplit * kDispThreads) {
     const SeqMid<MODE> mid{lng + d, sht, lam, oml, own_longer};
     float cur = pw_sum(mid, nS);
     if (own_longer) {  // np.sum(s1[:d]) + np.sum(mid) + np.sum(s1[d+n2:])   (:76-78, :111-113)
@@ -312,8 +321,26 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
         bv = best_v[i];
         bd = best_d[i];
       }
-    disp[b * 4 + k] = (bd == 0x7fffffff) ? 0 : bd;  // all-NaN objective: reference keeps 0
+    *out = float2{bv, __int_as_float(bd)};
   }
+}
+
+__global__ void salopt_finalize_kernel(const float2* __restrict__ part, int32_t* __restrict__ disp,
+                                       int n /* B * 4 */) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float bv = -INFINITY;
+  int bd = 0x7fffffff;
+#pragma unroll
+  for (int z = 0; z < kDispSplit; ++z) {
+    const float2 p = part[(size_t)i * kDispSplit + z];
+    const int d = __float_as_int(p.y);
+    if (p.x > bv || (p.x == bv && d < bd)) {
+      bv = p.x;
+      bd = d;
+    }
+  }
+  disp[i] = (bd == 0x7fffffff) ? 0 : bd;  // equal lengths, or an all-NaN objective: the reference keeps 0
 }
 
 }  // namespace pcgmix
@@ -356,12 +383,17 @@ extern "C" int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames
   return (int)hipGetLastError();
 }
 
+extern "C" long long pcgmix_salopt_workspace_bytes(int B) {
+  return B <= 0 ? 0 : (long long)B * 4 * pcgmix::kDispSplit * (long long)sizeof(float2);
+}
+
 extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
                                       const int32_t* mix_idx, float lam, int mode, int32_t* disp,
-                                      int B, int T, pcgmix_stream_t stream) {
+                                      void* workspace, int B, int T, pcgmix_stream_t stream) {
   using namespace pcgmix;
-  if (!sal || !frames || !mix_idx || !disp) return hipErrorInvalidValue;
-  if (B < 0 || T <= 0 || (mode != 0 && mode != 1)) return hipErrorInvalidValue;
+  if (!sal || !frames || !mix_idx || !disp || !workspace) return hipErrorInvalidValue;
+  if (B < 0 || B > 65535 || T <= 0 || (mode != 0 && mode != 1)) return hipErrorInvalidValue;
+  if (reinterpret_cast<uintptr_t>(workspace) & 7) return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
   const size_t lds = sizeof(float) * (size_t)2 * T;
   if (lds > 150 * 1024) return hipErrorInvalidValue;
@@ -373,13 +405,16 @@ extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
                                      150 * 1024))
     return (int)e;
   const float oml = 1.0f - lam;
-  dim3 grid((unsigned)B, 4), block(kDispThreads);
+  dim3 grid((unsigned)B, 4, kDispSplit), block(kDispThreads);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  float2* part = static_cast<float2*>(workspace);
   if (mode == 0)
     hipLaunchKernelGGL(salopt_disp_kernel<0>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
-                       disp, B, T);
+                       part, B, T);
   else
     hipLaunchKernelGGL(salopt_disp_kernel<1>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
-                       disp, B, T);
+                       part, B, T);
+  hipLaunchKernelGGL(salopt_finalize_kernel, dim3((unsigned)((B * 4 + 255) / 256)), dim3(256), 0, s,
+                     part, disp, B * 4);
   return (int)hipGetLastError();
 }

@@ -229,7 +229,9 @@ def test_bad_arguments(device):
     assert lib.pcgmix_saliency_post_f32(z.data_ptr(), z.data_ptr(), z.data_ptr(), 100,
                                         ctypes.c_double(12.0), 1, 1, 8, None) != 0     # even ksize
     assert lib.pcgmix_salopt_disp_f32(z.data_ptr(), z.data_ptr(), z.data_ptr(), ctypes.c_float(0.5),
-                                      2, z.data_ptr(), 1, 8, None) != 0               # bad mode
+                                      2, z.data_ptr(), z.data_ptr(), 1, 8, None) != 0  # bad mode
+    assert lib.pcgmix_salopt_disp_f32(z.data_ptr(), z.data_ptr(), z.data_ptr(), ctypes.c_float(0.5),
+                                      0, z.data_ptr(), None, 1, 8, None) != 0          # no workspace
 
 
 def test_displacements_full_batch_vs_oracle(device):
@@ -274,3 +276,27 @@ def test_graphed_saliency_equals_eager(device):
     finally:
         saliency.USE_GRAPHS = True
         saliency.set_saliency_model(None)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_displacements_long_gaps_vs_oracle(mode, device):
+    """Length gaps beyond one pass of the candidate split (> 1024 candidates per state) and gaps
+    that leave some of the split's blocks without a candidate, against the numpy oracle."""
+    B, T = 6, 9000
+    frames = np.array([[0, 300, 2800, 3100, 8900], [0, 200, 700, 1000, 3400], [0, 310, 2000, 2300, 6000],
+                       [0, 100, 350, 500, 900], [0, 300, 2800, 3100, 8900], [0, 250, 1400, 1650, 1660]],
+                      dtype=np.int64)
+    rs = np.random.RandomState(10 + mode)
+    sal = (rs.rand(B, T) ** 3).astype(np.float32)
+    sal[np.arange(T)[None, :] >= frames[:, 4:5]] = 0
+    mix = np.array([1, 0, 3, 2, 5, 4])
+    lam = np.float32(0.4142)
+    lam_np = np.full((1, 1), lam, dtype=np.float32)
+    tag = "(saloptenv)" if mode == 0 else "(saloptsum)"
+    ref = np.stack([O.salopt_displacements(sal[i], sal[mix[i]], frames[i], frames[mix[i]], lam_np, tag)
+                    for i in range(B)])
+    fr, mx = dev_i32(frames, device), dev_i32(mix, device)
+    got = saliency.optimal_displacements(torch.from_numpy(sal).to(device), fr.data_ptr(), mx.data_ptr(),
+                                         float(lam), mode, B, T)
+    assert np.array_equal(got.cpu().numpy().astype(np.int64), ref)
+    assert ref.max() > 1024 or (np.abs(np.diff(frames, axis=1)[mix] - np.diff(frames, axis=1)).max() > 1024)
