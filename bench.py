@@ -364,7 +364,8 @@ def secondary_kernel_times(device, B=256, iters=50):
     mix = torch.from_numpy(np.random.RandomState(0).permutation(B).astype(np.int32)).to(device)
     for mode, name in ((0, "env"), (1, "sum")):
         out[f"salopt_disp_{name}_256x5000"] = entry(
-            timeit(lambda: saliency.optimal_displacements(sal, fr.data_ptr(), mix.data_ptr(), 0.37, mode, B, T)),
+            timeit(lambda: saliency.optimal_displacements(sal, fr.data_ptr(), mix.data_ptr(), 0.37, mode, B, T,
+                                                          max_len=int(np.diff(frames, axis=1).max()))),
             B * 8 * T)
     spec, fs = frontend.logmel(x1, frames)
     tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)

@@ -195,7 +195,8 @@ def apply_plan(plan: MixPlan, data: torch.Tensor, frames: np.ndarray,
                 raise ValueError("saliency-guided mixing needs saliency maps")
             from . import saliency as _sal
             disp = _sal.optimal_displacements(saliency_maps, frames_ptr, mix_ptr,
-                                              float(plan.lam32), plan.salopt_mode, B, T)
+                                              float(plan.lam32), plan.salopt_mode, B, T,
+                                              max_len=int(np.diff(frames, axis=1).max()))
             keep.append(disp)
             off_ptr = disp.data_ptr()
         knots_ptr = op_ptr = None

@@ -18,7 +18,7 @@
 namespace pcgmix {
 
 constexpr int kSalThreads = 640;   // saliency_post: one block per row (625 x 8 outputs at T = 5000)
-constexpr int kDispThreads = 1024; // displacement scan: all candidates of a (sample, state) at once
+constexpr int kDispThreads = 256;  // displacement scan: 4 waves per block, every one with work
 constexpr int kMaxTaps = 255;
 
 struct Taps {
@@ -175,7 +175,14 @@ struct SeqMid {                 // op(l[i], s[i]); own_longer decides which one 
   float lam, oml;
   bool own_longer;
   __device__ __forceinline__ float op(float lv, float sv) const {
-    if (MODE == 0) return fmaxf(lv, sv);
+    if (MODE == 0) {
+      // np.maximum on finite values.  fmaxf() compiles to v_max_f32 PLUS one canonicalising
+      // v_max_f32 x, x per operand (IEEE quieting of signalling NaNs): three instructions where
+      // one does the work — the saliency maps hold no NaN (saliency.py:87 replaces them by 0).
+      float r;
+      asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(lv), "v"(sv));
+      return r;
+    }
     const float s1 = own_longer ? lv : sv, s2 = own_longer ? sv : lv;
     return __fadd_rn(__fmul_rn(s1, lam), __fmul_rn(s2, oml));   // s1*lam + s2*(1-lam)
   }
@@ -238,13 +245,16 @@ __device__ __forceinline__ float pw_sum(F elem, int n) {
   }
 }
 
-// kDispSplit blocks per (state k, sample b): block z takes the candidates d = 256 z + lane,
-// + 1024, ...  The cost of a (sample, state) pair grows with the square of its length gap, and with
-// one block per pair the launch lasted as long as its single heaviest pair (one CU busy for 60 us
-// at bs=256 while most of the chip had finished: profiles/r2_cfg3_step_kernels.csv); four blocks
-// per pair cut the longest block by four.  Every block writes its first strict maximum (value,
-// displacement) to `part`; salopt_finalize_kernel picks the greatest value, smallest displacement
-// on ties — the first strict maximum of the reference's ascending scan (augmentations.py:76).
+// kDispSplit blocks of 256 threads per (state k, sample b): block z takes the candidates
+// d = 256 z + lane, + 1024, ...; a block without a candidate exits at once.  Round 1 ran ONE
+// 1024-thread block per pair with 2*T floats of LDS: two blocks per CU, and of their 32 waves
+// only the ~10 that held a candidate worked — the rest sat at the closing barrier and kept the
+// wave slots (SQ counters, profiles/r2_disp_sq_counters.json: 75 % of all wave-cycles waiting,
+// VALU issue 20 % of the launch).  Small blocks whose LDS is sized by the longest heart state of
+// the batch (`max_len`, known on the host) put eight working blocks on a CU.  Every block
+// writes its first strict maximum (value, displacement) to `part`; salopt_finalize_kernel picks
+// the greatest value, smallest displacement on ties — the first strict maximum of the reference's
+// ascending scan (augmentations.py:76).
 // LDS: lng[nL] (the longer state's saliency), sht[nS] (the shorter one's).
 constexpr int kDispSplit = 4;
 
@@ -252,7 +262,7 @@ template <int MODE>  // 0: envelope (max), 1: lambda-weighted sum
 __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
     const float* __restrict__ sal, const int32_t* __restrict__ frames,
     const int32_t* __restrict__ mix_idx, float lam, float oml, float2* __restrict__ part, int B,
-    int T) {
+    int T, int max_len) {
   extern __shared__ __align__(16) float smem[];
   __shared__ float best_v[kDispThreads / 64];
   __shared__ int best_d[kDispThreads / 64];
@@ -270,6 +280,8 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   e1 = e1 < a1 ? a1 : (e1 > T ? T : e1);
   a2 = a2 < 0 ? 0 : (a2 > T ? T : a2);
   e2 = e2 < a2 ? a2 : (e2 > T ? T : e2);
+  e1 = e1 - a1 > max_len ? a1 + max_len : e1;       // memory safety: LDS holds 2 * max_len floats
+  e2 = e2 - a2 > max_len ? a2 + max_len : e2;       // (the caller passes the true maximum)
   const int n1 = e1 - a1, n2 = e2 - a2;
   const bool own_longer = n1 > n2;
   const int nL = own_longer ? n1 : n2, nS = own_longer ? n2 : n1;
@@ -389,13 +401,15 @@ extern "C" long long pcgmix_salopt_workspace_bytes(int B) {
 
 extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
                                       const int32_t* mix_idx, float lam, int mode, int32_t* disp,
-                                      void* workspace, int B, int T, pcgmix_stream_t stream) {
+                                      void* workspace, int max_len, int B, int T,
+                                      pcgmix_stream_t stream) {
   using namespace pcgmix;
   if (!sal || !frames || !mix_idx || !disp || !workspace) return hipErrorInvalidValue;
   if (B < 0 || B > 65535 || T <= 0 || (mode != 0 && mode != 1)) return hipErrorInvalidValue;
   if (reinterpret_cast<uintptr_t>(workspace) & 7) return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
-  const size_t lds = sizeof(float) * (size_t)2 * T;
+  if (max_len <= 0 || max_len > T) max_len = T;
+  const size_t lds = sizeof(float) * (size_t)2 * (size_t)((max_len + 3) & ~3);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
   static unsigned long long lds_ok0 = 0, lds_ok1 = 0;
   if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(salopt_disp_kernel<0>), &lds_ok0,
@@ -410,10 +424,10 @@ extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
   float2* part = static_cast<float2*>(workspace);
   if (mode == 0)
     hipLaunchKernelGGL(salopt_disp_kernel<0>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
-                       part, B, T);
+                       part, B, T, max_len);
   else
     hipLaunchKernelGGL(salopt_disp_kernel<1>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
-                       part, B, T);
+                       part, B, T, max_len);
   hipLaunchKernelGGL(salopt_finalize_kernel, dim3((unsigned)((B * 4 + 255) / 256)), dim3(256), 0, s,
                      part, disp, B * 4);
   return (int)hipGetLastError();

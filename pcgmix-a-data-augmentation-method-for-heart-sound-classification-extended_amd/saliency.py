@@ -183,9 +183,10 @@ def get_saliency_maps(args, device, data, target_ohe, frames, dim=1, gauss_k_n=1
 
 
 def optimal_displacements(saliency_maps: torch.Tensor, frames_dev_ptr: int, mix_dev_ptr: int,
-                          lam: float, mode: int, B: int, T: int) -> torch.Tensor:
+                          lam: float, mode: int, B: int, T: int, max_len: int = 0) -> torch.Tensor:
     """Displacement of the shorter state inside the longer one for every (sample, state):
-    int32 (B,4) on device (augmentations.py:60-128 via pcgmix_salopt_disp_f32)."""
+    int32 (B,4) on device (augmentations.py:60-128 via pcgmix_salopt_disp_f32).  ``max_len``: the
+    longest heart state of the batch in samples (from the host copy of ``frames``); 0 = unknown."""
     if saliency_maps.shape != (B, T) or saliency_maps.dtype != torch.float32 \
             or not saliency_maps.is_contiguous() or not saliency_maps.is_cuda:
         raise ValueError("saliency maps must be a contiguous float32 (B, T) device tensor")
@@ -196,5 +197,6 @@ def optimal_displacements(saliency_maps: torch.Tensor, frames_dev_ptr: int, mix_
     stream = torch.cuda.current_stream(saliency_maps.device).cuda_stream
     _lib.check(lib.pcgmix_salopt_disp_f32(saliency_maps.data_ptr(), frames_dev_ptr, mix_dev_ptr,
                                           ctypes.c_float(lam), mode, disp.data_ptr(), ws.data_ptr(),
-                                          B, T, ctypes.c_void_p(stream)), "pcgmix_salopt_disp_f32")
+                                          int(max_len), B, T, ctypes.c_void_p(stream)),
+               "pcgmix_salopt_disp_f32")
     return disp

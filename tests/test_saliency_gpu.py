@@ -229,9 +229,9 @@ def test_bad_arguments(device):
     assert lib.pcgmix_saliency_post_f32(z.data_ptr(), z.data_ptr(), z.data_ptr(), 100,
                                         ctypes.c_double(12.0), 1, 1, 8, None) != 0     # even ksize
     assert lib.pcgmix_salopt_disp_f32(z.data_ptr(), z.data_ptr(), z.data_ptr(), ctypes.c_float(0.5),
-                                      2, z.data_ptr(), z.data_ptr(), 1, 8, None) != 0  # bad mode
+                                      2, z.data_ptr(), z.data_ptr(), 0, 1, 8, None) != 0  # bad mode
     assert lib.pcgmix_salopt_disp_f32(z.data_ptr(), z.data_ptr(), z.data_ptr(), ctypes.c_float(0.5),
-                                      0, z.data_ptr(), None, 1, 8, None) != 0          # no workspace
+                                      0, z.data_ptr(), None, 0, 1, 8, None) != 0       # no workspace
 
 
 def test_displacements_full_batch_vs_oracle(device):
