@@ -269,7 +269,12 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   // Sample index fastest, states ordered by expected work (diastole, systole, S1, S2): with the
   // state as the fast index and a batch that is a multiple of 4, round-robin dispatch handed every
   // diastole block (the long ones) to the same quarter of the CUs.
-  const int b = blockIdx.x, z = blockIdx.z;
+  // Blocks are dealt to the CUs in launch order, and the kDispSplit blocks of one pair are
+  // gridDim.x * 4 apart — a multiple of the CU count at the benchmark batch, i.e. the SAME CU,
+  // whose LDS pipe the heaviest pair then saturates alone.  Rotating the sample index by a
+  // z-dependent offset puts them on different CUs.
+  const int z = blockIdx.z;
+  const int b = (int)((blockIdx.x + (unsigned)z * (gridDim.x / kDispSplit + 3)) % gridDim.x);
   const int k = (0x2013 >> (4 * blockIdx.y)) & 3;   // blockIdx.y 0,1,2,3 -> state 3,1,0,2
   float2* out = part + ((size_t)b * 4 + k) * kDispSplit + z;
   int m = mix_idx[b];
