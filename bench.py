@@ -399,7 +399,7 @@ def cfg3_salopt(device, steps=100, warmup=10, B=256, C=4, T=5000, reps=3):
             "steps": steps, "saliency_model": "CNN_potes (frozen copy)"}
 
 
-def cfg4_spectrogram(device, steps=8, warmup=2, B=256, T=5000):
+def cfg4_spectrogram(device, steps=12, warmup=4, B=256, T=5000):
     """BASELINE.json configs[3]: waveform (256,1,5000) -> HIP log-mel (256,1,128,128) -> 2D
     durratiomixup on the spectrogram columns -> ResNet9-2D train step (MIOpen convolutions)."""
     from pcgmix_amd import augmentations2d, frontend
@@ -754,7 +754,7 @@ def main():
             if not a.no_train:
                 leg("cfg4_spectrogram", lambda: cfg4_spectrogram(device))
                 leg("train_resnet9_1d_magwarp", lambda: train_steps_per_s(
-                    "durmixmagwarp(0.2,4)", "resnet9", 256, 4, 5000, rate, device, 10, 3, barrier,
+                    "durmixmagwarp(0.2,4)", "resnet9", 256, 4, 5000, rate, device, 20, 5, barrier,
                     rank))
         result["extra"] = extra
         if not a.no_cpu:

@@ -347,7 +347,8 @@ int pcgmix_adam_clip_multi_f32(int n_tensors, float* const* p, const float* cons
  * Backward, given dlogits (B,C):
  *   mask1/scale1 the conv branch's Dropout(.25) mask (B,K bytes) and 1/(1-p1), NULL = none
  *   dz (B,20) workspace/out (gradient at z; 16-byte aligned); dw2 (C,20), db2 (C, may be NULL), db1 (20, may be
- *   NULL), dw1 (20,K), dx (B,K, may be NULL) = gradient at the features BEFORE Dropout(.25).
+ *   NULL), dw1 (20,K; may be NULL when dx is given: frozen weights, e.g. the saliency model — x is
+ *   then not read at all), dx (B,K, may be NULL) = gradient at the features BEFORE Dropout(.25).
  * x is read once and dx written once (8 bytes per feature element); reductions are fixed-order.
  */
 int pcgmix_potes_head_fwd_f32(const float* x, const float* w1, const float* b1,

@@ -166,7 +166,9 @@ __global__ __launch_bounds__(kTailBwdGroups* kHeadO) void potes_tail_bwd_kernel(
 // order (deterministic); more than two splits would.
 constexpr int kHbWaves = 4, kHbRows = 64, kHbSplit = 2;
 
-template <bool MASKED>
+// NEED_DW = false: the weights are frozen (saliency model): only dx is produced — no read of x,
+// no dW1 accumulators, no reduction, no atomics.
+template <bool MASKED, bool NEED_DW>
 __global__ __launch_bounds__(kHbWaves * 64) void potes_head_bwd_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, const uint8_t* __restrict__ mask1,
     float scale1, const float* __restrict__ w1, float* __restrict__ dw1, float* __restrict__ dx,
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(kHbWaves * 64) void potes_head_bwd_kernel(
     for (int j = 0; j < kPer; ++j) {
       const int r = wave + kHbWaves * j;
       const size_t e = (valid && r < nb) ? (size_t)(b0 + r) * K + k : 0;
-      xv[j] = x[e];
+      xv[j] = NEED_DW ? x[e] : 0.f;
       mb[j] = MASKED ? mask1[e] : 1;
     }
 #pragma unroll
@@ -216,15 +218,18 @@ __global__ __launch_bounds__(kHbWaves * 64) void potes_head_bwd_kernel(
           s = fmaf(d.y, wcol[4 * q + 1], s);
           s = fmaf(d.z, wcol[4 * q + 2], s);
           s = fmaf(d.w, wcol[4 * q + 3], s);
-          acc[4 * q] = fmaf(d.x, xv[j], acc[4 * q]);
-          acc[4 * q + 1] = fmaf(d.y, xv[j], acc[4 * q + 1]);
-          acc[4 * q + 2] = fmaf(d.z, xv[j], acc[4 * q + 2]);
-          acc[4 * q + 3] = fmaf(d.w, xv[j], acc[4 * q + 3]);
+          if (NEED_DW) {
+            acc[4 * q] = fmaf(d.x, xv[j], acc[4 * q]);
+            acc[4 * q + 1] = fmaf(d.y, xv[j], acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(d.z, xv[j], acc[4 * q + 2]);
+            acc[4 * q + 3] = fmaf(d.w, xv[j], acc[4 * q + 3]);
+          }
         }
         if (valid && dx) dx[(size_t)(b0 + r) * K + k] = mb[j] ? s * scale1 : 0.f;
       }
     }
   }
+  if (!NEED_DW) return;
 #pragma unroll
   for (int o = 0; o < kHeadO; ++o) red[wave][o][lane] = acc[o];
   __syncthreads();
@@ -334,21 +339,28 @@ extern "C" int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, c
                                          float* dz, float* dw2, float* db2, float* db1, float* dw1,
                                          float* dx, int B, int K, int C, pcgmix_stream_t stream) {
   using namespace pcgmix;
-  if (!dlogits || !z || !w2 || !x || !w1 || !dz || !dw2 || !dw1 || B <= 0 || K <= 0 || C <= 0 ||
-      C > kHeadMaxC || (reinterpret_cast<uintptr_t>(dz) & 15))
+  if (!dlogits || !z || !w2 || !x || !w1 || !dz || !dw2 || (!dw1 && !dx) || B <= 0 || K <= 0 ||
+      C <= 0 || C > kHeadMaxC || (reinterpret_cast<uintptr_t>(dz) & 15))
     return hipErrorInvalidValue;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const long long n_dw1 = (long long)kHeadO * K;
-  const unsigned zero_blocks = (unsigned)((n_dw1 + 4095) / 4096);          // >= 1 since K > 0
+  const long long n_dw1 = dw1 ? (long long)kHeadO * K : 0;
+  const unsigned zero_blocks = (unsigned)((n_dw1 + 4095) / 4096);
   hipLaunchKernelGGL(potes_tail_bwd_kernel, dim3(1 + zero_blocks), dim3(kTailBwdGroups * kHeadO), 0,
                      s, dlogits, z, mask2, scale2, w2, dz, dw2, db2, db1, B, C, dw1, n_dw1);
   const dim3 grid((unsigned)((K + kHbCols - 1) / kHbCols), kHbSplit), block(kHbWaves * 64);
-  if (mask1) {
-    hipLaunchKernelGGL(potes_head_bwd_kernel<true>, grid, block, 0, s, dz, x, mask1, scale1, w1, dw1,
-                       dx, B, K);
+  if (!dw1) {                      // frozen weights: dx only
+    if (mask1)
+      hipLaunchKernelGGL((potes_head_bwd_kernel<true, false>), grid, block, 0, s, dz, x, mask1, scale1,
+                         w1, dw1, dx, B, K);
+    else
+      hipLaunchKernelGGL((potes_head_bwd_kernel<false, false>), grid, block, 0, s, dz, x, mask1, 1.0f,
+                         w1, dw1, dx, B, K);
+  } else if (mask1) {
+    hipLaunchKernelGGL((potes_head_bwd_kernel<true, true>), grid, block, 0, s, dz, x, mask1, scale1, w1,
+                       dw1, dx, B, K);
   } else {
-    hipLaunchKernelGGL(potes_head_bwd_kernel<false>, grid, block, 0, s, dz, x, mask1, 1.0f, w1, dw1,
-                       dx, B, K);
+    hipLaunchKernelGGL((potes_head_bwd_kernel<false, true>), grid, block, 0, s, dz, x, mask1, 1.0f, w1,
+                       dw1, dx, B, K);
   }
   return (int)hipGetLastError();
 }

@@ -185,7 +185,9 @@ class PotesHeadFunction(torch.autograd.Function):
         dlogits = dlogits.contiguous()
         dz = torch.empty((B, 20), dtype=torch.float32, device=dev)
         dw2 = torch.empty_like(w2)
-        dw1 = torch.empty_like(w1)
+        # frozen weights (the saliency model): only dx is wanted, the kernel then never reads x
+        need_dw1 = ctx.needs_input_grad[1] or not ctx.needs_input_grad[0]
+        dw1 = torch.empty_like(w1) if need_dw1 else None
         db1 = torch.empty(20, dtype=torch.float32, device=dev) if ctx.has_b1 else None
         db2 = torch.empty(C, dtype=torch.float32, device=dev) if ctx.has_b2 else None
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
@@ -196,7 +198,7 @@ class PotesHeadFunction(torch.autograd.Function):
             ctypes.c_float(1.0 / (1.0 - ctx.p2) if mask2 is not None else 1.0), w2.data_ptr(),
             x.data_ptr(), opt(mask1),
             ctypes.c_float(1.0 / (1.0 - ctx.p1) if mask1 is not None else 1.0), w1.data_ptr(),
-            dz.data_ptr(), dw2.data_ptr(), opt(db2), opt(db1), dw1.data_ptr(), opt(dx), B, K, C,
+            dz.data_ptr(), dw2.data_ptr(), opt(db2), opt(db1), opt(dw1), opt(dx), B, K, C,
             stream), "pcgmix_potes_head_bwd_f32")
         return dx, dw1, db1, dw2, db2, None, None, None
 

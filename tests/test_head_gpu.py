@@ -150,3 +150,32 @@ def test_head_backward_is_deterministic(device):
         grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]) and torch.equal(grads[0][k], grads[2][k]), k
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_head_input_gradient_with_frozen_weights(training, device):
+    """Saliency maps differentiate through a FROZEN model (saliency.py:47-61): the head's backward
+    then produces dx only (pcgmix_potes_head_bwd_f32 with dw1 = NULL: x is not read, no dW1
+    accumulation).  Same dx as with trainable weights, and as torch's."""
+    from pcgmix_amd import models
+    torch.manual_seed(3)
+    B, K = 48, 9968
+    lin1, lin2 = torch.nn.Linear(K, 20).to(device), torch.nn.Linear(20, 2).to(device)
+    feat = torch.randn(B, K, device=device)
+    r = torch.randn(B, 2, device=device)
+    outs = []
+    for frozen in (True, False):
+        for p in list(lin1.parameters()) + list(lin2.parameters()):
+            p.requires_grad_(not frozen)
+        x = feat.clone().requires_grad_(True)
+        torch.manual_seed(11)                                     # same dropout masks
+        lo = models.PotesHeadFunction.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias,
+                                            0.25, 0.5, training)
+        (gx,) = torch.autograd.grad((lo * r).sum(), x)
+        outs.append((lo.detach(), gx))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    if not training:
+        x = feat.clone().requires_grad_(True)
+        ref = lin2(torch.relu(lin1(x)))
+        (gt,) = torch.autograd.grad((ref * r).sum(), x)
+        assert torch.allclose(outs[0][1], gt, rtol=1e-4, atol=1e-6 * float(gt.abs().max()) + 1e-9)
