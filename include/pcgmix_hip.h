@@ -443,6 +443,12 @@ typedef struct pcgmix_ctx pcgmix_ctx;
 int pcgmix_ctx_create(int device, pcgmix_ctx** out);
 void pcgmix_ctx_destroy(pcgmix_ctx* ctx);
 double pcgmix_ctx_gate(pcgmix_ctx* ctx, uint64_t step);
+/* The label read-back alone, in two halves, for steps that have GPU work to enqueue in between
+ * (the saliency-guided step, augmentations.py:881-907): begin = the arg-max kernel on `stream`;
+ * wait = the spin on the flag word, then int64 class labels in labels_out (HOST, B). */
+int pcgmix_ctx_labels_begin(pcgmix_ctx* ctx, const int64_t* target_ohe_dev, int num_classes, int B,
+                            pcgmix_stream_t stream);
+int pcgmix_ctx_labels_wait(pcgmix_ctx* ctx, int64_t* labels_out, int B, pcgmix_stream_t stream);
 int pcgmix_augment_plain_f32(pcgmix_ctx* ctx, const float* x, float* y,
                              const int64_t* target_ohe_dev, int num_classes,
                              const int64_t* labels_host, const int64_t* frames, uint64_t step,

@@ -401,13 +401,29 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
         from . import saliency as _sal
         if host_labels is None:
             # the read-back must wait for whatever produced target_ohe, but not for the saliency
-            # graph: mark the stream, enqueue the graph (the GPU goes straight from the previous
-            # step's kernel into it), then read the labels on a side stream behind the mark
-            mark = torch.cuda.Event()
-            mark.record(torch.cuda.current_stream(data.device))
-            sal = _sal.get_saliency_maps(args, data.device, data, target_ohe, frames_np, dim=1,
-                                         gauss_k_n=101)
-            labels = labels_from_ohe(target_ohe, after=mark)
+            # graph: the label arg-max kernel goes first (it writes the labels into host-mapped
+            # memory), then the graph; the host picks the labels up when it needs them — by then
+            # the kernel has long finished and the GPU is inside the graph
+            ohe = target_ohe.detach()
+            if ohe.is_cuda and ohe.dtype == torch.int64 and ohe.dim() == 2 and ohe.is_contiguous() \
+                    and ohe.shape[0] == B:
+                lib = _lib.load()
+                idx = data.device.index
+                ctx = _CTX.get(idx) or step_context(idx)
+                stream = _raw_stream(data.device)
+                _lib.check(lib.pcgmix_ctx_labels_begin(ctx, ohe.data_ptr(), ohe.shape[1], B, stream),
+                           "pcgmix_ctx_labels_begin")
+                sal = _sal.get_saliency_maps(args, data.device, data, target_ohe, frames_np, dim=1,
+                                             gauss_k_n=101)
+                labels = np.empty(B, dtype=np.int64)
+                _lib.check(lib.pcgmix_ctx_labels_wait(ctx, labels.ctypes.data, B, stream),
+                           "pcgmix_ctx_labels_wait")
+            else:
+                mark = torch.cuda.Event()
+                mark.record(torch.cuda.current_stream(data.device))
+                sal = _sal.get_saliency_maps(args, data.device, data, target_ohe, frames_np, dim=1,
+                                             gauss_k_n=101)
+                labels = labels_from_ohe(target_ohe, after=mark)
         else:
             sal = _sal.get_saliency_maps(args, data.device, data, target_ohe, frames_np, dim=1,
                                          gauss_k_n=101)

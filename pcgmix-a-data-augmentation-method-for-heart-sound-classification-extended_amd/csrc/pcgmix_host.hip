@@ -525,6 +525,75 @@ hipError_t spline_op_device(pcgmix_ctx* c, int T, int n_knots, const double** ou
 
 }  // namespace
 
+namespace {
+
+// Enqueue the label arg-max for a (B, K) one-hot matrix on `s`; the labels land in c->lab and the
+// flag word takes the returned token.
+hipError_t labels_begin(pcgmix_ctx* c, const int64_t* ohe_dev, int K, int B, hipStream_t s) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+    return hipErrorStreamCaptureUnsupported;     // a host wait cannot be captured
+  if (c->lab_cap < (size_t)B) {
+    if (c->lab) (void)hipHostFree(c->lab);
+    c->lab = nullptr;
+    c->lab_cap = 0;
+    size_t cap = 1024;
+    while (cap < (size_t)B) cap <<= 1;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&c->lab), cap * sizeof(int32_t),
+                                 hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) return e;
+    c->lab_cap = cap;
+  }
+  ++c->token;
+  if (c->token == 0) c->token = 1;
+  hipLaunchKernelGGL(label_argmax_kernel, dim3(1), dim3(256), 0, s, ohe_dev, K, B, c->lab, c->flag,
+                     c->token);
+  return hipGetLastError();
+}
+
+// Spin until the flag word shows the current token (2 ms, then a stream synchronisation).
+hipError_t labels_wait(pcgmix_ctx* c, hipStream_t s) {
+  const uint32_t want = c->token;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (__atomic_load_n(c->flag, __ATOMIC_ACQUIRE) != want) {
+    _mm_pause();
+    if ((++spins & 1023u) == 0 &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+      hipError_t e = hipStreamSynchronize(s);
+      if (e != hipSuccess) return e;
+      if (__atomic_load_n(c->flag, __ATOMIC_ACQUIRE) != want) return hipErrorUnknown;
+    }
+  }
+  return hipSuccess;
+}
+
+}  // namespace
+
+// The label read-back on its own, in two halves, for callers that have GPU work to enqueue in
+// between (the saliency-guided step enqueues the frozen model's graph): begin = the arg-max kernel
+// on `stream`; wait = the spin, then int64 class labels in `labels_out` (host, B).
+extern "C" int pcgmix_ctx_labels_begin(pcgmix_ctx* c, const int64_t* target_ohe_dev, int num_classes,
+                                       int B, pcgmix_stream_t stream) {
+  if (!c || !target_ohe_dev || num_classes <= 0 || B <= 0) return hipErrorInvalidValue;
+  int cur = 0;
+  hipError_t e = hipGetDevice(&cur);
+  if (e != hipSuccess) return (int)e;
+  if (cur != c->device && (e = hipSetDevice(c->device)) != hipSuccess) return (int)e;
+  e = labels_begin(c, target_ohe_dev, num_classes, B, reinterpret_cast<hipStream_t>(stream));
+  if (cur != c->device) (void)hipSetDevice(cur);
+  return (int)e;
+}
+
+extern "C" int pcgmix_ctx_labels_wait(pcgmix_ctx* c, int64_t* labels_out, int B,
+                                      pcgmix_stream_t stream) {
+  if (!c || !labels_out || B <= 0 || (size_t)B > c->lab_cap) return hipErrorInvalidValue;
+  const hipError_t e = labels_wait(c, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return (int)e;
+  for (int b = 0; b < B; ++b) labels_out[b] = c->lab[b];
+  return hipSuccess;
+}
+
 extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
                                         const int64_t* target_ohe_dev, int num_classes,
                                         const int64_t* labels_host, const int64_t* frames,
@@ -548,27 +617,8 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   // 1. start the label read-back first: everything below up to step 4 does not need the labels
   //    and runs while the GPU finishes what precedes this call on `stream`
   const bool readback = labels_host == nullptr;
-  if (readback) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-      return hipErrorStreamCaptureUnsupported;     // a host wait cannot be captured
-    if (c->lab_cap < (size_t)B) {
-      if (c->lab) (void)hipHostFree(c->lab);
-      c->lab = nullptr;
-      c->lab_cap = 0;
-      size_t cap = 1024;
-      while (cap < (size_t)B) cap <<= 1;
-      e = hipHostMalloc(reinterpret_cast<void**>(&c->lab), cap * sizeof(int32_t),
-                        hipHostMallocMapped | hipHostMallocCoherent);
-      if (e != hipSuccess) return (int)e;
-      c->lab_cap = cap;
-    }
-    ++c->token;
-    if (c->token == 0) c->token = 1;
-    hipLaunchKernelGGL(label_argmax_kernel, dim3(1), dim3(256), 0, s, target_ohe_dev, num_classes,
-                       B, c->lab, c->flag, c->token);
-    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-  }
+  if (readback && (e = labels_begin(c, target_ohe_dev, num_classes, B, s)) != hipSuccess)
+    return (int)e;
 
   // 2. staging slot, boundaries validated and packed, knots copied, generator seeded
   const size_t n_int = (size_t)B * 6, n_int_pad = (n_int + 1) & ~(size_t)1;
@@ -605,17 +655,7 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   std::vector<int64_t> lab64;
   const int64_t* labels = labels_host;
   if (readback) {
-    const uint32_t want = c->token;
-    const auto t0 = std::chrono::steady_clock::now();
-    unsigned spins = 0;
-    while (__atomic_load_n(c->flag, __ATOMIC_ACQUIRE) != want) {
-      _mm_pause();
-      if ((++spins & 1023u) == 0 &&
-          std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
-        if ((e = hipStreamSynchronize(s)) != hipSuccess) return (int)e;
-        if (__atomic_load_n(c->flag, __ATOMIC_ACQUIRE) != want) return hipErrorUnknown;
-      }
-    }
+    if ((e = labels_wait(c, s)) != hipSuccess) return (int)e;
     lab64.resize((size_t)B);
     for (int b = 0; b < B; ++b) lab64[(size_t)b] = c->lab[b];
     labels = lab64.data();
