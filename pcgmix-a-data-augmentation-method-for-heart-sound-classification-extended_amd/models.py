@@ -471,6 +471,15 @@ class ResNet9_myrtle(nn.Module):
         self.pool1d = nn.MaxPool1d(4)
         self.flat = nn.Flatten()
         self.linear = nn.Linear(linear, num_classes)
+        # Conv1d weights are kept (O, I, 3) in shape and state_dict but laid out with the input
+        # channel innermost, so that their (O, I, 1, 3) view is channels_last as it stands: MIOpen's
+        # NHWC kernels otherwise get a re-laid-out copy of every weight in forward, backward-data
+        # and backward-weights (26 copies, 0.3 ms of a 32 ms bs=256 step,
+        # profiles/r2_resnet1d_step_kernels.csv).  A memory format, not a reshape: values, keys and
+        # shapes are unchanged; load_state_dict / .to() / deepcopy keep the strides.
+        for m in self.modules():
+            if isinstance(m, nn.Conv1d):
+                m.weight.data = m.weight.data.permute(0, 2, 1).contiguous().permute(0, 2, 1)
 
     # ---- execution layout ------------------------------------------------------------------
     # On a HIP device the activations flow as (B, C, 1, L) channels_last tensors through

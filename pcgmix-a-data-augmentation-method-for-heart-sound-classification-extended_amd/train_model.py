@@ -209,8 +209,9 @@ def make_optimizer(args, model: nn.Module):
     if args.op == "SGD":
         opt = torch.optim.SGD(params, lr=args.lr_max, weight_decay=args.weight_decay)
     elif args.op == "adam":
-        dense = lambda p: p.is_contiguous() or (   # noqa: E731
-            p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+        def dense(p):       # any non-overlapping dense layout: the kernel walks raw memory
+            order = sorted(range(p.dim()), key=lambda d: (-p.stride(d), -p.size(d)))
+            return p.numel() == 0 or p.permute(order).is_contiguous()
         if all(p.is_cuda and p.dtype == torch.float32 and dense(p) for p in params):
             # clip + Adam in one HIP pass per tensor (train_step then skips clip_grad_value_)
             opt = ClipAdam(params, lr=args.lr_max, weight_decay=args.weight_decay,
