@@ -337,29 +337,31 @@ int pcgmix_adam_clip_multi_f32(int n_tensors, float* const* p, const float* cons
 /* ------------------------------------------------------------------------------------------
  * Potes classifier head, forward and backward.                                       [device]
  *
- * Replaces CNN_potes' Flatten/concat -> dimreduc Linear(K->20) -> ReLU -> Dropout(.5) ->
- * Linear(20->C) (models.py:376-381, 456-465) and their autograd twins.
- *   x       (B,K) features AFTER the Dropout(.25) of the conv branch (K % 4 == 0, 16-byte aligned)
+ * Replaces CNN_potes' Dropout(.25) -> Flatten/concat -> dimreduc Linear(K->20) -> ReLU ->
+ * Dropout(.5) -> Linear(20->C) (models.py:364, 376-381, 456-465) and their autograd twins.
+ *   x       (B,K) features BEFORE the Dropout(.25) of the conv branch (K % 4 == 0, 16-byte aligned)
+ *   mask1   (B,K) bytes or NULL (no dropout): element kept iff byte >= thr1, kept values times
+ *           scale1.  thr = 1 reads a 0/1 mask; thr = 256*p reads uniformly random bytes (then
+ *           scale = 256/(256-thr)).  4-byte aligned.  Applied where x is read: no separate pass.
  *   w1,b1   dimreduc (20,K), (20) — b1 may be NULL;   w2,b2  linear (C,20), (C), C <= 8
- *   mask2   (B,20) bytes, non-zero = kept, NULL = no dropout (eval); scale2 = 1/(1-p2)
+ *   mask2   (B,20) bytes, kept iff byte >= thr2, NULL = no dropout (eval); scale2 as scale1
  *   partial workspace, pcgmix_skinny_linear_splits(B,K) * B * 20 floats
  *   z       (B,20) out: dimreduc output incl. bias, kept for backward;  logits (B,C) out
- * Backward, given dlogits (B,C):
- *   mask1/scale1 the conv branch's Dropout(.25) mask (B,K bytes) and 1/(1-p1), NULL = none
+ * Backward, given dlogits (B,C) and the SAME x, mask1, mask2:
  *   dz (B,20) workspace/out (gradient at z; 16-byte aligned); dw2 (C,20), db2 (C, may be NULL), db1 (20, may be
  *   NULL), dw1 (20,K; may be NULL when dx is given: frozen weights, e.g. the saliency model — x is
  *   then not read at all), dx (B,K, may be NULL) = gradient at the features BEFORE Dropout(.25).
- * x is read once and dx written once (8 bytes per feature element); reductions are fixed-order.
+ * x is read once and dx written once (9 bytes per feature element); reductions are fixed-order.
  */
-int pcgmix_potes_head_fwd_f32(const float* x, const float* w1, const float* b1,
-                              const uint8_t* mask2, float scale2, const float* w2, const float* b2,
-                              float* partial, float* z, float* logits, int B, int K, int C,
-                              pcgmix_stream_t stream);
+int pcgmix_potes_head_fwd_f32(const float* x, const uint8_t* mask1, float scale1, int thr1,
+                              const float* w1, const float* b1, const uint8_t* mask2, float scale2,
+                              int thr2, const float* w2, const float* b2, float* partial, float* z,
+                              float* logits, int B, int K, int C, pcgmix_stream_t stream);
 int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, const uint8_t* mask2,
-                              float scale2, const float* w2, const float* x, const uint8_t* mask1,
-                              float scale1, const float* w1, float* dz, float* dw2, float* db2,
-                              float* db1, float* dw1, float* dx, int B, int K, int C,
-                              pcgmix_stream_t stream);
+                              float scale2, int thr2, const float* w2, const float* x,
+                              const uint8_t* mask1, float scale1, int thr1, const float* w1,
+                              float* dz, float* dw2, float* db2, float* db1, float* dw1, float* dx,
+                              int B, int K, int C, pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Soft-target cross entropy (train_model.py:45-54, CELoss).                          [device]

@@ -18,8 +18,12 @@
 //   potes_head_bwd_kernel   dz -> dW1 = dz^T x and dx = mask1 * scale1 * (dz W1) in ONE pass over
 //                           the feature matrix x (read once, written once: 9 bytes/element)
 //
-// The dropout masks themselves come from torch's generator (graph-safe Philox state), so seeding
-// behaves as with nn.Dropout.  All reductions run in a fixed order (deterministic).
+// Dropout: the caller hands over bytes (same shape as what they mask) and a threshold; an element
+// is kept iff its byte >= thr.  thr = 1 reads a 0/1 mask; thr = 256*p reads uniformly random
+// bytes from torch's generator (one `random_()` call for both masks: seeding behaves as with
+// nn.Dropout; p = 0.25 and 0.5 are exact in 1/256ths).  The feature dropout is applied where the
+// features are read (split-K forward, fused backward): no separate pass over the 20 MB matrix.
+// All reductions run in a fixed order (deterministic).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -43,7 +47,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // The first kTailRows*C threads then form the logits.
 __global__ __launch_bounds__(kTailRows* kHeadO * 4) void potes_tail_fwd_kernel(
     const float* __restrict__ partial, int KS, const float* __restrict__ b1,
-    const uint8_t* __restrict__ mask2, float scale2, const float* __restrict__ w2,
+    const uint8_t* __restrict__ mask2, float scale2, int thr2, const float* __restrict__ w2,
     const float* __restrict__ b2, float* __restrict__ z, float* __restrict__ logits, int B, int C) {
   __shared__ float h[kTailRows][kHeadO];
   const int t = threadIdx.x, q = t & 3, e = t >> 2;            // e = r * kHeadO + o
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(kTailRows* kHeadO * 4) void potes_tail_fwd_kernel(
     v += b1 ? b1[o] : 0.f;
     z[i] = v;
     hv = v > 0.f ? v : 0.f;
-    if (mask2) hv = mask2[i] ? hv * scale2 : 0.f;
+    if (mask2) hv = (int)mask2[i] >= thr2 ? hv * scale2 : 0.f;
   }
   if (q == 0) h[r][o] = hv;
   __syncthreads();
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(kTailRows* kHeadO * 4) void potes_tail_fwd_kernel(
 // dW2[c][o] = sum_b dlogits[b][c] h[b][o]; db1[o] = sum_b dz[b][o]; db2[c] = sum_b dlogits[b][c].
 __global__ __launch_bounds__(kTailBwdGroups* kHeadO) void potes_tail_bwd_kernel(
     const float* __restrict__ dlogits, const float* __restrict__ z,
-    const uint8_t* __restrict__ mask2, float scale2, const float* __restrict__ w2,
+    const uint8_t* __restrict__ mask2, float scale2, int thr2, const float* __restrict__ w2,
     float* __restrict__ dz, float* __restrict__ dw2, float* __restrict__ db2,
     float* __restrict__ db1, int B, int C, float* __restrict__ zero, long long n_zero) {
   if (blockIdx.x > 0) {        // blocks 1.. clear the buffer the next kernel accumulates dW1 into
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(kTailBwdGroups* kHeadO) void potes_tail_bwd_kernel(
     const size_t i = (size_t)b * kHeadO + o;
     const float zz = z[i];
     float fac = zz > 0.f ? 1.f : 0.f;
-    if (mask2) fac = mask2[i] ? fac * scale2 : 0.f;
+    if (mask2) fac = (int)mask2[i] >= thr2 ? fac * scale2 : 0.f;
     const float hv = zz * fac;
     float s = 0.f;
 #pragma unroll
@@ -171,8 +175,8 @@ constexpr int kHbWaves = 4, kHbRows = 64, kHbSplit = 2;
 template <bool MASKED, bool NEED_DW>
 __global__ __launch_bounds__(kHbWaves * 64) void potes_head_bwd_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, const uint8_t* __restrict__ mask1,
-    float scale1, const float* __restrict__ w1, float* __restrict__ dw1, float* __restrict__ dx,
-    int B, int K) {
+    float scale1, int thr1, const float* __restrict__ w1, float* __restrict__ dw1,
+    float* __restrict__ dx, int B, int K) {
   __shared__ __align__(16) float dzl[kHbRows * kHeadO];
   __shared__ float red[kHbWaves][kHeadO][kHbCols];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -203,8 +207,9 @@ __global__ __launch_bounds__(kHbWaves * 64) void potes_head_bwd_kernel(
     for (int j = 0; j < kPer; ++j) {
       const int r = wave + kHbWaves * j;
       const size_t e = (valid && r < nb) ? (size_t)(b0 + r) * K + k : 0;
-      xv[j] = NEED_DW ? x[e] : 0.f;
-      mb[j] = MASKED ? mask1[e] : 1;
+      mb[j] = MASKED ? ((int)mask1[e] >= thr1 ? 1 : 0) : 1;
+      // x holds the features BEFORE the dropout: what the forward multiplied is mask * scale * x
+      xv[j] = NEED_DW ? (MASKED ? (mb[j] ? x[e] * scale1 : 0.f) : x[e]) : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
@@ -317,27 +322,30 @@ extern "C" int pcgmix_soft_ce_bwd_f32(const float* logits, const float* target, 
   return (int)hipGetLastError();
 }
 
-extern "C" int pcgmix_potes_head_fwd_f32(const float* x, const float* w1, const float* b1,
-                                         const uint8_t* mask2, float scale2, const float* w2,
-                                         const float* b2, float* partial, float* z, float* logits,
-                                         int B, int K, int C, pcgmix_stream_t stream) {
+extern "C" int pcgmix_potes_head_fwd_f32(const float* x, const uint8_t* mask1, float scale1,
+                                         int thr1, const float* w1, const float* b1,
+                                         const uint8_t* mask2, float scale2, int thr2,
+                                         const float* w2, const float* b2, float* partial, float* z,
+                                         float* logits, int B, int K, int C,
+                                         pcgmix_stream_t stream) {
   using namespace pcgmix;
   if (!w2 || !z || !logits || C <= 0 || C > kHeadMaxC) return hipErrorInvalidValue;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const hipError_t e = launch_skinny_partial(x, w1, partial, B, K, kHeadO, s);
+  const hipError_t e = launch_skinny_partial(x, w1, partial, B, K, kHeadO, s, mask1, scale1, thr1);
   if (e != hipSuccess) return (int)e;
   const int KS = pcgmix_skinny_linear_splits(B, K);
   hipLaunchKernelGGL(potes_tail_fwd_kernel, dim3((unsigned)((B + kTailRows - 1) / kTailRows)),
-                     dim3(kTailRows * kHeadO * 4), 0, s, partial, KS, b1, mask2, scale2, w2, b2, z,
-                     logits, B, C);
+                     dim3(kTailRows * kHeadO * 4), 0, s, partial, KS, b1, mask2, scale2, thr2, w2, b2,
+                     z, logits, B, C);
   return (int)hipGetLastError();
 }
 
 extern "C" int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, const uint8_t* mask2,
-                                         float scale2, const float* w2, const float* x,
-                                         const uint8_t* mask1, float scale1, const float* w1,
-                                         float* dz, float* dw2, float* db2, float* db1, float* dw1,
-                                         float* dx, int B, int K, int C, pcgmix_stream_t stream) {
+                                         float scale2, int thr2, const float* w2, const float* x,
+                                         const uint8_t* mask1, float scale1, int thr1,
+                                         const float* w1, float* dz, float* dw2, float* db2,
+                                         float* db1, float* dw1, float* dx, int B, int K, int C,
+                                         pcgmix_stream_t stream) {
   using namespace pcgmix;
   if (!dlogits || !z || !w2 || !x || !w1 || !dz || !dw2 || (!dw1 && !dx) || B <= 0 || K <= 0 ||
       C <= 0 || C > kHeadMaxC || (reinterpret_cast<uintptr_t>(dz) & 15))
@@ -346,21 +354,21 @@ extern "C" int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, c
   const long long n_dw1 = dw1 ? (long long)kHeadO * K : 0;
   const unsigned zero_blocks = (unsigned)((n_dw1 + 4095) / 4096);
   hipLaunchKernelGGL(potes_tail_bwd_kernel, dim3(1 + zero_blocks), dim3(kTailBwdGroups * kHeadO), 0,
-                     s, dlogits, z, mask2, scale2, w2, dz, dw2, db2, db1, B, C, dw1, n_dw1);
+                     s, dlogits, z, mask2, scale2, thr2, w2, dz, dw2, db2, db1, B, C, dw1, n_dw1);
   const dim3 grid((unsigned)((K + kHbCols - 1) / kHbCols), kHbSplit), block(kHbWaves * 64);
   if (!dw1) {                      // frozen weights: dx only
     if (mask1)
       hipLaunchKernelGGL((potes_head_bwd_kernel<true, false>), grid, block, 0, s, dz, x, mask1, scale1,
-                         w1, dw1, dx, B, K);
+                         thr1, w1, dw1, dx, B, K);
     else
       hipLaunchKernelGGL((potes_head_bwd_kernel<false, false>), grid, block, 0, s, dz, x, mask1, 1.0f,
-                         w1, dw1, dx, B, K);
+                         0, w1, dw1, dx, B, K);
   } else if (mask1) {
-    hipLaunchKernelGGL((potes_head_bwd_kernel<true, true>), grid, block, 0, s, dz, x, mask1, scale1, w1,
-                       dw1, dx, B, K);
+    hipLaunchKernelGGL((potes_head_bwd_kernel<true, true>), grid, block, 0, s, dz, x, mask1, scale1,
+                       thr1, w1, dw1, dx, B, K);
   } else {
-    hipLaunchKernelGGL((potes_head_bwd_kernel<false, true>), grid, block, 0, s, dz, x, mask1, 1.0f, w1,
-                       dw1, dx, B, K);
+    hipLaunchKernelGGL((potes_head_bwd_kernel<false, true>), grid, block, 0, s, dz, x, mask1, 1.0f, 0,
+                       w1, dw1, dx, B, K);
   }
   return (int)hipGetLastError();
 }

@@ -21,8 +21,9 @@ inline hipError_t allow_large_lds(const void* kernel, unsigned long long* done, 
 }
 
 // pcgmix_potes.hip: split-K partial products of the skinny linear layer (see there).
+// mask != nullptr: h holds the features before dropout; kept iff mask byte >= thr, times scale.
 hipError_t launch_skinny_partial(const float* h, const float* W, float* partial, int B, int K,
-                                 int O, hipStream_t s);
+                                 int O, hipStream_t s, const uint8_t* mask, float scale, int thr);
 
 }  // namespace pcgmix
 #endif

@@ -138,46 +138,71 @@ class SkinnyLinearFunction(torch.autograd.Function):
         return gx, gw, gb
 
 
+def dropout_threshold(p: float):
+    """(thr, scale) of the byte rule the head kernels apply: an element is kept iff its uniformly
+    random byte >= thr, thr = round(256 p); the drop probability is thr/256 (exact for the
+    reference's 0.25 and 0.5) and kept values are scaled by 256/(256-thr)."""
+    thr = min(255, max(0, int(round(256.0 * p))))
+    return thr, 256.0 / (256.0 - thr)
+
+
+def head_dropout_bytes(B: int, K: int) -> int:
+    """Random bytes one training forward of the head consumes: B*K for Dropout(p1) on the features,
+    B*20 for Dropout(p2) on the hidden layer (the second block starts 16-byte aligned)."""
+    return ((B * K + 15) // 16) * 16 + B * 20
+
+
 class PotesHeadFunction(torch.autograd.Function):
     """Dropout(p1) -> dimreduc Linear(K->20) -> ReLU -> Dropout(p2) -> Linear(20->C) of CNN_potes
-    (models.py:376-381, 456-465) as one autograd node: ``pcgmix_potes_head_fwd_f32`` /
-    ``pcgmix_potes_head_bwd_f32``.  Both dropout masks are drawn by torch's generator (so
-    ``torch.manual_seed`` and hipGraph capture behave as with nn.Dropout); everything else —
-    about 30 small torch launches and three GEMMs per training step — is five HIP kernels."""
+    (models.py:364, 376-381, 456-465) as one autograd node: ``pcgmix_potes_head_fwd_f32`` /
+    ``pcgmix_potes_head_bwd_f32``.  Both dropouts read uniformly random BYTES — one
+    ``random_()`` call on torch's generator (so ``torch.manual_seed`` behaves as with nn.Dropout),
+    or ``rnd``, a caller-filled uint8 buffer of ``head_dropout_bytes(B, K)`` bytes (the captured
+    training step fills a static one before every replay: RNG calls inside a hipGraph cost two
+    extra fill launches per replay) — and are applied where the kernels read their operands: no
+    separate masking pass over the feature matrix."""
 
     @staticmethod
-    def forward(ctx, feat, w1, b1, w2, b2, p1, p2, training):
+    def forward(ctx, feat, w1, b1, w2, b2, p1, p2, training, rnd=None):
         B, K = feat.shape
         C = w2.shape[0]
         dev = feat.device
         lib = _lib.load()
+        x = feat.contiguous()
         mask1 = mask2 = None
-        if training and p1 > 0.0:
-            x, mask1 = torch.ops.aten.native_dropout(feat, p1, True)
-        else:
-            x = feat.contiguous()
-        if training and p2 > 0.0:
-            mask2 = torch.empty((B, 20), dtype=torch.bool, device=dev).bernoulli_(1.0 - p2)
+        thr1 = thr2 = 0
+        s1 = s2 = 1.0
+        if training and (p1 > 0.0 or p2 > 0.0):
+            n = head_dropout_bytes(B, K)
+            if rnd is None:
+                rnd = torch.empty(n, dtype=torch.uint8, device=dev).random_()
+            elif rnd.numel() < n or rnd.dtype != torch.uint8 or not rnd.is_contiguous():
+                raise ValueError("rnd must be a contiguous uint8 tensor of head_dropout_bytes(B, K)")
+            if p1 > 0.0:
+                mask1, (thr1, s1) = rnd[:B * K], dropout_threshold(p1)
+            if p2 > 0.0:
+                mask2, (thr2, s2) = rnd[n - B * 20:n], dropout_threshold(p2)
         w1c, w2c = w1.detach().contiguous(), w2.detach().contiguous()
         ks = lib.pcgmix_skinny_linear_splits(B, K)
         partial = torch.empty((ks, B, 20), dtype=torch.float32, device=dev)
         z = torch.empty((B, 20), dtype=torch.float32, device=dev)
         logits = torch.empty((B, C), dtype=torch.float32, device=dev)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        opt = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         _lib.check(lib.pcgmix_potes_head_fwd_f32(
-            x.data_ptr(), w1c.data_ptr(), b1.detach().data_ptr() if b1 is not None else None,
-            mask2.data_ptr() if mask2 is not None else None,
-            ctypes.c_float(1.0 / (1.0 - p2) if mask2 is not None else 1.0), w2c.data_ptr(),
-            b2.detach().data_ptr() if b2 is not None else None, partial.data_ptr(), z.data_ptr(),
-            logits.data_ptr(), B, K, C, stream), "pcgmix_potes_head_fwd_f32")
+            x.data_ptr(), opt(mask1), ctypes.c_float(s1), thr1, w1c.data_ptr(),
+            b1.detach().data_ptr() if b1 is not None else None, opt(mask2), ctypes.c_float(s2), thr2,
+            w2c.data_ptr(), b2.detach().data_ptr() if b2 is not None else None, partial.data_ptr(),
+            z.data_ptr(), logits.data_ptr(), B, K, C, stream), "pcgmix_potes_head_fwd_f32")
         ctx.save_for_backward(x, w1c, w2c, z, mask1, mask2)
-        ctx.p1, ctx.p2 = p1, p2
+        ctx.drop = (thr1, s1, thr2, s2)
         ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         x, w1, w2, z, mask1, mask2 = ctx.saved_tensors
+        thr1, s1, thr2, s2 = ctx.drop
         B, K = x.shape
         C = w2.shape[0]
         dev = x.device
@@ -194,13 +219,11 @@ class PotesHeadFunction(torch.autograd.Function):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         opt = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         _lib.check(lib.pcgmix_potes_head_bwd_f32(
-            dlogits.data_ptr(), z.data_ptr(), opt(mask2),
-            ctypes.c_float(1.0 / (1.0 - ctx.p2) if mask2 is not None else 1.0), w2.data_ptr(),
-            x.data_ptr(), opt(mask1),
-            ctypes.c_float(1.0 / (1.0 - ctx.p1) if mask1 is not None else 1.0), w1.data_ptr(),
+            dlogits.data_ptr(), z.data_ptr(), opt(mask2), ctypes.c_float(s2), thr2, w2.data_ptr(),
+            x.data_ptr(), opt(mask1), ctypes.c_float(s1), thr1, w1.data_ptr(),
             dz.data_ptr(), dw2.data_ptr(), opt(db2), opt(db1), opt(dw1), opt(dx), B, K, C,
             stream), "pcgmix_potes_head_bwd_f32")
-        return dx, dw1, db1, dw2, db2, None, None, None
+        return dx, dw1, db1, dw2, db2, None, None, None, None
 
 
 def _potes_block(c_in: int, c_out: int, dropout: float = 0.0) -> nn.Sequential:
@@ -241,6 +264,7 @@ class CNN_potes(nn.Module):
         self.dropout = nn.Dropout(0.5)
         self.linear = nn.Linear(20, c_out)
         self.fused = True       # use the fused HIP conv stack on a HIP device (see _fused)
+        self.dropout_bytes = None   # static random bytes of a captured training step (see _logits_fused)
 
     def _fused(self, x: torch.Tensor) -> bool:
         """The hand-written HIP stack applies to the reference configuration (layers [8,4], float32)
@@ -270,10 +294,14 @@ class CNN_potes(nn.Module):
         rows = x[:, :4, :].reshape(B * 4, T)
         z = PotesStackFunction.apply(rows.contiguous(), c1.weight, c1.bias, c2.weight, c2.bias)
         drop = self.cnn1[1][3] if len(self.cnn1[1]) > 3 else None
+        # the captured training step hands over a static buffer of random bytes that it refills
+        # before every replay (GraphedTrainStep); everywhere else the head draws its own
+        rnd = self.dropout_bytes if (self.dropout_bytes is not None and self.training
+                                     and torch.cuda.is_current_stream_capturing()) else None
         return PotesHeadFunction.apply(z.reshape(B, -1), self.dimreduc.weight, self.dimreduc.bias,
                                        self.linear.weight, self.linear.bias,
                                        float(drop.p) if drop is not None else 0.0,
-                                       float(self.dropout.p), self.training)
+                                       float(self.dropout.p), self.training, rnd)
 
     def features(self, x: torch.Tensor) -> torch.Tensor:
         B, C, T = x.shape

@@ -374,6 +374,17 @@ class GraphedTrainStep:
         self.t[:, 0] = 1
         self.sync = sync
         self.bwd_seed = torch.full((), sync.backward_scale if sync else 1.0, device=device)
+        # Dropout inside a captured region costs two extra fill launches per replay (torch's
+        # graph-safe Philox state) on top of the mask kernels.  The Potes head reads random BYTES
+        # instead: a static buffer the captured kernels read, refilled by ONE eager `random_()` on
+        # torch's generator before every replay — seeding behaves as with nn.Dropout.
+        self.rnd = None
+        inner = model.module if hasattr(model, "module") else model
+        if isinstance(inner, models.CNN_potes) and device.type == "cuda":
+            K = inner.dimreduc.in_features
+            self.rnd = torch.empty(models.head_dropout_bytes(batch_size, K), dtype=torch.uint8,
+                                   device=device)
+            inner.dropout_bytes = self.rnd
         # The warm-up passes run the network on the all-zero placeholder batch: they must leave no
         # trace.  Weights are not updated (no optimiser step); BatchNorm running statistics and
         # num_batches_tracked, and the device RNG stream the dropout masks come from, are put
@@ -448,6 +459,8 @@ class GraphedTrainStep:
         else:                                           # one-hot in float on the host: one small
             self.t.copy_(F.one_hot(target, args.num_classes).to(torch.float32),   # H2D, no kernel
                          non_blocking=True)
+        if self.rnd is not None and self.model.training:
+            self.rnd.random_()                          # this step's dropout masks
         self.graph.replay()
         if self.sync is not None:
             self.sync.reduce_and_bind()

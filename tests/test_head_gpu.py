@@ -46,19 +46,22 @@ def test_head_kernels_match_torch(B, K, C, drop, device):
     partial = torch.empty(ks, B, 20, device=device)
     z = torch.empty(B, 20, device=device)
     logits = torch.empty(B, C, device=device)
-    xd = x.detach().contiguous()
+    xd = feat.detach().contiguous()                  # the kernels take the features BEFORE dropout
+    m1b = m1.to(torch.uint8).contiguous() if drop else None      # 0/1 bytes, threshold 1
+    thr = 1 if drop else 0
     opt = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
-    _lib.check(lib.pcgmix_potes_head_fwd_f32(xd.data_ptr(), w1.data_ptr(), b1.data_ptr(), opt(m2),
-                                             ctypes.c_float(s2), w2.data_ptr(), b2.data_ptr(),
-                                             partial.data_ptr(), z.data_ptr(), logits.data_ptr(),
-                                             B, K, C, _stream(device)), "fwd")
+    _lib.check(lib.pcgmix_potes_head_fwd_f32(xd.data_ptr(), opt(m1b), ctypes.c_float(s1), thr,
+                                             w1.data_ptr(), b1.data_ptr(), opt(m2), ctypes.c_float(s2),
+                                             thr, w2.data_ptr(), b2.data_ptr(), partial.data_ptr(),
+                                             z.data_ptr(), logits.data_ptr(), B, K, C, _stream(device)),
+               "fwd")
     assert torch.allclose(z, z_t, rtol=1e-4, atol=2e-5), float((z - z_t).abs().max())
     assert torch.allclose(logits, logits_t, rtol=1e-4, atol=2e-5)
     dz = torch.empty(B, 20, device=device)
     dw2, db2, db1 = torch.empty(C, 20, device=device), torch.empty(C, device=device), torch.empty(20, device=device)
     dw1, dx = torch.empty(20, K, device=device), torch.empty(B, K, device=device)
-    _lib.check(lib.pcgmix_potes_head_bwd_f32(dl.data_ptr(), z.data_ptr(), opt(m2), ctypes.c_float(s2),
-                                             w2.data_ptr(), xd.data_ptr(), opt(m1), ctypes.c_float(s1),
+    _lib.check(lib.pcgmix_potes_head_bwd_f32(dl.data_ptr(), z.data_ptr(), opt(m2), ctypes.c_float(s2), thr,
+                                             w2.data_ptr(), xd.data_ptr(), opt(m1b), ctypes.c_float(s1), thr,
                                              w1.data_ptr(), dz.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
                                              db1.data_ptr(), dw1.data_ptr(), dx.data_ptr(), B, K, C,
                                              _stream(device)), "bwd")
@@ -179,3 +182,29 @@ def test_head_input_gradient_with_frozen_weights(training, device):
         ref = lin2(torch.relu(lin1(x)))
         (gt,) = torch.autograd.grad((ref * r).sum(), x)
         assert torch.allclose(outs[0][1], gt, rtol=1e-4, atol=1e-6 * float(gt.abs().max()) + 1e-9)
+
+
+def test_random_byte_dropout_is_torch_dropout_with_the_same_mask(device):
+    """Training mode reads uniformly random bytes (kept iff byte >= 256 p): against torch ops given
+    the masks those bytes define; exact keep probabilities for the reference's p = 0.25 / 0.5."""
+    from pcgmix_amd import models
+    torch.manual_seed(4)
+    B, K = 64, 9968
+    lin1, lin2 = torch.nn.Linear(K, 20).to(device), torch.nn.Linear(20, 2).to(device)
+    feat = torch.randn(B, K, device=device).relu_()
+    rnd = torch.empty(models.head_dropout_bytes(B, K), dtype=torch.uint8, device=device).random_()
+    x = feat.clone().requires_grad_(True)
+    lo = models.PotesHeadFunction.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, 0.25, 0.5,
+                                        True, rnd)
+    r = torch.randn(B, 2, device=device)
+    g = torch.autograd.grad((lo * r).sum(), [x, lin1.weight, lin2.weight])
+    assert models.dropout_threshold(0.25) == (64, 256 / 192) and models.dropout_threshold(0.5) == (128, 2.0)
+    m1 = (rnd[:B * K].view(B, K) >= 64).float() * (256 / 192)
+    m2 = (rnd[rnd.numel() - B * 20:].view(B, 20) >= 128).float() * 2.0
+    assert abs(float((m1 > 0).float().mean()) - 0.75) < 5e-3 and abs(float((m2 > 0).float().mean()) - 0.5) < 0.06
+    xt = feat.clone().requires_grad_(True)
+    ref = lin2(torch.relu(lin1(xt * m1)) * m2)
+    gt = torch.autograd.grad((ref * r).sum(), [xt, lin1.weight, lin2.weight])
+    assert torch.allclose(lo, ref, rtol=1e-4, atol=1e-5)
+    for a, b in zip(g, gt):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 + 1e-4 * float(b.abs().max()))

@@ -484,3 +484,31 @@ def test_models_match_reference_logits_on_hip_path(device):
         out = m(inp, depth=0, pass_part="second").detach().cpu().numpy()
         err = np.abs(out - g[key + "_logits"]).max()
         assert err <= 1e-4, (key, err)
+
+
+def test_graphed_step_matches_eager_with_dropout(device):
+    """With dropout ON: the captured step reads its masks from a static buffer of random bytes
+    refilled by one eager random_() per step, the eager step draws the same number of bytes from
+    the same generator — so with the same seed the two runs see the same masks and must agree."""
+    B, C, T = 32, 4, 2500
+    pool = synthetic.make_batch(B, C, T, seed=9)
+    batch = (torch.from_numpy(pool[0]), torch.from_numpy(pool[2]), torch.from_numpy(pool[1]), pool[3],
+             torch.ones(B, dtype=torch.long), torch.arange(B))
+    results = []
+    for graphed in (False, True):
+        args = make_args(method="durratiomixup", batch_size=B, num_steps=12)
+        torch.manual_seed(0)
+        net = tm.build_model(args).to(device).train()
+        opt, sched = tm.make_optimizer(args, net)
+        crit = tm.SELCLoss(pool[2], 2, es=args.num_epochs + 1, device=device)
+        sc = tm.step_counter_class()
+        if graphed:
+            g = tm.GraphedTrainStep(args, net, opt, sched, crit, device, B, C, T)
+        torch.manual_seed(123)                      # the dropout stream of the 5 steps
+        losses = [float(g.step(batch, 0, sc)) if graphed else
+                  float(tm.train_step(args, net, batch, device, opt, sched, crit, 0, sc)) for _ in range(5)]
+        results.append((losses, [p.detach().clone() for p in net.parameters() if p.requires_grad]))
+    assert np.allclose(results[0][0], results[1][0], rtol=1e-4, atol=1e-5), results
+    assert len(set(results[0][0])) == 5
+    for a, b in zip(results[0][1], results[1][1]):
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-4)
