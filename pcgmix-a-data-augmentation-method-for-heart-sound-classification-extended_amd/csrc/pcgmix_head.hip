@@ -207,14 +207,16 @@ __global__ __launch_bounds__(kHbWaves * 64) void potes_head_bwd_kernel(
     for (int j = 0; j < kPer; ++j) {
       const int r = wave + kHbWaves * j;
       const size_t e = (valid && r < nb) ? (size_t)(b0 + r) * K + k : 0;
-      mb[j] = MASKED ? ((int)mask1[e] >= thr1 ? 1 : 0) : 1;
-      // x holds the features BEFORE the dropout: what the forward multiplied is mask * scale * x
-      xv[j] = NEED_DW ? (MASKED ? (mb[j] ? x[e] * scale1 : 0.f) : x[e]) : 0.f;
+      xv[j] = NEED_DW ? x[e] : 0.f;                 // both loads unconditional: a load that
+      mb[j] = MASKED ? mask1[e] : 1;                // depends on the mask byte would serialise them
     }
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
       const int r = wave + kHbWaves * j;
       if (r < nb) {                                 // wave-uniform
+        // x holds the features BEFORE the dropout: what the forward multiplied is mask*scale*x
+        const bool kept = !MASKED || (int)mb[j] >= thr1;
+        const float xm = MASKED ? (kept ? xv[j] * scale1 : 0.f) : xv[j];
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < kHeadO / 4; ++q) {
@@ -224,13 +226,13 @@ __global__ __launch_bounds__(kHbWaves * 64) void potes_head_bwd_kernel(
           s = fmaf(d.z, wcol[4 * q + 2], s);
           s = fmaf(d.w, wcol[4 * q + 3], s);
           if (NEED_DW) {
-            acc[4 * q] = fmaf(d.x, xv[j], acc[4 * q]);
-            acc[4 * q + 1] = fmaf(d.y, xv[j], acc[4 * q + 1]);
-            acc[4 * q + 2] = fmaf(d.z, xv[j], acc[4 * q + 2]);
-            acc[4 * q + 3] = fmaf(d.w, xv[j], acc[4 * q + 3]);
+            acc[4 * q] = fmaf(d.x, xm, acc[4 * q]);
+            acc[4 * q + 1] = fmaf(d.y, xm, acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(d.z, xm, acc[4 * q + 2]);
+            acc[4 * q + 3] = fmaf(d.w, xm, acc[4 * q + 3]);
           }
         }
-        if (valid && dx) dx[(size_t)(b0 + r) * K + k] = mb[j] ? s * scale1 : 0.f;
+        if (valid && dx) dx[(size_t)(b0 + r) * K + k] = kept ? s * scale1 : 0.f;
       }
     }
   }
