@@ -340,9 +340,11 @@ int pcgmix_adam_clip_multi_f32(int n_tensors, float* const* p, const float* cons
  * Replaces CNN_potes' Dropout(.25) -> Flatten/concat -> dimreduc Linear(K->20) -> ReLU ->
  * Dropout(.5) -> Linear(20->C) (models.py:364, 376-381, 456-465) and their autograd twins.
  *   x       (B,K) features BEFORE the Dropout(.25) of the conv branch (K % 4 == 0, 16-byte aligned)
- *   mask1   (B,K) bytes or NULL (no dropout): element kept iff byte >= thr1, kept values times
- *           scale1.  thr = 1 reads a 0/1 mask; thr = 256*p reads uniformly random bytes (then
- *           scale = 256/(256-thr)).  4-byte aligned.  Applied where x is read: no separate pass.
+ *   mask1   random bits or NULL (no dropout): element e = b*K + k owns bits1 (1, 2, 4 or 8)
+ *           consecutive bits at bit offset e*bits1 and is kept iff their value >= thr1, kept
+ *           values times scale1.  bits1 = 8, thr1 = 1 reads a 0/1 byte mask; uniformly random bits
+ *           with thr1 = 2^bits1 * p drop with probability p exactly (p = 0.25: 2 bits, thr 1;
+ *           scale = 1/(1-p)).  4-byte aligned.  Applied where x is read: no separate pass.
  *   w1,b1   dimreduc (20,K), (20) — b1 may be NULL;   w2,b2  linear (C,20), (C), C <= 8
  *   mask2   (B,20) bytes, kept iff byte >= thr2, NULL = no dropout (eval); scale2 as scale1
  *   partial workspace, pcgmix_skinny_linear_splits(B,K) * B * 20 floats
@@ -354,13 +356,14 @@ int pcgmix_adam_clip_multi_f32(int n_tensors, float* const* p, const float* cons
  * x is read once and dx written once (9 bytes per feature element); reductions are fixed-order.
  */
 int pcgmix_potes_head_fwd_f32(const float* x, const uint8_t* mask1, float scale1, int thr1,
-                              const float* w1, const float* b1, const uint8_t* mask2, float scale2,
+                              int bits1, const float* w1, const float* b1, const uint8_t* mask2, float scale2,
                               int thr2, const float* w2, const float* b2, float* partial, float* z,
                               float* logits, int B, int K, int C, pcgmix_stream_t stream);
 int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, const uint8_t* mask2,
                               float scale2, int thr2, const float* w2, const float* x,
-                              const uint8_t* mask1, float scale1, int thr1, const float* w1,
-                              float* dz, float* dw2, float* db2, float* db1, float* dw1, float* dx,
+                              const uint8_t* mask1, float scale1, int thr1, int bits1,
+                              const float* w1, float* dz, float* dw2, float* db2, float* db1,
+                              float* dw1, float* dx,
                               int B, int K, int C, pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

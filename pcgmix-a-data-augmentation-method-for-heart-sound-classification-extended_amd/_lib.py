@@ -60,11 +60,12 @@ SIGNATURES = {
     "pcgmix_adam_clip_multi_f32": (_c_int, [_c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float,
                                             _c_float, _c_float, _c_float, _c_float,
                                             ctypes.c_longlong, _ptr]),
-    "pcgmix_potes_head_fwd_f32": (_c_int, [_ptr, _ptr, _c_float, _c_int, _ptr, _ptr, _ptr, _c_float, _c_int,
-                                           _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr]),
+    "pcgmix_potes_head_fwd_f32": (_c_int, [_ptr, _ptr, _c_float, _c_int, _c_int, _ptr, _ptr, _ptr, _c_float,
+                                           _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int,
+                                           _ptr]),
     "pcgmix_potes_head_bwd_f32": (_c_int, [_ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _ptr, _ptr, _c_float,
-                                           _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int,
-                                           _c_int, _c_int, _ptr]),
+                                           _c_int, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                           _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_soft_ce_fwd_f32": (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),
     "pcgmix_soft_ce_bwd_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),
     "pcgmix_splice_same_label_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, ctypes.c_uint64, _c_float, _ptr,

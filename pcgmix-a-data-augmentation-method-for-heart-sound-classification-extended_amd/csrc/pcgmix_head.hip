@@ -175,7 +175,7 @@ constexpr int kHbWaves = 4, kHbRows = 64, kHbSplit = 2;
 template <bool MASKED, bool NEED_DW>
 __global__ __launch_bounds__(kHbWaves * 64) void potes_head_bwd_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, const uint8_t* __restrict__ mask1,
-    float scale1, int thr1, const float* __restrict__ w1, float* __restrict__ dw1,
+    float scale1, int thr1, int bits1, const float* __restrict__ w1, float* __restrict__ dw1,
     float* __restrict__ dx, int B, int K) {
   __shared__ __align__(16) float dzl[kHbRows * kHeadO];
   __shared__ float red[kHbWaves][kHeadO][kHbCols];
@@ -208,14 +208,16 @@ __global__ __launch_bounds__(kHbWaves * 64) void potes_head_bwd_kernel(
       const int r = wave + kHbWaves * j;
       const size_t e = (valid && r < nb) ? (size_t)(b0 + r) * K + k : 0;
       xv[j] = NEED_DW ? x[e] : 0.f;                 // both loads unconditional: a load that
-      mb[j] = MASKED ? mask1[e] : 1;                // depends on the mask byte would serialise them
+      mb[j] = MASKED ? mask1[(e * (size_t)bits1) >> 3] : 1;   // depends on the mask would serialise them
     }
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
       const int r = wave + kHbWaves * j;
       if (r < nb) {                                 // wave-uniform
         // x holds the features BEFORE the dropout: what the forward multiplied is mask*scale*x
-        const bool kept = !MASKED || (int)mb[j] >= thr1;
+        // element (row, k) owns bits1 random bits at bit offset (row*K + k)*bits1; K % 4 == 0
+        const bool kept = !MASKED ||
+            (int)((mb[j] >> ((k * bits1) & 7)) & ((1u << bits1) - 1u)) >= thr1;
         const float xm = MASKED ? (kept ? xv[j] * scale1 : 0.f) : xv[j];
         float s = 0.f;
 #pragma unroll
@@ -325,7 +327,7 @@ extern "C" int pcgmix_soft_ce_bwd_f32(const float* logits, const float* target, 
 }
 
 extern "C" int pcgmix_potes_head_fwd_f32(const float* x, const uint8_t* mask1, float scale1,
-                                         int thr1, const float* w1, const float* b1,
+                                         int thr1, int bits1, const float* w1, const float* b1,
                                          const uint8_t* mask2, float scale2, int thr2,
                                          const float* w2, const float* b2, float* partial, float* z,
                                          float* logits, int B, int K, int C,
@@ -333,7 +335,8 @@ extern "C" int pcgmix_potes_head_fwd_f32(const float* x, const uint8_t* mask1, f
   using namespace pcgmix;
   if (!w2 || !z || !logits || C <= 0 || C > kHeadMaxC) return hipErrorInvalidValue;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const hipError_t e = launch_skinny_partial(x, w1, partial, B, K, kHeadO, s, mask1, scale1, thr1);
+  const hipError_t e =
+      launch_skinny_partial(x, w1, partial, B, K, kHeadO, s, mask1, scale1, thr1, bits1);
   if (e != hipSuccess) return (int)e;
   const int KS = pcgmix_skinny_linear_splits(B, K);
   hipLaunchKernelGGL(potes_tail_fwd_kernel, dim3((unsigned)((B + kTailRows - 1) / kTailRows)),
@@ -344,13 +347,14 @@ extern "C" int pcgmix_potes_head_fwd_f32(const float* x, const uint8_t* mask1, f
 
 extern "C" int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, const uint8_t* mask2,
                                          float scale2, int thr2, const float* w2, const float* x,
-                                         const uint8_t* mask1, float scale1, int thr1,
+                                         const uint8_t* mask1, float scale1, int thr1, int bits1,
                                          const float* w1, float* dz, float* dw2, float* db2,
                                          float* db1, float* dw1, float* dx, int B, int K, int C,
                                          pcgmix_stream_t stream) {
   using namespace pcgmix;
   if (!dlogits || !z || !w2 || !x || !w1 || !dz || !dw2 || (!dw1 && !dx) || B <= 0 || K <= 0 ||
-      C <= 0 || C > kHeadMaxC || (reinterpret_cast<uintptr_t>(dz) & 15))
+      C <= 0 || C > kHeadMaxC || (reinterpret_cast<uintptr_t>(dz) & 15) ||
+      (mask1 && bits1 != 1 && bits1 != 2 && bits1 != 4 && bits1 != 8) || (K & 3))
     return hipErrorInvalidValue;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const long long n_dw1 = dw1 ? (long long)kHeadO * K : 0;
@@ -361,16 +365,16 @@ extern "C" int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, c
   if (!dw1) {                      // frozen weights: dx only
     if (mask1)
       hipLaunchKernelGGL((potes_head_bwd_kernel<true, false>), grid, block, 0, s, dz, x, mask1, scale1,
-                         thr1, w1, dw1, dx, B, K);
+                         thr1, bits1, w1, dw1, dx, B, K);
     else
       hipLaunchKernelGGL((potes_head_bwd_kernel<false, false>), grid, block, 0, s, dz, x, mask1, 1.0f,
-                         0, w1, dw1, dx, B, K);
+                         0, 8, w1, dw1, dx, B, K);
   } else if (mask1) {
     hipLaunchKernelGGL((potes_head_bwd_kernel<true, true>), grid, block, 0, s, dz, x, mask1, scale1,
-                       thr1, w1, dw1, dx, B, K);
+                       thr1, bits1, w1, dw1, dx, B, K);
   } else {
     hipLaunchKernelGGL((potes_head_bwd_kernel<false, true>), grid, block, 0, s, dz, x, mask1, 1.0f, 0,
-                       w1, dw1, dx, B, K);
+                       8, w1, dw1, dx, B, K);
   }
   return (int)hipGetLastError();
 }

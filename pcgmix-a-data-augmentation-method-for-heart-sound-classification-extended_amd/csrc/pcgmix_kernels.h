@@ -21,9 +21,11 @@ inline hipError_t allow_large_lds(const void* kernel, unsigned long long* done, 
 }
 
 // pcgmix_potes.hip: split-K partial products of the skinny linear layer (see there).
-// mask != nullptr: h holds the features before dropout; kept iff mask byte >= thr, times scale.
+// mask != nullptr: h holds the features before dropout; element e owns `bits` random bits of mask
+// (bit offset e*bits), kept iff their value >= thr, times scale.
 hipError_t launch_skinny_partial(const float* h, const float* W, float* partial, int B, int K,
-                                 int O, hipStream_t s, const uint8_t* mask, float scale, int thr);
+                                 int O, hipStream_t s, const uint8_t* mask, float scale, int thr,
+                                 int bits);
 
 }  // namespace pcgmix
 #endif

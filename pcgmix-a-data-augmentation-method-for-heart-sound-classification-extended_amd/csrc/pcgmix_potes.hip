@@ -838,12 +838,13 @@ constexpr int kSkStride = 68;       // LDS row stride in floats (16-byte aligned
 // tile of W row-contiguously (4 rows x 256 B per request), parks them in LDS and reads them back
 // in operand order; the next step's global loads are in flight while the MFMAs run.
 // MASK: h is the feature matrix BEFORE Dropout(p1); the dropout is applied while the tile is
-// parked in LDS: element kept iff mask[b][k] >= thr (bytes, same shape as h), kept values times
-// `scale`.  Spares the separate dropout pass (a 20 MB write and re-read at bs=256).
+// parked in LDS: element e = b*K + k owns `bits` (1, 2, 4 or 8) consecutive random bits of `mask`
+// (bit offset e*bits), kept iff their value >= thr, kept values times `scale`.  Spares the
+// separate dropout pass (a 20 MB write and re-read at bs=256).
 template <int O, bool MASK>
 __global__ __launch_bounds__(kSkinnyWaves * 64) void skinny_linear_partial_kernel(
     const float* __restrict__ h, const float* __restrict__ W, float* __restrict__ partial, int B,
-    int K, const uint8_t* __restrict__ mask, float scale, int thr) {
+    int K, const uint8_t* __restrict__ mask, float scale, int thr, int bits) {
   constexpr int kWRows = (O + 3) / 4 * 4;                                // W tile rows in LDS
   constexpr int kWaveFloats = (32 + kWRows) * kSkStride;
   __shared__ __align__(16) float smem[kSkinnyWaves * kWaveFloats];
@@ -869,7 +870,10 @@ __global__ __launch_bounds__(kSkinnyWaves * 64) void skinny_linear_partial_kerne
       const size_t e = (size_t)(row < B ? row : B - 1) * K + (ok ? k : 0);
       const f4 v = *reinterpret_cast<const f4*>(h + e);
       gx[it] = ok ? v : z4;
-      if (MASK) gm[it] = *reinterpret_cast<const uint32_t*>(mask + e);   // 4 bytes: K % 4 == 0
+      if (MASK) {     // the 4*bits random bits of this float4 (e % 4 == 0: byte- or word-aligned)
+        gm[it] = bits == 8 ? *reinterpret_cast<const uint32_t*>(mask + e)
+                           : (uint32_t)mask[(e * (size_t)bits) >> 3] >> ((e * (size_t)bits) & 7);
+      }
     }
 #pragma unroll
     for (int it = 0; it < kWRows / 4; ++it) {
@@ -888,11 +892,11 @@ __global__ __launch_bounds__(kSkinnyWaves * 64) void skinny_linear_partial_kerne
     for (int it = 0; it < 8; ++it) {
       f4 v = gx[it];
       if (MASK) {
-        const uint32_t m = gm[it];
-        v.x = (int)(m & 0xffu) >= thr ? v.x * scale : 0.f;
-        v.y = (int)((m >> 8) & 0xffu) >= thr ? v.y * scale : 0.f;
-        v.z = (int)((m >> 16) & 0xffu) >= thr ? v.z * scale : 0.f;
-        v.w = (int)(m >> 24) >= thr ? v.w * scale : 0.f;
+        const uint32_t m = gm[it], fm = (1u << bits) - 1u;
+        v.x = (int)(m & fm) >= thr ? v.x * scale : 0.f;
+        v.y = (int)((m >> bits) & fm) >= thr ? v.y * scale : 0.f;
+        v.z = (int)((m >> (2 * bits)) & fm) >= thr ? v.z * scale : 0.f;
+        v.w = (int)((m >> (3 * bits)) & fm) >= thr ? v.w * scale : 0.f;
       }
       *reinterpret_cast<f4*>(xs + (4 * it + lr) * kSkStride + lc) = v;
     }
@@ -1221,29 +1225,32 @@ extern "C" int pcgmix_skinny_linear_splits(int B, int K) {
 namespace pcgmix {
 // Launch the split-K partial products of z = h W^T (shared with the fused head, pcgmix_head.hip).
 hipError_t launch_skinny_partial(const float* h, const float* W, float* partial, int B, int K,
-                                 int O, hipStream_t s, const uint8_t* mask, float scale, int thr) {
+                                 int O, hipStream_t s, const uint8_t* mask, float scale, int thr,
+                                 int bits) {
   if (!h || !W || !partial || B <= 0 || K <= 0 || (K & 3) || O <= 0 || O > kSkinnyMaxO)
     return hipErrorInvalidValue;
   if ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(W)) & 15)
     return hipErrorInvalidValue;
-  if (mask && (reinterpret_cast<uintptr_t>(mask) & 3)) return hipErrorInvalidValue;
+  if (mask && ((reinterpret_cast<uintptr_t>(mask) & 3) ||
+               (bits != 1 && bits != 2 && bits != 4 && bits != 8)))
+    return hipErrorInvalidValue;
   const int KS = pcgmix_skinny_linear_splits(B, K);
   dim3 grid((unsigned)((B + kSkinnyRows - 1) / kSkinnyRows), (unsigned)KS),
       block(kSkinnyWaves * 64);
   if (O == 20 && mask) {
     hipLaunchKernelGGL((skinny_linear_partial_kernel<20, true>), grid, block, 0, s, h, W, partial, B, K,
-                       mask, scale, thr);
+                       mask, scale, thr, bits);
   } else if (mask) {
     return hipErrorInvalidValue;                      // the masked variant exists for the Potes head
   } else if (O == 20) {
     hipLaunchKernelGGL((skinny_linear_partial_kernel<20, false>), grid, block, 0, s, h, W, partial, B,
-                       K, nullptr, 1.f, 0);
+                       K, nullptr, 1.f, 0, 8);
   } else if (O == 8) {
     hipLaunchKernelGGL((skinny_linear_partial_kernel<8, false>), grid, block, 0, s, h, W, partial, B,
-                       K, nullptr, 1.f, 0);
+                       K, nullptr, 1.f, 0, 8);
   } else if (O == 16) {
     hipLaunchKernelGGL((skinny_linear_partial_kernel<16, false>), grid, block, 0, s, h, W, partial, B,
-                       K, nullptr, 1.f, 0);
+                       K, nullptr, 1.f, 0, 8);
   } else {
     return hipErrorInvalidValue;
   }
@@ -1257,7 +1264,7 @@ extern "C" int pcgmix_skinny_linear_fwd_f32(const float* h, const float* W, cons
   using namespace pcgmix;
   if (!z) return hipErrorInvalidValue;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const hipError_t e = launch_skinny_partial(h, W, partial, B, K, O, s, nullptr, 1.f, 0);
+  const hipError_t e = launch_skinny_partial(h, W, partial, B, K, O, s, nullptr, 1.f, 0, 8);
   if (e != hipSuccess) return (int)e;
   const int KS = pcgmix_skinny_linear_splits(B, K);
   const int n = B * O;

@@ -138,18 +138,28 @@ class SkinnyLinearFunction(torch.autograd.Function):
         return gx, gw, gb
 
 
-def dropout_threshold(p: float):
-    """(thr, scale) of the byte rule the head kernels apply: an element is kept iff its uniformly
-    random byte >= thr, thr = round(256 p); the drop probability is thr/256 (exact for the
-    reference's 0.25 and 0.5) and kept values are scaled by 256/(256-thr)."""
-    thr = min(255, max(0, int(round(256.0 * p))))
-    return thr, 256.0 / (256.0 - thr)
+def dropout_threshold(p: float, max_bits: int = 8):
+    """(bits, thr, scale) of the rule the head kernels apply: an element owns ``bits`` uniformly
+    random bits and is kept iff their value >= thr.  The fewest bits (1, 2, 4, 8) that represent p
+    exactly are used (0.5: 1 bit, 0.25: 2 bits); otherwise 8 bits with p rounded to 1/256ths.
+    Kept values are scaled by 2^bits/(2^bits - thr)."""
+    for bits in (1, 2, 4, 8):
+        if bits > max_bits:
+            break
+        v = p * (1 << bits)
+        if abs(v - round(v)) < 1e-9 or bits == 8:
+            thr = min((1 << bits) - 1, max(0, int(round(v))))
+            return bits, thr, float(1 << bits) / float((1 << bits) - thr)
+    bits = max_bits
+    thr = min((1 << bits) - 1, max(0, int(round(p * (1 << bits)))))
+    return bits, thr, float(1 << bits) / float((1 << bits) - thr)
 
 
-def head_dropout_bytes(B: int, K: int) -> int:
-    """Random bytes one training forward of the head consumes: B*K for Dropout(p1) on the features,
-    B*20 for Dropout(p2) on the hidden layer (the second block starts 16-byte aligned)."""
-    return ((B * K + 15) // 16) * 16 + B * 20
+def head_dropout_bytes(B: int, K: int, p1: float = 0.25) -> int:
+    """Random bytes one training forward of the head consumes: B*K*bits(p1)/8 for Dropout(p1) on
+    the features (padded to 16), B*20 bytes for Dropout(p2) on the hidden layer."""
+    bits = dropout_threshold(p1)[0] if p1 > 0.0 else 0
+    return ((B * K * bits // 8 + 15) // 16) * 16 + B * 20
 
 
 class PotesHeadFunction(torch.autograd.Function):
@@ -171,17 +181,21 @@ class PotesHeadFunction(torch.autograd.Function):
         x = feat.contiguous()
         mask1 = mask2 = None
         thr1 = thr2 = 0
+        bits1 = 8
         s1 = s2 = 1.0
         if training and (p1 > 0.0 or p2 > 0.0):
-            n = head_dropout_bytes(B, K)
+            n = head_dropout_bytes(B, K, p1)
             if rnd is None:
                 rnd = torch.empty(n, dtype=torch.uint8, device=dev).random_()
             elif rnd.numel() < n or rnd.dtype != torch.uint8 or not rnd.is_contiguous():
-                raise ValueError("rnd must be a contiguous uint8 tensor of head_dropout_bytes(B, K)")
+                raise ValueError("rnd must be a contiguous uint8 tensor of head_dropout_bytes(B, K, p1)")
             if p1 > 0.0:
-                mask1, (thr1, s1) = rnd[:B * K], dropout_threshold(p1)
+                bits1, thr1, s1 = dropout_threshold(p1)
+                mask1 = rnd[:B * K * bits1 // 8]
             if p2 > 0.0:
-                mask2, (thr2, s2) = rnd[n - B * 20:n], dropout_threshold(p2)
+                _b, thr2, s2 = dropout_threshold(p2, max_bits=8)
+                thr2, s2 = (256 * thr2) >> _b, s2           # the hidden mask is read as whole bytes
+                mask2 = rnd[n - B * 20:n]
         w1c, w2c = w1.detach().contiguous(), w2.detach().contiguous()
         ks = lib.pcgmix_skinny_linear_splits(B, K)
         partial = torch.empty((ks, B, 20), dtype=torch.float32, device=dev)
@@ -190,19 +204,19 @@ class PotesHeadFunction(torch.autograd.Function):
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         opt = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         _lib.check(lib.pcgmix_potes_head_fwd_f32(
-            x.data_ptr(), opt(mask1), ctypes.c_float(s1), thr1, w1c.data_ptr(),
+            x.data_ptr(), opt(mask1), ctypes.c_float(s1), thr1, bits1, w1c.data_ptr(),
             b1.detach().data_ptr() if b1 is not None else None, opt(mask2), ctypes.c_float(s2), thr2,
             w2c.data_ptr(), b2.detach().data_ptr() if b2 is not None else None, partial.data_ptr(),
             z.data_ptr(), logits.data_ptr(), B, K, C, stream), "pcgmix_potes_head_fwd_f32")
         ctx.save_for_backward(x, w1c, w2c, z, mask1, mask2)
-        ctx.drop = (thr1, s1, thr2, s2)
+        ctx.drop = (thr1, bits1, s1, thr2, s2)
         ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         x, w1, w2, z, mask1, mask2 = ctx.saved_tensors
-        thr1, s1, thr2, s2 = ctx.drop
+        thr1, bits1, s1, thr2, s2 = ctx.drop
         B, K = x.shape
         C = w2.shape[0]
         dev = x.device
@@ -220,7 +234,7 @@ class PotesHeadFunction(torch.autograd.Function):
         opt = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         _lib.check(lib.pcgmix_potes_head_bwd_f32(
             dlogits.data_ptr(), z.data_ptr(), opt(mask2), ctypes.c_float(s2), thr2, w2.data_ptr(),
-            x.data_ptr(), opt(mask1), ctypes.c_float(s1), thr1, w1.data_ptr(),
+            x.data_ptr(), opt(mask1), ctypes.c_float(s1), thr1, bits1, w1.data_ptr(),
             dz.data_ptr(), dw2.data_ptr(), opt(db2), opt(db1), opt(dw1), opt(dx), B, K, C,
             stream), "pcgmix_potes_head_bwd_f32")
         return dx, dw1, db1, dw2, db2, None, None, None, None

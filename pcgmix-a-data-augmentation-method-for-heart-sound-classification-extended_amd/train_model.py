@@ -382,8 +382,9 @@ class GraphedTrainStep:
         inner = model.module if hasattr(model, "module") else model
         if isinstance(inner, models.CNN_potes) and device.type == "cuda":
             K = inner.dimreduc.in_features
-            self.rnd = torch.empty(models.head_dropout_bytes(batch_size, K), dtype=torch.uint8,
-                                   device=device)
+            drop = inner.cnn1[1][3] if len(inner.cnn1[1]) > 3 else None
+            self.rnd = torch.empty(models.head_dropout_bytes(batch_size, K, float(drop.p) if drop else 0.0),
+                                   dtype=torch.uint8, device=device)
             inner.dropout_bytes = self.rnd
         # The warm-up passes run the network on the all-zero placeholder batch: they must leave no
         # trace.  Weights are not updated (no optimiser step); BatchNorm running statistics and

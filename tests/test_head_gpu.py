@@ -50,7 +50,7 @@ def test_head_kernels_match_torch(B, K, C, drop, device):
     m1b = m1.to(torch.uint8).contiguous() if drop else None      # 0/1 bytes, threshold 1
     thr = 1 if drop else 0
     opt = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
-    _lib.check(lib.pcgmix_potes_head_fwd_f32(xd.data_ptr(), opt(m1b), ctypes.c_float(s1), thr,
+    _lib.check(lib.pcgmix_potes_head_fwd_f32(xd.data_ptr(), opt(m1b), ctypes.c_float(s1), thr, 8,
                                              w1.data_ptr(), b1.data_ptr(), opt(m2), ctypes.c_float(s2),
                                              thr, w2.data_ptr(), b2.data_ptr(), partial.data_ptr(),
                                              z.data_ptr(), logits.data_ptr(), B, K, C, _stream(device)),
@@ -61,7 +61,7 @@ def test_head_kernels_match_torch(B, K, C, drop, device):
     dw2, db2, db1 = torch.empty(C, 20, device=device), torch.empty(C, device=device), torch.empty(20, device=device)
     dw1, dx = torch.empty(20, K, device=device), torch.empty(B, K, device=device)
     _lib.check(lib.pcgmix_potes_head_bwd_f32(dl.data_ptr(), z.data_ptr(), opt(m2), ctypes.c_float(s2), thr,
-                                             w2.data_ptr(), xd.data_ptr(), opt(m1b), ctypes.c_float(s1), thr,
+                                             w2.data_ptr(), xd.data_ptr(), opt(m1b), ctypes.c_float(s1), thr, 8,
                                              w1.data_ptr(), dz.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
                                              db1.data_ptr(), dw1.data_ptr(), dx.data_ptr(), B, K, C,
                                              _stream(device)), "bwd")
@@ -184,24 +184,31 @@ def test_head_input_gradient_with_frozen_weights(training, device):
         assert torch.allclose(outs[0][1], gt, rtol=1e-4, atol=1e-6 * float(gt.abs().max()) + 1e-9)
 
 
-def test_random_byte_dropout_is_torch_dropout_with_the_same_mask(device):
-    """Training mode reads uniformly random bytes (kept iff byte >= 256 p): against torch ops given
-    the masks those bytes define; exact keep probabilities for the reference's p = 0.25 / 0.5."""
+@pytest.mark.parametrize("p1,p2", [(0.25, 0.5), (0.5, 0.25), (0.1, 0.5), (0.0625, 0.3)])
+def test_random_bit_dropout_is_torch_dropout_with_the_same_mask(p1, p2, device):
+    """Training mode reads uniformly random bits (an element owns 1, 2, 4 or 8 of them and is kept
+    iff their value >= thr): against torch ops given the masks those bits define; the keep
+    probabilities are exact for the reference's p = 0.25 (2 bits) and 0.5 (1 bit)."""
     from pcgmix_amd import models
     torch.manual_seed(4)
     B, K = 64, 9968
     lin1, lin2 = torch.nn.Linear(K, 20).to(device), torch.nn.Linear(20, 2).to(device)
     feat = torch.randn(B, K, device=device).relu_()
-    rnd = torch.empty(models.head_dropout_bytes(B, K), dtype=torch.uint8, device=device).random_()
+    rnd = torch.empty(models.head_dropout_bytes(B, K, p1), dtype=torch.uint8, device=device).random_()
     x = feat.clone().requires_grad_(True)
-    lo = models.PotesHeadFunction.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, 0.25, 0.5,
+    lo = models.PotesHeadFunction.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, p1, p2,
                                         True, rnd)
     r = torch.randn(B, 2, device=device)
     g = torch.autograd.grad((lo * r).sum(), [x, lin1.weight, lin2.weight])
-    assert models.dropout_threshold(0.25) == (64, 256 / 192) and models.dropout_threshold(0.5) == (128, 2.0)
-    m1 = (rnd[:B * K].view(B, K) >= 64).float() * (256 / 192)
-    m2 = (rnd[rnd.numel() - B * 20:].view(B, 20) >= 128).float() * 2.0
-    assert abs(float((m1 > 0).float().mean()) - 0.75) < 5e-3 and abs(float((m2 > 0).float().mean()) - 0.5) < 0.06
+    assert models.dropout_threshold(0.25) == (2, 1, 4 / 3) and models.dropout_threshold(0.5) == (1, 1, 2.0)
+    bits, thr, sc = models.dropout_threshold(p1)
+    e = torch.arange(B * K, device=device)
+    val = (rnd[(e * bits) >> 3].to(torch.int32) >> ((e * bits) & 7)) & ((1 << bits) - 1)
+    m1 = (val >= thr).float().view(B, K) * sc
+    b2, t2, s2 = models.dropout_threshold(p2)
+    m2 = (rnd[rnd.numel() - B * 20:].view(B, 20).to(torch.int32) >= ((256 * t2) >> b2)).float() * s2
+    assert abs(float((m1 > 0).float().mean()) - (1 - thr / (1 << bits))) < 5e-3
+    assert abs(float((m2 > 0).float().mean()) - (1 - t2 / (1 << b2))) < 0.06
     xt = feat.clone().requires_grad_(True)
     ref = lin2(torch.relu(lin1(xt * m1)) * m2)
     gt = torch.autograd.grad((ref * r).sum(), [xt, lin1.weight, lin2.weight])
