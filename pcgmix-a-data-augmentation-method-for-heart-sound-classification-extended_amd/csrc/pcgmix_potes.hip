@@ -871,8 +871,10 @@ __global__ __launch_bounds__(kSkinnyWaves * 64) void skinny_linear_partial_kerne
       const f4 v = *reinterpret_cast<const f4*>(h + e);
       gx[it] = ok ? v : z4;
       if (MASK) {     // the 4*bits random bits of this float4 (e % 4 == 0: byte- or word-aligned)
-        gm[it] = bits == 8 ? *reinterpret_cast<const uint32_t*>(mask + e)
-                           : (uint32_t)mask[(e * (size_t)bits) >> 3] >> ((e * (size_t)bits) & 7);
+        const size_t bit = e * (size_t)bits;
+        gm[it] = bits == 8   ? *reinterpret_cast<const uint32_t*>(mask + e)
+                 : bits == 4 ? (uint32_t)*reinterpret_cast<const uint16_t*>(mask + (bit >> 3))
+                             : (uint32_t)mask[bit >> 3] >> (bit & 7);
       }
     }
 #pragma unroll
