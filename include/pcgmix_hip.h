@@ -166,19 +166,16 @@ int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames, float* sa
  *
  *   sal         device, (B, T) saliency maps
  *   disp        device, int32 (B, 4) out — feeds pcgmix_mix_warp_f32's `off`
- *   workspace   device, pcgmix_salopt_workspace_bytes(B, max_len) bytes, 16-byte aligned: the
- *               candidates of one (sample, state) are shared out over several blocks (a
- *               device-built work list of 32-candidate chunks when max_len <= 1536; inside a
- *               chunk a lane owns one (candidate, 128-element leaf of numpy's summation tree));
- *               their partial arg-maxima meet here (greatest value, smallest displacement on
- *               ties = first strict maximum)
+ *   workspace   device, pcgmix_salopt_workspace_bytes(B) bytes, 8-byte aligned: the candidates of
+ *               one (sample, state) are shared out over several blocks; their partial arg-maxima
+ *               meet here (greatest value, smallest displacement on ties = first strict maximum)
  *   max_len     the longest heart state of the batch in samples, max_k,b(frames[b][k+1] -
  *               frames[b][k]) — the caller has `frames` on the host — or 0 for "unknown" (= T).
  *               It sizes the blocks' LDS (2 * max_len floats): the smaller, the more blocks a CU
  *               holds.  States longer than max_len are cut to it (memory safety only).
  *   B <= 65535, T <= 19000
  */
-long long pcgmix_salopt_workspace_bytes(int B, int max_len);
+long long pcgmix_salopt_workspace_bytes(int B);
 int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames, const int32_t* mix_idx,
                            float lam, int mode, int32_t* disp, void* workspace, int max_len, int B,
                            int T, pcgmix_stream_t stream);

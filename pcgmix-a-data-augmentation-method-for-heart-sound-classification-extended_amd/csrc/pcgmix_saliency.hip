@@ -10,7 +10,6 @@
 // so that a saliency-guided step needs no host round trip: the displacement table they produce is
 // consumed directly by pcgmix_mix_warp_f32 as its `off` argument.
 #include <hip/hip_runtime.h>
-#include <stdlib.h>
 #include <math.h>
 #include <stdint.h>
 
@@ -208,11 +207,9 @@ __device__ __forceinline__ int pw_split(int n) {
   return n2 - (n2 % 8);
 }
 
-// leaf(start, cn) yields the sum of one leaf (cn <= 128 elements from `start`); the walk visits the
-// leaves left to right and combines their sums in numpy's order.
-template <class LeafFn>
-__device__ __forceinline__ float pw_walk(int n, LeafFn leaf) {
-  if (n <= 128) return leaf(0, n);
+template <class F>
+__device__ __forceinline__ float pw_sum(F elem, int n) {
+  if (n <= 128) return pw_leaf(elem, 0, n);
   float left[kPwDepth];
 #pragma unroll
   for (int l = 0; l < kPwDepth; ++l) left[l] = 0.f;
@@ -229,7 +226,7 @@ __device__ __forceinline__ float pw_walk(int n, LeafFn leaf) {
       ++depth;
       continue;
     }
-    float v = leaf(start, cn);
+    float v = pw_leaf(elem, start, cn);
     for (;;) {  // climb
       if (depth == 0) return v;
       const int lvl = depth - 1;
@@ -246,11 +243,6 @@ __device__ __forceinline__ float pw_walk(int n, LeafFn leaf) {
       depth = lvl;
     }
   }
-}
-
-template <class F>
-__device__ __forceinline__ float pw_sum(F elem, int n) {
-  return pw_walk(n, [&](int start, int cn) { return pw_leaf(elem, start, cn); });
 }
 
 // kDispSplit blocks of 256 threads per (state k, sample b): block z takes the candidates
@@ -368,240 +360,6 @@ __global__ void salopt_finalize_kernel(const float2* __restrict__ part, int32_t*
   disp[i] = (bd == 0x7fffffff) ? 0 : bd;  // equal lengths, or an all-NaN objective: the reference keeps 0
 }
 
-// ---- leaf-level displacement search ------------------------------------------------------------
-// With a lane per candidate the launch lasts as long as one wave's chain of order-constrained
-// 8-wide add groups: 27 us for the heaviest pair ALONE on the chip, whatever the block shape
-// (profiles/probes/disp_single_pair.py, disp_sweep.sh).  numpy's summation fixes the order INSIDE a
-// leaf (<= 128 elements) and the order in which leaf sums are combined — but leaves are independent
-// of each other.  So a work item here is a chunk of kLeafNC candidates of one (sample, state) pair,
-// and inside it a lane owns one (candidate, leaf): <= 16 add groups instead of ~290.  Three steps
-// per chunk: (1) enumerate the leaves — once for the middle sum (same length for every candidate),
-// per candidate for the head and tail sums (their lengths are d and gap - d); (2) leaf sums into
-// LDS; (3) one lane per candidate replays the three split trees over the stored sums, forms
-// (head + mid) + tail and takes part in the chunk's arg-max.  Chunks come from a device-side work
-// list (salopt_plan_kernel) handed out by an atomic counter: heavy pairs spread over the chip.
-constexpr int kLeafNC = 32;          // candidates per chunk
-constexpr int kLeafThreads = 256;
-constexpr int kLeafMaxLen = 1536;    // longest state this path takes (else: the per-candidate kernel);
-                                     // numpy's split tree of n <= 1536 elements has <= 16 leaves
-                                     // (the maximum, 16, is reached at n = 1088; n = 1929 has 17)
-constexpr int kLeafMaxSeg = 16;      // leaves of one head / middle / tail sum
-constexpr int kLeafMaxMid = 16;
-
-struct DispPlanHeader {              // first 16 bytes of the workspace
-  unsigned counter, total, pad0, pad1;
-};
-
-// pair index p = y * B + b with y in the heavy-first state order used by the grid kernels
-__device__ __forceinline__ int disp_pair_state(int y) { return (0x2013 >> (4 * y)) & 3; }
-
-__device__ __forceinline__ void disp_pair_lengths(const int32_t* __restrict__ frames,
-                                                  const int32_t* __restrict__ mix_idx, int b, int k,
-                                                  int B, int T, int max_len, int& m, int& a1, int& a2,
-                                                  int& n1, int& n2) {
-  m = mix_idx[b];
-  m = (m < 0 || m >= B) ? b : m;
-  a1 = frames[b * 5 + k];
-  int e1 = frames[b * 5 + k + 1];
-  a2 = frames[m * 5 + k];
-  int e2 = frames[m * 5 + k + 1];
-  a1 = a1 < 0 ? 0 : (a1 > T ? T : a1);
-  e1 = e1 < a1 ? a1 : (e1 > T ? T : e1);
-  a2 = a2 < 0 ? 0 : (a2 > T ? T : a2);
-  e2 = e2 < a2 ? a2 : (e2 > T ? T : e2);
-  e1 = e1 - a1 > max_len ? a1 + max_len : e1;
-  e2 = e2 - a2 > max_len ? a2 + max_len : e2;
-  n1 = e1 - a1;
-  n2 = e2 - a2;
-}
-
-// One block: chunks per pair, exclusive scan, work list (pair, chunk), counter reset.
-__global__ __launch_bounds__(1024) void salopt_plan_kernel(
-    const int32_t* __restrict__ frames, const int32_t* __restrict__ mix_idx, DispPlanHeader* hdr,
-    int* __restrict__ pair_off /* 4B + 1 */, int2* __restrict__ work, int B, int T, int max_len) {
-  __shared__ int scan[1024];
-  __shared__ int carry;
-  const int n_pairs = 4 * B;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n_pairs; base += 1024) {
-    const int p = base + threadIdx.x;
-    int chunks = 0;
-    if (p < n_pairs) {
-      const int b = p % B, k = disp_pair_state(p / B);
-      int m, a1, a2, n1, n2;
-      disp_pair_lengths(frames, mix_idx, b, k, B, T, max_len, m, a1, a2, n1, n2);
-      if (n1 != n2) chunks = ((n1 > n2 ? n1 - n2 : n2 - n1) + 1 + kLeafNC - 1) / kLeafNC;
-    }
-    scan[threadIdx.x] = chunks;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {             // Hillis-Steele inclusive scan
-      const int v = threadIdx.x >= o ? scan[threadIdx.x - o] : 0;
-      __syncthreads();
-      scan[threadIdx.x] += v;
-      __syncthreads();
-    }
-    const int excl = carry + scan[threadIdx.x] - chunks;
-    if (p < n_pairs) {
-      pair_off[p] = excl;
-      for (int c = 0; c < chunks; ++c) work[excl + c] = int2{p, c};
-    }
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += scan[1023];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    pair_off[n_pairs] = carry;
-    hdr->total = (unsigned)carry;
-    hdr->counter = 0u;
-  }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kLeafThreads) void salopt_disp_leaf_kernel(
-    const float* __restrict__ sal, const int32_t* __restrict__ frames,
-    const int32_t* __restrict__ mix_idx, float lam, float oml, DispPlanHeader* hdr,
-    const int2* __restrict__ work, float2* __restrict__ part, int B, int T, int max_len) {
-  extern __shared__ __align__(16) float smem[];      // lng[max_len] | sht[max_len]
-  __shared__ int s_w;
-  __shared__ int mtab[kLeafMaxMid];                  // (start << 8) | len of the middle sum's leaves
-  __shared__ int s_lm;
-  __shared__ unsigned short htab[kLeafNC][kLeafMaxSeg], ttab[kLeafNC][kLeafMaxSeg];  // (start/8 << 8) | len
-  __shared__ unsigned char lh[kLeafNC], lt[kLeafNC];
-  __shared__ float sm[kLeafMaxMid][kLeafNC], sh[kLeafNC][kLeafMaxSeg], st[kLeafNC][kLeafMaxSeg];
-  float* lng = smem;
-  const int tid = threadIdx.x;
-  for (;;) {
-    __syncthreads();                                 // previous chunk's LDS fully consumed
-    if (tid == 0) s_w = (int)atomicAdd(&hdr->counter, 1u);
-    __syncthreads();
-    const int w = s_w;
-    if (w >= (int)hdr->total) return;                // every wave of every block gets here
-    const int2 wk = work[w];
-    const int b = wk.x % B, k = disp_pair_state(wk.x / B);
-    int m, a1, a2, n1, n2;
-    disp_pair_lengths(frames, mix_idx, b, k, B, T, max_len, m, a1, a2, n1, n2);
-    const bool own_longer = n1 > n2;
-    const int nL = own_longer ? n1 : n2, nS = own_longer ? n2 : n1, gap = nL - nS;
-    const int c0 = wk.y * kLeafNC;
-    const int nc = gap + 1 - c0 < kLeafNC ? gap + 1 - c0 : kLeafNC;    // >= 1 by construction
-    const float* gl = sal + (size_t)(own_longer ? b : m) * T + (own_longer ? a1 : a2);
-    const float* gs = sal + (size_t)(own_longer ? m : b) * T + (own_longer ? a2 : a1);
-    float* sht = smem + ((nL + 3) & ~3);
-    for (int i = tid; i < nL; i += kLeafThreads) lng[i] = gl[i];
-    for (int i = tid; i < nS; i += kLeafThreads) sht[i] = gs[i];
-    // (1) leaf tables.  Leaf starts are multiples of 8 (numpy splits at multiples of 8).
-    if (tid == 0) {
-      int cnt = 0;
-      pw_walk(nS, [&](int start, int cn) {
-        if (cnt < kLeafMaxMid) mtab[cnt] = (start << 8) | cn;
-        ++cnt;
-        return 0.f;
-      });
-      s_lm = cnt;
-    }
-    if (own_longer && tid >= 64 && tid < 64 + nc) {            // wave 1: head tables
-      const int c = tid - 64, d = c0 + c;
-      int cnt = 0;
-      pw_walk(d, [&](int start, int cn) {
-        if (cnt < kLeafMaxSeg) htab[c][cnt] = (unsigned short)(((start >> 3) << 8) | cn);
-        ++cnt;
-        return 0.f;
-      });
-      lh[c] = (unsigned char)cnt;
-    }
-    if (own_longer && tid >= 128 && tid < 128 + nc) {          // wave 2: tail tables
-      const int c = tid - 128, d = c0 + c;
-      int cnt = 0;
-      pw_walk(gap - d, [&](int start, int cn) {
-        if (cnt < kLeafMaxSeg) ttab[c][cnt] = (unsigned short)(((start >> 3) << 8) | cn);
-        ++cnt;
-        return 0.f;
-      });
-      lt[c] = (unsigned char)cnt;
-    }
-    __syncthreads();
-    // (2) leaf sums: lane = (leaf slot, candidate), candidates on consecutive lanes
-    const int lm = s_lm;
-    for (int item = tid; item < lm * kLeafNC; item += kLeafThreads) {
-      const int l = item / kLeafNC, c = item - l * kLeafNC;
-      if (c < nc) {
-        const int e = mtab[l];
-        const SeqMid<MODE> mid{lng + c0 + c, sht, lam, oml, own_longer};
-        sm[l][c] = pw_leaf(mid, e >> 8, e & 0xff);
-      }
-    }
-    if (own_longer) {
-      for (int item = tid; item < kLeafMaxSeg * kLeafNC; item += kLeafThreads) {
-        const int l = item / kLeafNC, c = item - l * kLeafNC;
-        if (c < nc) {
-          const int d = c0 + c;
-          if (l < lh[c]) {
-            const int e = htab[c][l];
-            sh[c][l] = pw_leaf(SeqPlain{lng}, (e >> 8) << 3, e & 0xff);
-          }
-          if (l < lt[c]) {
-            const int e = ttab[c][l];
-            st[c][l] = pw_leaf(SeqPlain{lng + d + nS}, (e >> 8) << 3, e & 0xff);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // (3) wave 0: one lane per candidate replays the trees over the stored leaf sums
-    if (tid < 64) {
-      float bv = -INFINITY;
-      int bd = 0x7fffffff;
-      if (tid < nc) {
-        const int c = tid, d = c0 + c;
-        int j = 0;
-        float cur = pw_walk(nS, [&](int, int) { return sm[j++][c]; });
-        if (own_longer) {   // np.sum(s1[:d]) + np.sum(mid) + np.sum(s1[d+n2:])   (:76-78, :111-113)
-          int jh = 0, jt = 0;
-          const float head = pw_walk(d, [&](int, int) { return sh[c][jh++]; });
-          const float tail = pw_walk(gap - d, [&](int, int) { return st[c][jt++]; });
-          cur = __fadd_rn(__fadd_rn(head, cur), tail);
-        }
-        if (cur > bv) {
-          bv = cur;
-          bd = d;
-        }
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, 64);
-        const int od = __shfl_xor(bd, o, 64);
-        if (ov > bv || (ov == bv && od < bd)) {
-          bv = ov;
-          bd = od;
-        }
-      }
-      if (tid == 0) part[w] = float2{bv, __int_as_float(bd)};
-    }
-  }
-}
-
-// Per pair: greatest value over its chunks, smallest displacement on ties (chunks are ascending
-// ranges of d, each holding its own first strict maximum).
-__global__ void salopt_leaf_finalize_kernel(const float2* __restrict__ part,
-                                            const int* __restrict__ pair_off,
-                                            int32_t* __restrict__ disp, int B) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= 4 * B) return;
-  float bv = -INFINITY;
-  int bd = 0x7fffffff;
-  for (int w = pair_off[p]; w < pair_off[p + 1]; ++w) {
-    const float2 q = part[w];
-    const int d = __float_as_int(q.y);
-    if (q.x > bv || (q.x == bv && d < bd)) {
-      bv = q.x;
-      bd = d;
-    }
-  }
-  const int b = p % B, k = disp_pair_state(p / B);
-  disp[b * 4 + k] = (bd == 0x7fffffff) ? 0 : bd;
-}
-
 }  // namespace pcgmix
 
 extern "C" int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames, float* sal,
@@ -642,19 +400,8 @@ extern "C" int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames
   return (int)hipGetLastError();
 }
 
-namespace {
-inline long long leaf_work_items(int B, int max_len) {   // upper bound of the work list
-  return (long long)B * 4 * ((max_len + 1 + pcgmix::kLeafNC - 1) / pcgmix::kLeafNC);
-}
-}  // namespace
-
-extern "C" long long pcgmix_salopt_workspace_bytes(int B, int max_len) {
-  if (B <= 0) return 0;
-  const long long grid_part = (long long)B * 4 * pcgmix::kDispSplit * (long long)sizeof(float2);
-  if (max_len <= 0 || max_len > pcgmix::kLeafMaxLen) return grid_part;
-  const long long items = leaf_work_items(B, max_len);
-  const long long leaf = 16 + (((long long)B * 4 + 1) * 4 + 15) / 16 * 16 + items * 8 + items * 8;
-  return leaf > grid_part ? leaf : grid_part;
+extern "C" long long pcgmix_salopt_workspace_bytes(int B) {
+  return B <= 0 ? 0 : (long long)B * 4 * pcgmix::kDispSplit * (long long)sizeof(float2);
 }
 
 extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
@@ -664,45 +411,11 @@ extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
   using namespace pcgmix;
   if (!sal || !frames || !mix_idx || !disp || !workspace) return hipErrorInvalidValue;
   if (B < 0 || B > 65535 || T <= 0 || (mode != 0 && mode != 1)) return hipErrorInvalidValue;
-  if (reinterpret_cast<uintptr_t>(workspace) & 15) return hipErrorInvalidValue;
+  if (reinterpret_cast<uintptr_t>(workspace) & 7) return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
-  const bool known = max_len > 0 && max_len <= T;
-  if (!known) max_len = T;
-  const float oml = 1.0f - lam;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (max_len <= 0 || max_len > T) max_len = T;
   const size_t lds = sizeof(float) * (size_t)2 * (size_t)((max_len + 3) & ~3);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
-  static const bool force_grid = getenv("PCGMIX_DISP_GRID") != nullptr;     // tuning / A-B runs
-  if (known && max_len <= kLeafMaxLen && !force_grid) {
-    // leaf-level path: plan -> persistent chunk workers -> per-pair arg-max
-    char* ws = static_cast<char*>(workspace);
-    DispPlanHeader* hdr = reinterpret_cast<DispPlanHeader*>(ws);
-    int* pair_off = reinterpret_cast<int*>(ws + 16);
-    const long long off_bytes = (((long long)B * 4 + 1) * 4 + 15) / 16 * 16;
-    const long long items = leaf_work_items(B, max_len);
-    int2* work = reinterpret_cast<int2*>(ws + 16 + off_bytes);
-    float2* part = reinterpret_cast<float2*>(ws + 16 + off_bytes + items * 8);
-    hipLaunchKernelGGL(salopt_plan_kernel, dim3(1), dim3(1024), 0, s, frames, mix_idx, hdr, pair_off,
-                       work, B, T, max_len);
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      static int cached_cus[64] = {0};
-      if (!cached_cus[dev & 63])
-        (void)hipDeviceGetAttribute(&cached_cus[dev & 63], hipDeviceAttributeMultiprocessorCount, dev);
-      if (cached_cus[dev & 63] > 0) cus = cached_cus[dev & 63];
-    }
-    long long blocks = (long long)cus * 6;
-    if (blocks > items) blocks = items;
-    if (mode == 0)
-      hipLaunchKernelGGL(salopt_disp_leaf_kernel<0>, dim3((unsigned)blocks), dim3(kLeafThreads), lds, s,
-                         sal, frames, mix_idx, lam, oml, hdr, work, part, B, T, max_len);
-    else
-      hipLaunchKernelGGL(salopt_disp_leaf_kernel<1>, dim3((unsigned)blocks), dim3(kLeafThreads), lds, s,
-                         sal, frames, mix_idx, lam, oml, hdr, work, part, B, T, max_len);
-    hipLaunchKernelGGL(salopt_leaf_finalize_kernel, dim3((unsigned)((B * 4 + 255) / 256)), dim3(256), 0,
-                       s, part, pair_off, disp, B);
-    return (int)hipGetLastError();
-  }
   static unsigned long long lds_ok0 = 0, lds_ok1 = 0;
   if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(salopt_disp_kernel<0>), &lds_ok0,
                                      150 * 1024))
@@ -710,7 +423,9 @@ extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
   if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(salopt_disp_kernel<1>), &lds_ok1,
                                      150 * 1024))
     return (int)e;
+  const float oml = 1.0f - lam;
   dim3 grid((unsigned)B, 4, kDispSplit), block(kDispThreads);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   float2* part = static_cast<float2*>(workspace);
   if (mode == 0)
     hipLaunchKernelGGL(salopt_disp_kernel<0>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,

@@ -192,8 +192,8 @@ def optimal_displacements(saliency_maps: torch.Tensor, frames_dev_ptr: int, mix_
         raise ValueError("saliency maps must be a contiguous float32 (B, T) device tensor")
     disp = torch.empty((B, 4), dtype=torch.int32, device=saliency_maps.device)
     lib = _lib.load()
-    ws = torch.empty(max(2, (lib.pcgmix_salopt_workspace_bytes(B, int(max_len)) + 15) // 16 * 2),
-                     dtype=torch.int64, device=saliency_maps.device)
+    ws = torch.empty(max(1, lib.pcgmix_salopt_workspace_bytes(B) // 8), dtype=torch.int64,
+                     device=saliency_maps.device)
     stream = torch.cuda.current_stream(saliency_maps.device).cuda_stream
     _lib.check(lib.pcgmix_salopt_disp_f32(saliency_maps.data_ptr(), frames_dev_ptr, mix_dev_ptr,
                                           ctypes.c_float(lam), mode, disp.data_ptr(), ws.data_ptr(),
