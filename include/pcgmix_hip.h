@@ -367,6 +367,33 @@ int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, const uint8_
                               int B, int K, int C, pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Potes classifier head + soft-target cross entropy, fused.                           [device]
+ *
+ * The head above followed by CELoss (train_model.py:45-54: mean_b(-sum_c log_softmax(logits)[b,c]
+ * * target[b,c])) as ONE autograd node: the row-local part of the four small kernels between the
+ * split-K product and the head's backward (tail forward, CE forward, CE backward, tail backward)
+ * runs in one launch, their batch reductions in a second.
+ *   forward : x, masks, weights, target (B,C float, soft targets) -> z, logits, loss (scalar) and,
+ *             for d loss = 1: dz (B,20) and small = [dW2 (C x 20) | db2 (C) | db1 (20)];
+ *             ws: pcgmix_potes_head_loss_workspace_floats(B) floats; dw1_zero (20,K) or NULL: the
+ *             buffer the backward accumulates dW1 into, cleared here.
+ *   backward: gscale = device scalar d L / d loss (NULL = 1): dx and dW1 from dz * gscale in one pass
+ *             over x (as pcgmix_potes_head_bwd_f32), small_out = small_in * gscale.
+ */
+long long pcgmix_potes_head_loss_workspace_floats(int B);
+int pcgmix_potes_head_loss_fwd_f32(const float* x, const uint8_t* mask1, float scale1, int thr1,
+                                   int bits1, const float* w1, const float* b1, const uint8_t* mask2,
+                                   float scale2, int thr2, const float* w2, const float* b2,
+                                   const float* target, float* partial, float* z, float* logits,
+                                   float* dz, float* loss, float* small, float* ws, float* dw1_zero,
+                                   int B, int K, int C, pcgmix_stream_t stream);
+int pcgmix_potes_head_loss_bwd_f32(const float* dz, const float* gscale, const float* x,
+                                   const uint8_t* mask1, float scale1, int thr1, int bits1,
+                                   const float* w1, const float* small_in, float* small_out,
+                                   float* dw1, float* dx, int B, int K, int C,
+                                   pcgmix_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Soft-target cross entropy (train_model.py:45-54, CELoss).                          [device]
  *   loss[0] = mean_b( -sum_c log_softmax(logits)[b,c] * target[b,c] )
  *   dlogits[b,c] = gout[0] / B * (softmax[b,c] * sum_c' target[b,c'] - target[b,c])

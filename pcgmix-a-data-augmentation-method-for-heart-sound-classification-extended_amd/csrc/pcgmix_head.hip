@@ -176,8 +176,15 @@ template <bool MASKED, bool NEED_DW>
 __global__ __launch_bounds__(kHbWaves * 64) void potes_head_bwd_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, const uint8_t* __restrict__ mask1,
     float scale1, int thr1, int bits1, const float* __restrict__ w1, float* __restrict__ dw1,
-    float* __restrict__ dx, int B, int K) {
+    float* __restrict__ dx, int B, int K, const float* __restrict__ gscale,
+    const float* __restrict__ small_in, float* __restrict__ small_out, int n_small) {
   __shared__ __align__(16) float dzl[kHbRows * kHeadO];
+  // gscale (device scalar, may be NULL = 1): the gradient that arrived at the loss — dz was formed
+  // for d loss = 1 by the fused tail+loss kernel; everything downstream is linear in it.  Block
+  // (0,0) also scales the small gradients (dW2, db2, db1) that kernel produced.
+  const float gs = gscale ? gscale[0] : 1.f;
+  if (small_out && blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = threadIdx.x; i < n_small; i += kHbWaves * 64) small_out[i] = small_in[i] * gs;
   __shared__ float red[kHbWaves][kHeadO][kHbCols];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k0 = blockIdx.x * kHbCols, k = k0 + lane;
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(kHbWaves * 64) void potes_head_bwd_kernel(
     __syncthreads();
     for (int i = threadIdx.x; i < nb * (kHeadO / 4); i += kHbWaves * 64)
       *reinterpret_cast<f4*>(dzl + 4 * i) =
-          reinterpret_cast<const f4*>(dz + (size_t)b0 * kHeadO)[i];   // b0 * 80 B: 16-byte aligned
+          reinterpret_cast<const f4*>(dz + (size_t)b0 * kHeadO)[i] * gs;   // b0 * 80 B: 16-byte aligned
     __syncthreads();
     // all of this wave's rows of the chunk are requested before the first is used; the loads are
     // unconditional on a clamped address (a predicated load puts a branch and a vmcnt(0) wait
@@ -306,6 +313,148 @@ __global__ __launch_bounds__(256) void soft_ce_bwd_kernel(const float* __restric
     dlogits[(size_t)b * C + c] = g * (expf(x[c] - m - lse) * ts - t[c]);
 }
 
+// ------------------------------------------------------------------------------ tail + loss, fused
+// potes_tail_fwd_kernel, soft_ce_fwd_kernel, soft_ce_bwd_kernel and potes_tail_bwd_kernel are four
+// launches of 4.6-7.2 us for a few KB of data; everything they compute is local to a batch row
+// except five batch reductions (the loss, dW2, db2, db1).  potes_tail_loss_kernel does the row-local
+// part for 4 rows per block — z, logits, the row's soft-target cross entropy, dlogits, dz (for
+// d loss = 1) — and writes its rows' contributions to the reductions; potes_tail_loss_finalize_kernel
+// adds the per-block contributions in a fixed order.  Two launches instead of four.
+constexpr int kTlStride = 192;   // floats per row block: dW2[c*20+o] at 0..159, db2 at 160..167,
+                                 // db1 at 168..187, loss at 188
+
+__global__ __launch_bounds__(kTailRows* kHeadO * 4) void potes_tail_loss_kernel(
+    const float* __restrict__ partial, int KS, const float* __restrict__ b1,
+    const uint8_t* __restrict__ mask2, float scale2, int thr2, const float* __restrict__ w2,
+    const float* __restrict__ b2, const float* __restrict__ target, float* __restrict__ z,
+    float* __restrict__ logits, float* __restrict__ dz, float* __restrict__ ws,
+    float* __restrict__ zero, long long n_zero, int B, int C, int nrb) {
+  if ((int)blockIdx.x >= nrb) {    // the other blocks clear the buffer head_bwd accumulates dW1 into
+    const int nz = (int)gridDim.x - nrb;
+    const long long per = (n_zero + nz - 1) / nz;
+    const long long lo = (long long)((int)blockIdx.x - nrb) * per;
+    const long long hi = lo + per < n_zero ? lo + per : n_zero;
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) zero[i] = 0.f;
+    return;
+  }
+  __shared__ float h[kTailRows][kHeadO], fac[kTailRows][kHeadO], dzl[kTailRows][kHeadO];
+  __shared__ float lg[kTailRows][kHeadMaxC], dl[kTailRows][kHeadMaxC], rl[kTailRows];
+  const int t = threadIdx.x, q = t & 3, e = t >> 2;            // e = r * kHeadO + o
+  const int r = e / kHeadO, o = e - r * kHeadO;
+  const int row = blockIdx.x * kTailRows + r;
+  const size_t i = (size_t)(row < B ? row : 0) * kHeadO + o;
+  const size_t plane = (size_t)B * kHeadO;
+  float v = 0.f;
+  int ks = q;
+  for (; ks + 12 < KS; ks += 16) {                  // four independent loads in flight
+    const float t0 = partial[(size_t)ks * plane + i], t1 = partial[(size_t)(ks + 4) * plane + i],
+                t2 = partial[(size_t)(ks + 8) * plane + i], t3 = partial[(size_t)(ks + 12) * plane + i];
+    v += t0; v += t1; v += t2; v += t3;
+  }
+  for (; ks < KS; ks += 4) v += partial[(size_t)ks * plane + i];
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  if (q == 0) {
+    float hv = 0.f, f = 0.f;
+    if (row < B) {
+      v += b1 ? b1[o] : 0.f;
+      z[i] = v;
+      f = v > 0.f ? 1.f : 0.f;
+      if (mask2) f = (int)mask2[i] >= thr2 ? f * scale2 : 0.f;
+      hv = v * f;
+    }
+    h[r][o] = hv;
+    fac[r][o] = f;
+  }
+  __syncthreads();
+  if (t < kTailRows * C) {
+    const int rr = t / C, c = t - rr * C;
+    const int row2 = blockIdx.x * kTailRows + rr;
+    float a = 0.f;
+    if (row2 < B) {
+      a = b2 ? b2[c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < kHeadO; ++k) a = fmaf(h[rr][k], w2[c * kHeadO + k], a);
+      logits[(size_t)row2 * C + c] = a;
+    }
+    lg[rr][c] = a;
+  }
+  __syncthreads();
+  if (t < kTailRows) {             // the row's soft-target CE (train_model.py:45-54) and dlogits
+    const int row2 = blockIdx.x * kTailRows + t;
+    float loss_r = 0.f;
+    if (row2 < B) {
+      const float* tg = target + (size_t)row2 * C;
+      float m = lg[t][0];
+      for (int c = 1; c < C; ++c) m = fmaxf(m, lg[t][c]);
+      float se = 0.f, ts = 0.f;
+      for (int c = 0; c < C; ++c) {
+        se += expf(lg[t][c] - m);
+        ts += tg[c];
+      }
+      const float lse = logf(se), inv_b = 1.f / (float)B;
+      for (int c = 0; c < C; ++c) {
+        loss_r -= (lg[t][c] - m - lse) * tg[c];
+        dl[t][c] = inv_b * (expf(lg[t][c] - m - lse) * ts - tg[c]);
+      }
+    } else {
+      for (int c = 0; c < C; ++c) dl[t][c] = 0.f;
+    }
+    rl[t] = loss_r;
+  }
+  __syncthreads();
+  if (q == 0) {                    // dz = (z > 0) * m2 * (dlogits W2), for d loss = 1
+    float sacc = 0.f;
+    for (int c = 0; c < C; ++c) sacc = fmaf(dl[r][c], w2[c * kHeadO + o], sacc);
+    const float d = sacc * fac[r][o];
+    dzl[r][o] = d;
+    if (row < B) dz[i] = d;
+  }
+  __syncthreads();
+  float* out = ws + (size_t)blockIdx.x * kTlStride;
+  if (t < kHeadMaxC * kHeadO) {    // dW2[c][o] contribution of these rows
+    const int c = t / kHeadO, oo = t - c * kHeadO;
+    float a = 0.f;
+    if (c < C)
+      for (int rr = 0; rr < kTailRows; ++rr) a = fmaf(dl[rr][c], h[rr][oo], a);
+    out[t] = a;
+  } else if (t < kHeadMaxC * kHeadO + kHeadMaxC) {
+    const int c = t - kHeadMaxC * kHeadO;
+    float a = 0.f;
+    if (c < C)
+      for (int rr = 0; rr < kTailRows; ++rr) a += dl[rr][c];
+    out[t] = a;
+  } else if (t < kHeadMaxC * kHeadO + kHeadMaxC + kHeadO) {
+    const int oo = t - kHeadMaxC * kHeadO - kHeadMaxC;
+    float a = 0.f;
+    for (int rr = 0; rr < kTailRows; ++rr) a += dzl[rr][oo];
+    out[t] = a;
+  } else if (t == kHeadMaxC * kHeadO + kHeadMaxC + kHeadO) {
+    out[t] = (rl[0] + rl[1]) + (rl[2] + rl[3]);
+  }
+}
+
+__global__ __launch_bounds__(kTlStride) void potes_tail_loss_finalize_kernel(
+    const float* __restrict__ ws, int nrb, float* __restrict__ loss, float* __restrict__ small,
+    int B, int C) {
+  // small = [dW2 (C x 20) | db2 (C) | db1 (20)], for d loss = 1
+  const int t = threadIdx.x;
+  if (t > kHeadMaxC * kHeadO + kHeadMaxC + kHeadO) return;
+  float a = 0.f;
+  for (int g = 0; g < nrb; ++g) a += ws[(size_t)g * kTlStride + t];
+  if (t < kHeadMaxC * kHeadO) {
+    const int c = t / kHeadO, o = t - c * kHeadO;
+    if (c < C) small[c * kHeadO + o] = a;
+  } else if (t < kHeadMaxC * kHeadO + kHeadMaxC) {
+    const int c = t - kHeadMaxC * kHeadO;
+    if (c < C) small[C * kHeadO + c] = a;
+  } else if (t < kHeadMaxC * kHeadO + kHeadMaxC + kHeadO) {
+    small[C * kHeadO + C + (t - kHeadMaxC * kHeadO - kHeadMaxC)] = a;
+  } else {
+    loss[0] = a / (float)B;
+  }
+}
+
 }  // namespace pcgmix
 
 extern "C" int pcgmix_soft_ce_fwd_f32(const float* logits, const float* target, float* loss, int B,
@@ -365,16 +514,70 @@ extern "C" int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, c
   if (!dw1) {                      // frozen weights: dx only
     if (mask1)
       hipLaunchKernelGGL((potes_head_bwd_kernel<true, false>), grid, block, 0, s, dz, x, mask1, scale1,
-                         thr1, bits1, w1, dw1, dx, B, K);
+                         thr1, bits1, w1, dw1, dx, B, K, nullptr, nullptr, nullptr, 0);
     else
       hipLaunchKernelGGL((potes_head_bwd_kernel<false, false>), grid, block, 0, s, dz, x, mask1, 1.0f,
-                         0, 8, w1, dw1, dx, B, K);
+                         0, 8, w1, dw1, dx, B, K, nullptr, nullptr, nullptr, 0);
   } else if (mask1) {
     hipLaunchKernelGGL((potes_head_bwd_kernel<true, true>), grid, block, 0, s, dz, x, mask1, scale1,
-                       thr1, bits1, w1, dw1, dx, B, K);
+                       thr1, bits1, w1, dw1, dx, B, K, nullptr, nullptr, nullptr, 0);
   } else {
     hipLaunchKernelGGL((potes_head_bwd_kernel<false, true>), grid, block, 0, s, dz, x, mask1, 1.0f, 0,
-                       8, w1, dw1, dx, B, K);
+                       8, w1, dw1, dx, B, K, nullptr, nullptr, nullptr, 0);
   }
+  return (int)hipGetLastError();
+}
+
+extern "C" long long pcgmix_potes_head_loss_workspace_floats(int B) {
+  return B <= 0 ? 0 : (long long)((B + pcgmix::kTailRows - 1) / pcgmix::kTailRows) * pcgmix::kTlStride;
+}
+
+extern "C" int pcgmix_potes_head_loss_fwd_f32(const float* x, const uint8_t* mask1, float scale1,
+                                              int thr1, int bits1, const float* w1, const float* b1,
+                                              const uint8_t* mask2, float scale2, int thr2,
+                                              const float* w2, const float* b2, const float* target,
+                                              float* partial, float* z, float* logits, float* dz,
+                                              float* loss, float* small, float* ws, float* dw1_zero,
+                                              int B, int K, int C, pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!w2 || !target || !z || !logits || !dz || !loss || !small || !ws || C <= 0 || C > kHeadMaxC ||
+      (reinterpret_cast<uintptr_t>(dz) & 15))
+    return hipErrorInvalidValue;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const hipError_t e =
+      launch_skinny_partial(x, w1, partial, B, K, kHeadO, s, mask1, scale1, thr1, bits1);
+  if (e != hipSuccess) return (int)e;
+  const int KS = pcgmix_skinny_linear_splits(B, K);
+  const int nrb = (B + kTailRows - 1) / kTailRows;
+  const long long n_zero = dw1_zero ? (long long)kHeadO * K : 0;
+  const unsigned zero_blocks = (unsigned)((n_zero + 4095) / 4096);
+  hipLaunchKernelGGL(potes_tail_loss_kernel, dim3((unsigned)nrb + zero_blocks),
+                     dim3(kTailRows * kHeadO * 4), 0, s, partial, KS, b1, mask2, scale2, thr2, w2, b2,
+                     target, z, logits, dz, ws, dw1_zero, n_zero, B, C, nrb);
+  hipLaunchKernelGGL(potes_tail_loss_finalize_kernel, dim3(1), dim3(kTlStride), 0, s, ws, nrb, loss,
+                     small, B, C);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pcgmix_potes_head_loss_bwd_f32(const float* dz, const float* gscale, const float* x,
+                                              const uint8_t* mask1, float scale1, int thr1, int bits1,
+                                              const float* w1, const float* small_in,
+                                              float* small_out, float* dw1, float* dx, int B, int K,
+                                              int C, pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!dz || !x || !w1 || (!dw1 && !dx) || B <= 0 || K <= 0 || (K & 3) || C <= 0 || C > kHeadMaxC ||
+      (reinterpret_cast<uintptr_t>(dz) & 15) ||
+      (mask1 && bits1 != 1 && bits1 != 2 && bits1 != 4 && bits1 != 8) || (small_out && !small_in))
+    return hipErrorInvalidValue;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int n_small = C * kHeadO + C + kHeadO;
+  const dim3 grid((unsigned)((K + kHbCols - 1) / kHbCols), kHbSplit), block(kHbWaves * 64);
+#define PCGMIX_HB(M, D)                                                                          \
+  hipLaunchKernelGGL((potes_head_bwd_kernel<M, D>), grid, block, 0, s, dz, x, mask1,              \
+                     mask1 ? scale1 : 1.0f, mask1 ? thr1 : 0, mask1 ? bits1 : 8, w1, dw1, dx, B, K, \
+                     gscale, small_in, small_out, n_small)
+  if (!dw1) { if (mask1) PCGMIX_HB(true, false); else PCGMIX_HB(false, false); }
+  else { if (mask1) PCGMIX_HB(true, true); else PCGMIX_HB(false, true); }
+#undef PCGMIX_HB
   return (int)hipGetLastError();
 }

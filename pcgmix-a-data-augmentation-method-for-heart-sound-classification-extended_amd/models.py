@@ -240,6 +240,86 @@ class PotesHeadFunction(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2, None, None, None, None
 
 
+class PotesHeadLossFunction(torch.autograd.Function):
+    """``PotesHeadFunction`` followed by the soft-target cross entropy (CELoss, train_model.py:45-54)
+    as ONE autograd node: ``pcgmix_potes_head_loss_{fwd,bwd}_f32``.  Returns (loss, logits); the
+    logits are an auxiliary, non-differentiable output (accuracy counters).  Between the split-K
+    product and the pass over the features the separate nodes launch four ~5 us kernels for a few
+    KB of data; here two.  Whatever gradient arrives at the loss multiplies the stored ones inside
+    the backward kernel (no extra launch)."""
+
+    @staticmethod
+    def forward(ctx, feat, w1, b1, w2, b2, target, p1, p2, training, rnd=None):
+        B, K = feat.shape
+        C = w2.shape[0]
+        dev = feat.device
+        lib = _lib.load()
+        x = feat.contiguous()
+        tgt = target.to(torch.float32).contiguous()
+        mask1 = mask2 = None
+        thr1 = thr2 = 0
+        bits1 = 8
+        s1 = s2 = 1.0
+        if training and (p1 > 0.0 or p2 > 0.0):
+            n = head_dropout_bytes(B, K, p1)
+            if rnd is None:
+                rnd = torch.empty(n, dtype=torch.uint8, device=dev).random_()
+            elif rnd.numel() < n or rnd.dtype != torch.uint8 or not rnd.is_contiguous():
+                raise ValueError("rnd must be a contiguous uint8 tensor of head_dropout_bytes(B, K, p1)")
+            if p1 > 0.0:
+                bits1, thr1, s1 = dropout_threshold(p1)
+                mask1 = rnd[:B * K * bits1 // 8]
+            if p2 > 0.0:
+                _b, thr2, s2 = dropout_threshold(p2, max_bits=8)
+                thr2 = (256 * thr2) >> _b
+                mask2 = rnd[n - B * 20:n]
+        w1c, w2c = w1.detach().contiguous(), w2.detach().contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        partial = torch.empty((lib.pcgmix_skinny_linear_splits(B, K), B, 20), **f32)
+        z, logits = torch.empty((B, 20), **f32), torch.empty((B, C), **f32)
+        dz, loss = torch.empty((B, 20), **f32), torch.empty((), **f32)
+        small = torch.empty(C * 20 + C + 20, **f32)
+        ws = torch.empty(lib.pcgmix_potes_head_loss_workspace_floats(B), **f32)
+        need_dw1 = ctx.needs_input_grad[1] or not ctx.needs_input_grad[0]
+        dw1 = torch.empty_like(w1c) if need_dw1 else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        opt = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        _lib.check(lib.pcgmix_potes_head_loss_fwd_f32(
+            x.data_ptr(), opt(mask1), ctypes.c_float(s1), thr1, bits1, w1c.data_ptr(),
+            b1.detach().data_ptr() if b1 is not None else None, opt(mask2), ctypes.c_float(s2), thr2,
+            w2c.data_ptr(), b2.detach().data_ptr() if b2 is not None else None, tgt.data_ptr(),
+            partial.data_ptr(), z.data_ptr(), logits.data_ptr(), dz.data_ptr(), loss.data_ptr(),
+            small.data_ptr(), ws.data_ptr(), opt(dw1), B, K, C, stream),
+            "pcgmix_potes_head_loss_fwd_f32")
+        ctx.save_for_backward(x, w1c, dz, small, mask1, dw1)
+        ctx.drop = (thr1, bits1, s1)
+        ctx.C = C
+        ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, gloss, _glogits):
+        x, w1, dz, small, mask1, dw1 = ctx.saved_tensors
+        thr1, bits1, s1 = ctx.drop
+        B, K = x.shape
+        C = ctx.C
+        lib = _lib.load()
+        g = gloss.to(torch.float32).contiguous()
+        small_out = torch.empty_like(small)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        opt = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        _lib.check(lib.pcgmix_potes_head_loss_bwd_f32(
+            dz.data_ptr(), g.data_ptr(), x.data_ptr(), opt(mask1), ctypes.c_float(s1), thr1, bits1,
+            w1.data_ptr(), small.data_ptr(), small_out.data_ptr(), opt(dw1), opt(dx), B, K, C, stream),
+            "pcgmix_potes_head_loss_bwd_f32")
+        dw2 = small_out[:C * 20].view(C, 20)
+        db2 = small_out[C * 20:C * 20 + C] if ctx.has_b2 else None
+        db1 = small_out[C * 20 + C:] if ctx.has_b1 else None
+        return dx, dw1, db1, dw2, db2, None, None, None, None, None
+
+
 def _potes_block(c_in: int, c_out: int, dropout: float = 0.0) -> nn.Sequential:
     # Conv1d(k=5, padding=1) + ReLU + MaxPool(2) [+ Dropout]   (reference models.py:359-365)
     layers = [nn.Conv1d(c_in, c_out, kernel_size=5, padding=1), nn.ReLU(inplace=True),
@@ -316,6 +396,22 @@ class CNN_potes(nn.Module):
                                        self.linear.weight, self.linear.bias,
                                        float(drop.p) if drop is not None else 0.0,
                                        float(self.dropout.p), self.training, rnd)
+
+    def loss_and_logits(self, x: torch.Tensor, target: torch.Tensor):
+        """(soft-target cross entropy, logits) of the whole network in one chain of HIP kernels
+        — the conv stack, then head and loss as ONE autograd node (``PotesHeadLossFunction``).
+        Needs ``_fused_head(x)``; ``target`` is the (B, classes) one-hot / soft target matrix."""
+        B, C, T = x.shape
+        c1, c2 = self.cnn1[0][0], self.cnn1[1][0]
+        rows = x[:, :4, :].reshape(B * 4, T)
+        z = PotesStackFunction.apply(rows.contiguous(), c1.weight, c1.bias, c2.weight, c2.bias)
+        drop = self.cnn1[1][3] if len(self.cnn1[1]) > 3 else None
+        rnd = self.dropout_bytes if (self.dropout_bytes is not None and self.training
+                                     and torch.cuda.is_current_stream_capturing()) else None
+        return PotesHeadLossFunction.apply(z.reshape(B, -1), self.dimreduc.weight, self.dimreduc.bias,
+                                           self.linear.weight, self.linear.bias, target,
+                                           float(drop.p) if drop is not None else 0.0,
+                                           float(self.dropout.p), self.training, rnd)
 
     def features(self, x: torch.Tensor) -> torch.Tensor:
         B, C, T = x.shape

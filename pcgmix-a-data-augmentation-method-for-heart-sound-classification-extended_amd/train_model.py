@@ -307,6 +307,22 @@ def reseed_device_rng(args, device) -> None:
         torch.cuda.manual_seed(int(seed))
 
 
+def fused_loss_model(model, criterion, data, target_ohe, epoch):
+    """The CNN_potes whose head and loss can run as one autograd node for this step, or None:
+    an unwrapped CNN_potes on the HIP path, a criterion in its plain-CE phase (CELoss, or SELCLoss
+    up to its turning point, train_model.py:66-72), targets that need no gradient."""
+    if not isinstance(model, models.CNN_potes) or target_ohe.requires_grad:
+        return None
+    if isinstance(criterion, SELCLoss):
+        if epoch is None or epoch > criterion.es:
+            return None
+    elif not isinstance(criterion, CELoss):
+        return None
+    if not (data.dim() == 3 and model._fused_head(data) and data.shape[0] > 0):
+        return None
+    return model
+
+
 def train_step(args, model, batch, device, optimizer, scheduler, criterion, epoch, step_counter,
                stats: Optional[dict] = None, sync: Optional["FlatGradSync"] = None):
     """One iteration of the reference's batch loop (train_model.py:498-582) without host syncs.
@@ -319,9 +335,14 @@ def train_step(args, model, batch, device, optimizer, scheduler, criterion, epoc
     data, target_ohe, _, _ = aug.augment(args, data, target_ohe, frames, wav, step_counter,
                                          model, device, None,
                                          host_labels=target.numpy() if not target.is_cuda else None)
-    out = model(data, depth=getattr(args, "depth", 0), pass_part="second")
+    fused = fused_loss_model(model, criterion, data, target_ohe, epoch) \
+        if getattr(args, "depth", 0) == 0 else None
+    if fused is not None:                   # head + loss as one autograd node (two launches, not four)
+        loss, out = fused.loss_and_logits(data, target_ohe)
+    else:
+        out = model(data, depth=getattr(args, "depth", 0), pass_part="second")
+        loss = criterion(out, target_ohe, indices, epoch, "train")
     args.depth = 0
-    loss = criterion(out, target_ohe, indices, epoch, "train")
     if sync is None:
         loss.backward()
     else:                                   # flat-buffer averaging instead of DDP hooks
@@ -417,8 +438,13 @@ class GraphedTrainStep:
             self.loss, self.out = self._fwd_bwd()
 
     def _fwd_bwd(self):
-        out = self.model(self.x, depth=0, pass_part="second")
-        loss = self.ce(out, self.t)
+        fused = fused_loss_model(self.model, self.ce, self.x, self.t, None) \
+            if isinstance(self.ce, CELoss) else None
+        if fused is not None:
+            loss, out = fused.loss_and_logits(self.x, self.t)
+        else:
+            out = self.model(self.x, depth=0, pass_part="second")
+            loss = self.ce(out, self.t)
         loss.backward(self.bwd_seed)
         if self.sync is not None and self.sync.params is not None:
             self.sync.pack()

@@ -215,3 +215,39 @@ def test_random_bit_dropout_is_torch_dropout_with_the_same_mask(p1, p2, device):
     assert torch.allclose(lo, ref, rtol=1e-4, atol=1e-5)
     for a, b in zip(g, gt):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 + 1e-4 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("training,soft", [(True, False), (True, True), (False, False)])
+def test_fused_head_loss_equals_head_then_celoss(training, soft, device):
+    """PotesHeadLossFunction (head + soft-target CE as one autograd node, two launches between the
+    split-K product and the feature pass) == PotesHeadFunction followed by CELoss: loss, logits and
+    every gradient, with dropout on (same generator state -> same random bytes) and with a loss
+    gradient other than 1."""
+    from pcgmix_amd import models
+    torch.manual_seed(5)
+    m = models.CNN_potes_TS(4, 2, "PhysioNet").to(device).train(training)
+    x = torch.randn(24, 4, 2500, device=device)
+    t = F.one_hot(torch.randint(0, 2, (24,), device=device), 2).float()
+    if soft:
+        t = 0.7 * t + 0.3 * t.flip(0)
+    gscale = torch.tensor(0.37, device=device)
+    res = []
+    for fused in (True, False):
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        torch.manual_seed(77)
+        if fused:
+            loss, logits = m.loss_and_logits(xi, t)
+        else:
+            logits = m(xi, depth=0, pass_part="second")
+            loss = tm.CELoss(2)(logits, t)
+        loss.backward(gscale)
+        res.append((loss.detach(), logits.detach(), xi.grad.clone(),
+                    {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert torch.allclose(res[0][0], res[1][0], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(res[0][2], res[1][2], rtol=1e-4, atol=1e-7 + 1e-4 * float(res[1][2].abs().max()))
+    assert res[0][3].keys() == res[1][3].keys()
+    for k in res[0][3]:
+        a, b = res[0][3][k], res[1][3][k]
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-7 + 1e-4 * float(b.abs().max())), k
