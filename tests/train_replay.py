@@ -48,15 +48,17 @@ def trajectory(device, mode):
     extras = {}
     if mode == "epoch":
         losses = []
-        inner = crit.CEloss
+        orig = tm.train_step
 
-        class Rec(torch.nn.Module):
-            def forward(self, lo, t):
-                v = inner(lo, t)
-                losses.append(v.detach())
-                return v
-        crit.CEloss = Rec()
-        mean_loss, acc, lrs = tm.train_epoch(args, net, batches, device, opt, sched, crit, 1, sc)
+        def recording_step(*a, **k):            # train_epoch returns the mean only
+            v = orig(*a, **k)
+            losses.append(v)
+            return v
+        tm.train_step = recording_step
+        try:
+            mean_loss, acc, lrs = tm.train_epoch(args, net, batches, device, opt, sched, crit, 1, sc)
+        finally:
+            tm.train_step = orig
         extras = {"mean_loss": mean_loss, "acc": acc}
         losses = [float(v) for v in losses]
     else:
