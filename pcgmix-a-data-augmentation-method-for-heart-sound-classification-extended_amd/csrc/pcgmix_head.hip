@@ -434,14 +434,33 @@ __global__ __launch_bounds__(kTailRows* kHeadO * 4) void potes_tail_loss_kernel(
   }
 }
 
-__global__ __launch_bounds__(kTlStride) void potes_tail_loss_finalize_kernel(
+// Column t of the per-block contributions, summed in a FIXED order: four threads per column
+// take a quarter of the row blocks each (their loads all in flight together), then thread 0 of
+// the column adds the four partial sums in order.  (One thread walking all 64 row blocks took
+// 16 us: 64 dependent-latency loads.)
+constexpr int kTlSeg = 4;
+__global__ __launch_bounds__(kTlStride* kTlSeg) void potes_tail_loss_finalize_kernel(
     const float* __restrict__ ws, int nrb, float* __restrict__ loss, float* __restrict__ small,
     int B, int C) {
   // small = [dW2 (C x 20) | db2 (C) | db1 (20)], for d loss = 1
-  const int t = threadIdx.x;
-  if (t > kHeadMaxC * kHeadO + kHeadMaxC + kHeadO) return;
+  __shared__ float seg[kTlSeg][kTlStride];
+  const int t = threadIdx.x % kTlStride, sg = threadIdx.x / kTlStride;
+  const int per = (nrb + kTlSeg - 1) / kTlSeg;
+  const int g0 = sg * per, g1 = g0 + per < nrb ? g0 + per : nrb;
   float a = 0.f;
-  for (int g = 0; g < nrb; ++g) a += ws[(size_t)g * kTlStride + t];
+  int g = g0;
+  for (; g + 8 <= g1; g += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ws[(size_t)(g + j) * kTlStride + t];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a += v[j];
+  }
+  for (; g < g1; ++g) a += ws[(size_t)g * kTlStride + t];
+  seg[sg][t] = a;
+  __syncthreads();
+  if (sg != 0 || t > kHeadMaxC * kHeadO + kHeadMaxC + kHeadO) return;
+  a = ((seg[0][t] + seg[1][t]) + seg[2][t]) + seg[3][t];
   if (t < kHeadMaxC * kHeadO) {
     const int c = t / kHeadO, o = t - c * kHeadO;
     if (c < C) small[c * kHeadO + o] = a;
@@ -554,8 +573,8 @@ extern "C" int pcgmix_potes_head_loss_fwd_f32(const float* x, const uint8_t* mas
   hipLaunchKernelGGL(potes_tail_loss_kernel, dim3((unsigned)nrb + zero_blocks),
                      dim3(kTailRows * kHeadO * 4), 0, s, partial, KS, b1, mask2, scale2, thr2, w2, b2,
                      target, z, logits, dz, ws, dw1_zero, n_zero, B, C, nrb);
-  hipLaunchKernelGGL(potes_tail_loss_finalize_kernel, dim3(1), dim3(kTlStride), 0, s, ws, nrb, loss,
-                     small, B, C);
+  hipLaunchKernelGGL(potes_tail_loss_finalize_kernel, dim3(1), dim3(kTlStride * kTlSeg), 0, s, ws, nrb,
+                     loss, small, B, C);
   return (int)hipGetLastError();
 }
 

@@ -296,11 +296,14 @@ class PotesHeadLossFunction(torch.autograd.Function):
         ctx.C = C
         ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
         ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)        # no zeros for the logits' gradient slot (a fill launch)
         return loss, logits
 
     @staticmethod
     def backward(ctx, gloss, _glogits):
         x, w1, dz, small, mask1, dw1 = ctx.saved_tensors
+        if gloss is None:                       # nothing upstream of the loss
+            return (None,) * 10
         thr1, bits1, s1 = ctx.drop
         B, K = x.shape
         C = ctx.C
