@@ -487,6 +487,11 @@ int pcgmix_augment_plain_f32(pcgmix_ctx* ctx, const float* x, float* y,
                              float lam, const double* knots, int n_knots, int64_t* mix_out,
                              int B, int C, int T, pcgmix_stream_t stream);
 
+/* Diagnostic: mean host nanoseconds per pcgmix_augment_plain_f32 call since the last query, by
+ * phase: label kernel launch | slot reserve | pack + seed | label wait | grouping + permutation |
+ * H2D enqueue | kernel launch | event record.  Returns the number of calls averaged; resets. */
+long long pcgmix_ctx_phase_times(pcgmix_ctx* ctx, double* out8);
+
 /* Which instantiation of the splice kernel pcgmix_mix_warp_f32 launches for this problem:
  * vec = 4 (16-byte lanes; needs T % 4 == 0 and 16-byte aligned x, y) or 1, unroll = quads per
  * lane (1, 2, 4).  For reporting: the kernel's name is mix_warp_kernel<vec, warp, unroll>. */

@@ -84,6 +84,7 @@ SIGNATURES = {
     "pcgmix_ctx_create": (_c_int, [_c_int, ctypes.POINTER(_ptr)]),
     "pcgmix_ctx_destroy": (None, [_ptr]),
     "pcgmix_ctx_gate": (ctypes.c_double, [_ptr, ctypes.c_uint64]),
+    "pcgmix_ctx_phase_times": (ctypes.c_longlong, [_ptr, _ptr]),
     "pcgmix_ctx_labels_begin": (_c_int, [_ptr, _ptr, _c_int, _c_int, _ptr]),
     "pcgmix_ctx_labels_wait": (_c_int, [_ptr, _ptr, _c_int, _ptr]),
     "pcgmix_augment_plain_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _ptr, ctypes.c_uint64,

@@ -144,7 +144,15 @@ struct PyRandom {
   }
 
   void init_by_array(const uint32_t* key, int len) {
-    init_genrand(19650218u);
+    // init_genrand(19650218) is the same 624 words every time: computed once, copied after that
+    // (a third of the 1871 dependent steps of a seeding)
+    static const PyRandom* base = [] {
+      PyRandom* b = static_cast<PyRandom*>(::operator new(sizeof(PyRandom)));
+      b->init_genrand(19650218u);
+      return b;
+    }();
+    std::memcpy(mt, base->mt, sizeof(mt));
+    idx = 624;
     int i = 1, j = 0;
     for (int k = (624 > len ? 624 : len); k; --k) {
       mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
@@ -386,6 +394,7 @@ extern "C" long long pcgmix_splice_staging_bytes(int B, int C, int n_knots) {
 namespace {
 
 constexpr int kSlots = 8;
+constexpr int kSlotGroup = 4;     // slots per completion event
 
 struct Slot {
   char* pinned = nullptr;
@@ -420,6 +429,8 @@ __global__ __launch_bounds__(256) void label_argmax_kernel(const int64_t* __rest
 }  // namespace
 
 struct pcgmix_ctx {
+  double phase_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // accumulated host time per phase (diagnostic)
+  long long calls = 0;
   int device = 0;
   Slot slot[kSlots];
   int next = 0;
@@ -430,6 +441,8 @@ struct pcgmix_ctx {
   std::map<std::pair<int, int>, double*> ops;   // (T, n_knots) -> device operator
   uint64_t gate_step = ~0ull;      // generator seeded for this step (pcgmix_ctx_gate), reusable
   PyRandom* seeded = nullptr;
+  std::vector<int64_t> keys, pool, idx;   // per-step scratch of the partner draw
+  std::vector<int> gid;
 };
 
 extern "C" int pcgmix_ctx_create(int device, pcgmix_ctx** out) {
@@ -484,11 +497,15 @@ extern "C" double pcgmix_ctx_gate(pcgmix_ctx* c, uint64_t step) {
 
 namespace {
 
-hipError_t slot_reserve(Slot& s, size_t nbytes) {
-  if (s.busy) {                               // the kernel that read this slot must be done
-    hipError_t e = hipEventSynchronize(s.ev);
-    if (e != hipSuccess) return e;
-    s.busy = false;
+hipError_t slot_reserve(pcgmix_ctx* c, int i, size_t nbytes) {
+  Slot& s = c->slot[i];
+  if (i % kSlotGroup == 0) {                  // entering a group: its previous round must be done
+    Slot& g = c->slot[i + kSlotGroup - 1];
+    if (g.busy) {
+      hipError_t e = hipEventSynchronize(g.ev);
+      if (e != hipSuccess) return e;
+      g.busy = false;
+    }
   }
   if (s.cap >= nbytes) return hipSuccess;
   size_t cap = 8192;
@@ -605,6 +622,12 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
       (knots && n_knots < 2))
     return hipErrorInvalidValue;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  auto tp = std::chrono::steady_clock::now();
+  auto lap = [&](int i) {
+    const auto now = std::chrono::steady_clock::now();
+    c->phase_ns[i] += std::chrono::duration<double, std::nano>(now - tp).count();
+    tp = now;
+  };
   int cur = 0;
   hipError_t e = hipGetDevice(&cur);
   if (e != hipSuccess) return (int)e;
@@ -619,14 +642,16 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   const bool readback = labels_host == nullptr;
   if (readback && (e = labels_begin(c, target_ohe_dev, num_classes, B, s)) != hipSuccess)
     return (int)e;
+  lap(0);
 
   // 2. staging slot, boundaries validated and packed, knots copied, generator seeded
   const size_t n_int = (size_t)B * 6, n_int_pad = (n_int + 1) & ~(size_t)1;
   const size_t nk = knots ? (size_t)B * n_knots * C : 0;
   const size_t nbytes = n_int_pad * 4 + nk * sizeof(double);
-  Slot& sl = c->slot[c->next];
-  c->next = (c->next + 1) % kSlots;
-  if ((e = slot_reserve(sl, nbytes)) != hipSuccess) return (int)e;
+  const int my_slot = c->next;           // advanced only when the step has been enqueued
+  Slot& sl = c->slot[my_slot];
+  if ((e = slot_reserve(c, my_slot, nbytes)) != hipSuccess) return (int)e;
+  lap(1);
   int32_t* st = reinterpret_cast<int32_t*>(sl.pinned);
   int bad = 0;
   for (int b = 0; b < B; ++b) {
@@ -649,6 +674,7 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     c->gate_step = step;
   }
 
+  lap(2);
   // 3. wait for the labels (the one host wait the reference's signature forces,
   //    augmentations.py:501): spin on the flag word the kernel releases; if it does not show up
   //    within 2 ms fall back to a stream synchronisation
@@ -660,43 +686,69 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     for (int b = 0; b < B; ++b) lab64[(size_t)b] = c->lab[b];
     labels = lab64.data();
   }
+  lap(3);
   if (bad) return bad;                       // malformed boundaries: nothing else is enqueued
 
   // 4. groups of equal label in order of first appearance (augmentations.py:500-510), each
-  //    permuted by a fresh Random(step).sample: one initialisation, state copied per group
-  std::vector<int64_t> keys;
-  std::vector<std::vector<int64_t>> members;
+  //    permuted by a fresh Random(step).sample: one initialisation, state copied per group.
+  //    Scratch lives in the context (no allocation per step): gid[b] = group of sample b,
+  //    members of group g = the samples b with gid[b] == g in ascending order.
+  c->keys.clear();
+  c->gid.resize((size_t)B);
+  c->pool.resize((size_t)B);
+  c->idx.resize((size_t)B);
   for (int b = 0; b < B; ++b) {
     size_t g = 0;
-    while (g < keys.size() && keys[g] != labels[b]) ++g;
-    if (g == keys.size()) {
-      keys.push_back(labels[b]);
-      members.emplace_back();
-    }
-    members[g].push_back(b);
+    while (g < c->keys.size() && c->keys[g] != labels[b]) ++g;
+    if (g == c->keys.size()) c->keys.push_back(labels[b]);
+    c->gid[(size_t)b] = (int)g;
   }
-  std::vector<int64_t> pool;
   int32_t* mixp = st + (size_t)B * 5;
-  for (const auto& idx : members) {
-    const size_t n = idx.size();
+  for (size_t g = 0; g < c->keys.size(); ++g) {
+    size_t n = 0;
+    for (int b = 0; b < B; ++b)
+      if (c->gid[(size_t)b] == (int)g) c->idx[n++] = b;
     PyRandom rng = *c->seeded;
-    pool = idx;
+    std::memcpy(c->pool.data(), c->idx.data(), n * sizeof(int64_t));
     for (size_t i = 0; i < n; ++i) {                 // sample(population, k = n): pool branch
       const uint64_t j = rng.randbelow((uint64_t)(n - i));
-      mix_out[idx[i]] = pool[j];
-      mixp[idx[i]] = (int32_t)pool[j];
-      pool[j] = pool[n - i - 1];
+      mix_out[c->idx[i]] = c->pool[j];
+      mixp[c->idx[i]] = (int32_t)c->pool[j];
+      c->pool[j] = c->pool[n - i - 1];
     }
   }
-
+  lap(4);
   // 5. one H2D copy, the launch, the slot's event behind it
   if ((e = hipMemcpyAsync(sl.dev, sl.pinned, nbytes, hipMemcpyHostToDevice, s)) != hipSuccess)
     return (int)e;
+  lap(5);
   const int32_t* d = reinterpret_cast<const int32_t*>(sl.dev);
   const int err = pcgmix_mix_warp_f32(x, y, d, d + (size_t)B * 5, nullptr, lam, knots_dev, op_dev,
                                       knots ? n_knots : 0, nullptr, B, C, T, stream);
   if (err) return err;
-  if ((e = hipEventRecord(sl.ev, s)) != hipSuccess) return (int)e;
-  sl.busy = true;
+  lap(6);
+  // An event per GROUP of kSlotGroup slots: recorded behind the group's last launch, waited for
+  // before the group's first reuse (one stream-order point covers all four: fewer API calls).
+  if (my_slot % kSlotGroup == kSlotGroup - 1) {
+    if ((e = hipEventRecord(sl.ev, s)) != hipSuccess) return (int)e;
+    sl.busy = true;
+  }
+  c->next = (my_slot + 1) % kSlots;
+  lap(7);
+  ++c->calls;
   return hipSuccess;
+}
+
+// Diagnostic: mean host nanoseconds per call spent in the 8 phases of pcgmix_augment_plain_f32
+// since the last query (label kernel launch | slot reserve | pack + seed | label wait | grouping +
+// permutation | H2D enqueue | kernel launch | event record); resets the accumulators.
+extern "C" long long pcgmix_ctx_phase_times(pcgmix_ctx* c, double* out8) {
+  if (!c || !out8) return 0;
+  const long long n = c->calls;
+  for (int i = 0; i < 8; ++i) {
+    out8[i] = n ? c->phase_ns[i] / (double)n : 0.0;
+    c->phase_ns[i] = 0.0;
+  }
+  c->calls = 0;
+  return n;
 }
