@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 9
+#define PCGMIX_ABI_VERSION 10
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -288,11 +288,20 @@ int pcgmix_potes_stack_bwd_f32(const float* x, const float* grad_h2, const float
  *                                          no forward recompute at all
  * Gradients flow exactly where the forward's maxima were (the recomputing kernels re-derive the
  * routing with a different summation order and can differ at exact near-ties).
+ *
+ * rnd_out != NULL: the forward launch also fills rnd_out[0 .. rnd_bytes) (16-byte aligned, a
+ * multiple of 16) with the uniformly random bytes the head's dropouts read (mask1 / mask2 of
+ * pcgmix_potes_head_*): 32-bit word w = a keyed counter hash of w.  The 64-bit key is `key`, or —
+ * key_dev != NULL — the two 32-bit words (low, high) at key_dev in DEVICE memory: for training
+ * steps captured in a hipGraph, nn.Dropout's mask generation (models.py:364, 380) without an RNG
+ * launch per replay — the key changes per step, the graph does not.  rnd_out == NULL: nothing is
+ * filled (rnd_bytes, key_dev, key ignored).
  */
 long long pcgmix_potes_mask_bytes(int N, int T, int layer);
 int pcgmix_potes_stack_fwd_save_f32(const float* x, const float* w1, const float* b1,
                                     const float* w2, const float* b2, float* h2, uint8_t* m2,
-                                    uint8_t* s1, int N, int T, pcgmix_stream_t stream);
+                                    uint8_t* s1, int N, int T, uint8_t* rnd_out, long long rnd_bytes,
+                                    const uint32_t* key_dev, uint64_t key, pcgmix_stream_t stream);
 int pcgmix_potes_stack_bwd_mask_f32(const float* x, const float* grad_h2, const uint8_t* m2,
                                     const float* w1, const float* b1, const float* w2,
                                     const float* b2, float* partial, float* grads, int N, int T,
@@ -333,6 +342,18 @@ int pcgmix_adam_clip_multi_f32(int n_tensors, float* const* p, const float* cons
                                float* const* m, float* const* v, const long long* n, float clip,
                                float lr, float beta1, float beta2, float eps, float weight_decay,
                                long long step, pcgmix_stream_t stream);
+
+/* The multi-tensor update with its eight scalars in DEVICE memory, for a launch captured in a
+ * hipGraph (OneCycleLR moves lr and beta1 every step, the bias corrections move with `step`:
+ * kernel arguments would be frozen at capture).  pcgmix_adam_hyper computes the eight floats on
+ * the host exactly as pcgmix_adam_clip_multi_f32 does internally — {clip, weight_decay, 1-beta1,
+ * beta2, 1-beta2, lr/(1-beta1^step), 1/sqrt(1-beta2^step), eps} — and the caller gets them to
+ * hyper_dev before the replay (e.g. with pcgmix_ctx_set_payload).                              */
+int pcgmix_adam_hyper(float clip, float lr, float beta1, float beta2, float eps, float weight_decay,
+                      long long step, float* out8);
+int pcgmix_adam_clip_multi_dev_f32(int n_tensors, float* const* p, const float* const* g,
+                                   float* const* m, float* const* v, const long long* n,
+                                   const float* hyper_dev, pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Potes classifier head, forward and backward.                                       [device]
@@ -475,6 +496,17 @@ typedef struct pcgmix_ctx pcgmix_ctx;
 int pcgmix_ctx_create(int device, pcgmix_ctx** out);
 void pcgmix_ctx_destroy(pcgmix_ctx* ctx);
 double pcgmix_ctx_gate(pcgmix_ctx* ctx, uint64_t step);
+/* Up to 1 MiB the caller wants on the device together with the NEXT pcgmix_augment_plain_f32 step
+ * of this context (the float targets the loss reads — train_model.py:541-549 moves them with
+ * their own .to(device) —, optimiser scalars, a dropout key): the bytes are copied now, appended
+ * to that step's index block (same pinned slot, same single H2D copy) and written to dst_dev
+ * (DEVICE, 16-byte aligned, >= bytes rounded up to 16) by the splice kernel, i.e. they are in
+ * place for everything enqueued behind the step on its stream.  One shot; bytes == 0 withdraws. */
+int pcgmix_ctx_set_payload(pcgmix_ctx* ctx, const void* host, size_t bytes, void* dst_dev);
+/* Sends a pending payload on its own — the step it was meant for ran no plain splice (probability
+ * gate): one H2D copy from the context's pinned ring straight to dst_dev on `stream`.  No-op
+ * when nothing is pending. */
+int pcgmix_ctx_flush_payload(pcgmix_ctx* ctx, pcgmix_stream_t stream);
 /* The label read-back alone, in two halves, for steps that have GPU work to enqueue in between
  * (the saliency-guided step, augmentations.py:881-907): begin = the arg-max kernel on `stream`;
  * wait = the spin on the flag word, then int64 class labels in labels_out (HOST, B). */

@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -49,7 +49,8 @@ SIGNATURES = {
     "pcgmix_potes_stack_bwd_f32": (_c_int, [_ptr] * 8 + [_c_int, _c_int, _ptr]),
     "pcgmix_potes_stack_input_grad_f32": (_c_int, [_ptr] * 7 + [_c_int, _c_int, _ptr]),
     "pcgmix_potes_mask_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
-    "pcgmix_potes_stack_fwd_save_f32": (_c_int, [_ptr] * 8 + [_c_int, _c_int, _ptr]),
+    "pcgmix_potes_stack_fwd_save_f32": (_c_int, [_ptr] * 8 + [_c_int, _c_int, _ptr, ctypes.c_longlong,
+                                                 _ptr, ctypes.c_uint64, _ptr]),
     "pcgmix_potes_stack_bwd_mask_f32": (_c_int, [_ptr] * 9 + [_c_int, _c_int, _ptr]),
     "pcgmix_potes_stack_input_grad_mask_f32": (_c_int, [_ptr] * 6 + [_c_int, _c_int, _ptr]),
     "pcgmix_skinny_linear_splits": (_c_int, [_c_int, _c_int]),
@@ -60,6 +61,8 @@ SIGNATURES = {
     "pcgmix_adam_clip_multi_f32": (_c_int, [_c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float,
                                             _c_float, _c_float, _c_float, _c_float,
                                             ctypes.c_longlong, _ptr]),
+    "pcgmix_adam_hyper": (_c_int, [_c_float] * 6 + [ctypes.c_longlong, _ptr]),
+    "pcgmix_adam_clip_multi_dev_f32": (_c_int, [_c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
     "pcgmix_potes_head_fwd_f32": (_c_int, [_ptr, _ptr, _c_float, _c_int, _c_int, _ptr, _ptr, _ptr, _c_float,
                                            _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int,
                                            _ptr]),
@@ -84,6 +87,8 @@ SIGNATURES = {
     "pcgmix_ctx_create": (_c_int, [_c_int, ctypes.POINTER(_ptr)]),
     "pcgmix_ctx_destroy": (None, [_ptr]),
     "pcgmix_ctx_gate": (ctypes.c_double, [_ptr, ctypes.c_uint64]),
+    "pcgmix_ctx_set_payload": (_c_int, [_ptr, _ptr, ctypes.c_size_t, _ptr]),
+    "pcgmix_ctx_flush_payload": (_c_int, [_ptr, _ptr]),
     "pcgmix_ctx_phase_times": (ctypes.c_longlong, [_ptr, _ptr]),
     "pcgmix_ctx_labels_begin": (_c_int, [_ptr, _ptr, _c_int, _c_int, _ptr]),
     "pcgmix_ctx_labels_wait": (_c_int, [_ptr, _ptr, _c_int, _ptr]),

@@ -443,6 +443,8 @@ struct pcgmix_ctx {
   PyRandom* seeded = nullptr;
   std::vector<int64_t> keys, pool, idx;   // per-step scratch of the partner draw
   std::vector<int> gid;
+  std::vector<char> payload;       // pcgmix_ctx_set_payload: rides with the next index block
+  void* payload_dst = nullptr;
 };
 
 extern "C" int pcgmix_ctx_create(int device, pcgmix_ctx** out) {
@@ -611,6 +613,51 @@ extern "C" int pcgmix_ctx_labels_wait(pcgmix_ctx* c, int64_t* labels_out, int B,
   return hipSuccess;
 }
 
+// Bytes the caller wants on the device together with the next step (e.g. the float targets the
+// loss reads, optimiser hyper-parameters, a dropout key): they are appended to the step's index
+// block — same pinned slot, same single H2D copy — and block (0,0,0) of the splice kernel writes
+// them to dst_dev, so they are in place for whatever the caller enqueues behind the step.  One
+// shot: consumed by the next successful pcgmix_augment_plain_f32 on this context.  bytes == 0
+// withdraws a pending payload.
+extern "C" int pcgmix_ctx_set_payload(pcgmix_ctx* c, const void* host, size_t bytes, void* dst_dev) {
+  if (!c || (bytes && (!host || !dst_dev)) || bytes > (1u << 20) ||
+      (reinterpret_cast<uintptr_t>(dst_dev) & 15))
+    return hipErrorInvalidValue;
+  c->payload.assign((bytes + 15) & ~(size_t)15, 0);
+  if (bytes) std::memcpy(c->payload.data(), host, bytes);
+  c->payload_dst = bytes ? dst_dev : nullptr;
+  return hipSuccess;
+}
+
+// A pending payload on its own: the step it was meant to ride with did not run a plain splice
+// (probability gate, another method).  Same staging ring, one H2D copy straight to dst_dev.
+extern "C" int pcgmix_ctx_flush_payload(pcgmix_ctx* c, pcgmix_stream_t stream) {
+  if (!c) return hipErrorInvalidValue;
+  if (c->payload.empty()) return hipSuccess;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int cur = 0;
+  hipError_t e = hipGetDevice(&cur);
+  if (e != hipSuccess) return (int)e;
+  if (cur != c->device && (e = hipSetDevice(c->device)) != hipSuccess) return (int)e;
+  const int my_slot = c->next;
+  Slot& sl = c->slot[my_slot];
+  e = slot_reserve(c, my_slot, c->payload.size());
+  if (e == hipSuccess) {
+    std::memcpy(sl.pinned, c->payload.data(), c->payload.size());
+    e = hipMemcpyAsync(c->payload_dst, sl.pinned, c->payload.size(), hipMemcpyHostToDevice, s);
+  }
+  if (e == hipSuccess && my_slot % kSlotGroup == kSlotGroup - 1) {
+    if ((e = hipEventRecord(sl.ev, s)) == hipSuccess) sl.busy = true;
+  }
+  if (e == hipSuccess) {
+    c->next = (my_slot + 1) % kSlots;
+    c->payload.clear();
+    c->payload_dst = nullptr;
+  }
+  if (cur != c->device) (void)hipSetDevice(cur);
+  return (int)e;
+}
+
 extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
                                         const int64_t* target_ohe_dev, int num_classes,
                                         const int64_t* labels_host, const int64_t* frames,
@@ -647,7 +694,8 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   // 2. staging slot, boundaries validated and packed, knots copied, generator seeded
   const size_t n_int = (size_t)B * 6, n_int_pad = (n_int + 1) & ~(size_t)1;
   const size_t nk = knots ? (size_t)B * n_knots * C : 0;
-  const size_t nbytes = n_int_pad * 4 + nk * sizeof(double);
+  const size_t pay_off = (n_int_pad * 4 + nk * sizeof(double) + 15) & ~(size_t)15;
+  const size_t nbytes = pay_off + c->payload.size();
   const int my_slot = c->next;           // advanced only when the step has been enqueued
   Slot& sl = c->slot[my_slot];
   if ((e = slot_reserve(c, my_slot, nbytes)) != hipSuccess) return (int)e;
@@ -669,6 +717,7 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     std::memcpy(sl.pinned + n_int_pad * 4, knots, nk * sizeof(double));
     knots_dev = reinterpret_cast<const double*>(sl.dev + n_int_pad * 4);
   }
+  if (!c->payload.empty()) std::memcpy(sl.pinned + pay_off, c->payload.data(), c->payload.size());
   if (c->gate_step != step) {
     new (c->seeded) PyRandom(step);
     c->gate_step = step;
@@ -723,9 +772,13 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     return (int)e;
   lap(5);
   const int32_t* d = reinterpret_cast<const int32_t*>(sl.dev);
-  const int err = pcgmix_mix_warp_f32(x, y, d, d + (size_t)B * 5, nullptr, lam, knots_dev, op_dev,
-                                      knots ? n_knots : 0, nullptr, B, C, T, stream);
+  const int err = pcgmix::launch_mix_warp(x, y, d, d + (size_t)B * 5, nullptr, lam, knots_dev, op_dev,
+                                          knots ? n_knots : 0, nullptr, B, C, T, s,
+                                          sl.dev + pay_off, c->payload_dst,
+                                          (int)(c->payload.size() / 16));
   if (err) return err;
+  c->payload.clear();
+  c->payload_dst = nullptr;
   lap(6);
   // An event per GROUP of kSlotGroup slots: recorded behind the group's last launch, waited for
   // before the group's first reuse (one stream-order point covers all four: fewer API calls).

@@ -27,5 +27,12 @@ hipError_t launch_skinny_partial(const float* h, const float* W, float* partial,
                                  int O, hipStream_t s, const uint8_t* mask, float scale, int thr,
                                  int bits);
 
+// pcgmix_mix.hip: pcgmix_mix_warp_f32 plus an optional payload of pay_n16 16-byte words that
+// block (0,0,0) copies from pay_src to pay_dst (both 16-byte aligned device addresses).
+int launch_mix_warp(const float* x, float* y, const int32_t* frames, const int32_t* mix_idx,
+                    const int32_t* off, float lam, const double* knots, const double* spline_op,
+                    int n_knots, const int32_t* zero_rect, int B, int C, int T, hipStream_t s,
+                    const void* pay_src, void* pay_dst, int pay_n16);
+
 }  // namespace pcgmix
 #endif

@@ -139,8 +139,14 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
     const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ frames,
     const int32_t* __restrict__ mix_idx, const int32_t* __restrict__ off, float lam, float oml,
     const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots,
-    const int32_t* __restrict__ zero_rect, int B, int C, int T, int epb) {
+    const int32_t* __restrict__ zero_rect, int B, int C, int T, int epb,
+    const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst, int pay_n16) {
   extern __shared__ __align__(16) double lds[];  // spline records per channel, then thresholds
+
+  // Step payload (pcgmix_ctx_set_payload): a few KB that travelled with the index block and
+  // belong somewhere else on the device; block (0,0,0) forwards them.
+  if (pay_n16 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0)
+    for (int i = threadIdx.x; i < pay_n16; i += kThreads) pay_dst[i] = pay_src[i];
 
   const int b = blockIdx.z * kBatchPerGridZ + blockIdx.y;
   if (b >= B) return;  // block-uniform
@@ -311,7 +317,23 @@ extern "C" int pcgmix_mix_warp_f32(const float* x, float* y, const int32_t* fram
                                    const double* knots, const double* spline_op, int n_knots,
                                    const int32_t* zero_rect, int B, int C, int T,
                                    pcgmix_stream_t stream) {
+  return pcgmix::launch_mix_warp(x, y, frames, mix_idx, off, lam, knots, spline_op, n_knots,
+                                 zero_rect, B, C, T, reinterpret_cast<hipStream_t>(stream), nullptr,
+                                 nullptr, 0);
+}
+
+int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, const int32_t* mix_idx,
+                            const int32_t* off, float lam, const double* knots,
+                            const double* spline_op, int n_knots, const int32_t* zero_rect, int B,
+                            int C, int T, hipStream_t s, const void* pay_src_v, void* pay_dst_v,
+                            int pay_n16) {
   using namespace pcgmix;
+  const uint4* pay_src = static_cast<const uint4*>(pay_src_v);
+  uint4* pay_dst = static_cast<uint4*>(pay_dst_v);
+  if (pay_n16 < 0 || (pay_n16 > 0 && (!pay_src || !pay_dst ||
+                                      ((reinterpret_cast<uintptr_t>(pay_src) |
+                                        reinterpret_cast<uintptr_t>(pay_dst)) & 15))))
+    return hipErrorInvalidValue;
   if (!x || !y || !frames || !mix_idx || x == y) return hipErrorInvalidValue;
   if (B < 0 || C <= 0 || T <= 0) return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
@@ -333,13 +355,13 @@ extern "C" int pcgmix_mix_warp_f32(const float* x, float* y, const int32_t* fram
   }
   const float oml = 1.0f - lam;  // float32 subtraction, as torch's (1 - lam) on a float32 tensor
 
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const unsigned gy = (unsigned)(B < kBatchPerGridZ ? B : kBatchPerGridZ);
   const unsigned gz = (unsigned)((B + kBatchPerGridZ - 1) / kBatchPerGridZ);
   dim3 grid(chunks, gy, gz), block(kThreads);
 #define PCGMIX_LAUNCH(V, W, UU)                                                              \
   hipLaunchKernelGGL((mix_warp_kernel<V, W, UU>), grid, block, lds, s, x, y, frames, mix_idx, \
-                     off, lam, oml, knots, spline_op, n_knots, zero_rect, B, C, T, epb)
+                     off, lam, oml, knots, spline_op, n_knots, zero_rect, B, C, T, epb, pay_src,  \
+                     pay_dst, pay_n16)
 #define PCGMIX_LAUNCH_U(W)                                \
   do {                                                    \
     if (U == 4) PCGMIX_LAUNCH(4, W, 4);                   \

@@ -196,11 +196,40 @@ constexpr int kFwdNX = 4 * kFwdTP + 12;         // 1020
 // forward: m2 (N, 4, ceil(P2/4)) — per pooled output 2 bits (0 = ReLU-dead, 1 = first conv output
 // of the pooled pair won, 2 = second), four outputs per byte — and, if s1 != nullptr, s1
 // (N, 8, P1) — the same selector for the first layer, one byte per pooled position.
+//
+// rnd != nullptr (SAVE only): the launch also fills rnd[0 .. rnd_n16) (16-byte words) with the
+// uniformly random bytes the classifier head's dropouts read (pcgmix_head.hip) — word i =
+// counter_hash(key, 4i .. 4i+3), key = two 32-bit words in device memory (or, key == nullptr, the
+// two kernel arguments).  In a captured training step this replaces an eager `random_()` launch
+// before every replay: the key changes per replay (it rides with the step payload), the graph
+// does not.
+__device__ __forceinline__ uint32_t counter_hash(uint32_t i, uint32_t k0, uint32_t k1) {
+  uint32_t h = i * 0x9E3779B1u + k0;      // murmur3's 32-bit finaliser, keyed before and inside
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h ^= k1;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
 template <bool SAVE>
 __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ h2,
-    uint8_t* __restrict__ m2, uint8_t* __restrict__ s1, int N, int T) {
+    uint8_t* __restrict__ m2, uint8_t* __restrict__ s1, int N, int T, uint4* __restrict__ rnd,
+    long long rnd_n16, const uint32_t* __restrict__ key, uint32_t key_lo, uint32_t key_hi) {
+  if (SAVE && rnd) {
+    const uint32_t k0 = key ? key[0] : key_lo, k1 = key ? key[1] : key_hi;
+    const long long stride = (long long)gridDim.x * gridDim.y * kPotThreads;
+    for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * kPotThreads + threadIdx.x;
+         i < rnd_n16; i += stride) {
+      const uint32_t c = (uint32_t)i * 4u;
+      rnd[i] = make_uint4(counter_hash(c, k0, k1), counter_hash(c + 1, k0, k1),
+                          counter_hash(c + 2, k0, k1), counter_hash(c + 3, k0, k1));
+    }
+  }
   __shared__ PotesWeights W;
   // swizzled planes (see layer1_t): x = 255 float4 -> E 128 + O 128; a1 = 127 float4 per channel
   // -> E 64 + O 64 per channel (+4 floats: lane 63 of conv2 reads E[64] of the last channel)
@@ -1020,10 +1049,18 @@ struct AdamTable {
   int count;
 };
 
+// hyper != nullptr: the eight scalars are read from device memory instead (clip, wd, 1-b1, b2,
+// 1-b2, step_size, 1/sqrt(bc2), eps — pcgmix_adam_hyper's layout): a launch captured in a
+// hipGraph then follows OneCycleLR's lr/beta1 and the bias corrections from replay to replay.
 __global__ __launch_bounds__(256) void adam_clip_multi_kernel(AdamTable tab, float clip, float wd,
                                                               float one_m_b1, float b2,
                                                               float one_m_b2, float step_size,
-                                                              float inv_bc2_sqrt, float eps) {
+                                                              float inv_bc2_sqrt, float eps,
+                                                              const float* __restrict__ hyper) {
+  if (hyper) {
+    clip = hyper[0]; wd = hyper[1]; one_m_b1 = hyper[2]; b2 = hyper[3];
+    one_m_b2 = hyper[4]; step_size = hyper[5]; inv_bc2_sqrt = hyper[6]; eps = hyper[7];
+  }
   int t = 0;
   while (t + 1 < tab.count && (int)blockIdx.x >= tab.blk_start[t + 1]) ++t;
   float* __restrict__ p = tab.p[t];
@@ -1052,18 +1089,54 @@ __global__ __launch_bounds__(256) void adam_clip_multi_kernel(AdamTable tab, flo
 
 }  // namespace pcgmix
 
+extern "C" int pcgmix_adam_hyper(float clip, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, long long step, float* out8) {
+  if (!out8 || step < 1) return hipErrorInvalidValue;
+  // bias corrections in float64 on the host, as torch computes them from Python floats
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  out8[0] = clip;
+  out8[1] = weight_decay;
+  out8[2] = 1.0f - beta1;
+  out8[3] = beta2;
+  out8[4] = 1.0f - beta2;
+  out8[5] = (float)((double)lr / bc1);
+  out8[6] = (float)(1.0 / std::sqrt(bc2));
+  out8[7] = eps;
+  return hipSuccess;
+}
+
+static int adam_multi_launch(int n_tensors, float* const* p, const float* const* g, float* const* m,
+                             float* const* v, const long long* n, const float* h8,
+                             const float* hyper_dev, hipStream_t stream);
+
+extern "C" int pcgmix_adam_clip_multi_dev_f32(int n_tensors, float* const* p, const float* const* g,
+                                              float* const* m, float* const* v, const long long* n,
+                                              const float* hyper_dev, pcgmix_stream_t stream) {
+  if (n_tensors < 0 || !hyper_dev || (n_tensors > 0 && (!p || !g || !m || !v || !n)))
+    return hipErrorInvalidValue;
+  const float zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return adam_multi_launch(n_tensors, p, g, m, v, n, zero8, hyper_dev,
+                           reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int pcgmix_adam_clip_multi_f32(int n_tensors, float* const* p, const float* const* g,
                                           float* const* m, float* const* v, const long long* n,
                                           float clip, float lr, float beta1, float beta2, float eps,
                                           float weight_decay, long long step,
                                           pcgmix_stream_t stream) {
-  using namespace pcgmix;
   if (n_tensors < 0 || step < 1 || (n_tensors > 0 && (!p || !g || !m || !v || !n)))
     return hipErrorInvalidValue;
-  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
-  const float inv_bc2_sqrt = (float)(1.0 / std::sqrt(bc2));
+  float h8[8];
+  pcgmix_adam_hyper(clip, lr, beta1, beta2, eps, weight_decay, step, h8);
+  return adam_multi_launch(n_tensors, p, g, m, v, n, h8, nullptr,
+                           reinterpret_cast<hipStream_t>(stream));
+}
+
+static int adam_multi_launch(int n_tensors, float* const* p, const float* const* g, float* const* m,
+                             float* const* v, const long long* n, const float* h8,
+                             const float* hyper_dev, hipStream_t stream) {
+  using namespace pcgmix;
   for (int first = 0; first < n_tensors; first += kAdamMaxTensors) {
     AdamTable tab;
     tab.count = 0;
@@ -1081,9 +1154,8 @@ extern "C" int pcgmix_adam_clip_multi_f32(int n_tensors, float* const* p, const 
     }
     if (tab.count == 0) continue;
     tab.blk_start[tab.count] = blocks;
-    hipLaunchKernelGGL(adam_clip_multi_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), tab, clip, weight_decay,
-                       1.0f - beta1, beta2, 1.0f - beta2, step_size, inv_bc2_sqrt, eps);
+    hipLaunchKernelGGL(adam_clip_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab,
+                       h8[0], h8[1], h8[2], h8[3], h8[4], h8[5], h8[6], h8[7], hyper_dev);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return (int)err;
   }
@@ -1135,7 +1207,7 @@ extern "C" int pcgmix_potes_stack_fwd_f32(const float* x, const float* w1, const
   const PotesDims d = potes_dims(T);
   dim3 grid((unsigned)((d.P2 + kFwdTP - 1) / kFwdTP), (unsigned)N), block(kPotThreads);
   hipLaunchKernelGGL(potes_fwd_kernel<false>, grid, block, 0, reinterpret_cast<hipStream_t>(stream),
-                     x, w1, b1, w2, b2, h2, nullptr, nullptr, N, T);
+                     x, w1, b1, w2, b2, h2, nullptr, nullptr, N, T, nullptr, 0ll, nullptr, 0u, 0u);
   return (int)hipGetLastError();
 }
 
@@ -1149,15 +1221,21 @@ extern "C" long long pcgmix_potes_mask_bytes(int N, int T, int layer) {
 extern "C" int pcgmix_potes_stack_fwd_save_f32(const float* x, const float* w1, const float* b1,
                                                const float* w2, const float* b2, float* h2,
                                                uint8_t* m2, uint8_t* s1, int N, int T,
+                                               uint8_t* rnd_out, long long rnd_bytes,
+                                               const uint32_t* key_dev, uint64_t key,
                                                pcgmix_stream_t stream) {
   using namespace pcgmix;
   if (!x || !w1 || !b1 || !w2 || !b2 || !h2 || !m2 || N < 0 || T < 14 || N > 65535)
+    return hipErrorInvalidValue;
+  if (rnd_out && (rnd_bytes <= 0 || (rnd_bytes & 15) || rnd_bytes > (16ll << 30) ||
+                  (reinterpret_cast<uintptr_t>(rnd_out) & 15) || N == 0))
     return hipErrorInvalidValue;
   if (N == 0) return hipSuccess;
   const PotesDims d = potes_dims(T);
   dim3 grid((unsigned)((d.P2 + kFwdTP - 1) / kFwdTP), (unsigned)N), block(kPotThreads);
   hipLaunchKernelGGL(potes_fwd_kernel<true>, grid, block, 0, reinterpret_cast<hipStream_t>(stream),
-                     x, w1, b1, w2, b2, h2, m2, s1, N, T);
+                     x, w1, b1, w2, b2, h2, m2, s1, N, T, reinterpret_cast<uint4*>(rnd_out),
+                     rnd_out ? rnd_bytes / 16 : 0ll, key_dev, (uint32_t)key, (uint32_t)(key >> 32));
   return (int)hipGetLastError();
 }
 

@@ -45,7 +45,10 @@ class PotesStackFunction(torch.autograd.Function):
     use_masks = True
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, rnd=None, key=None):
+        # rnd: a uint8 buffer the forward kernel fills, on the side, with the random bytes the
+        # head's dropouts read (pcgmix_hip.h); key: the 64-bit key of the fill — an int, or a
+        # device tensor of two int32 words (captured step: the key changes per replay)
         N, T = x.shape
         lib = _lib.load()
         P2 = lib.pcgmix_potes_out_len(T)
@@ -62,7 +65,13 @@ class PotesStackFunction(torch.autograd.Function):
             _lib.check(lib.pcgmix_potes_stack_fwd_save_f32(
                 x.data_ptr(), w1c.data_ptr(), b1c.data_ptr(), w2c.data_ptr(), b2c.data_ptr(),
                 h2.data_ptr(), m2.data_ptr(), s1.data_ptr() if s1 is not None else None, N, T,
-                stream), "pcgmix_potes_stack_fwd_save_f32")
+                rnd.data_ptr() if rnd is not None else None, rnd.numel() if rnd is not None else 0,
+                key.data_ptr() if torch.is_tensor(key) else None,
+                0 if (key is None or torch.is_tensor(key)) else int(key), stream),
+                "pcgmix_potes_stack_fwd_save_f32")
+        elif rnd is not None:
+            raise RuntimeError("PotesStackFunction: dropout bytes are filled by the mask-saving "
+                               "forward (needs use_masks and a gradient)")
         else:
             _lib.check(lib.pcgmix_potes_stack_fwd_f32(x.data_ptr(), w1c.data_ptr(), b1c.data_ptr(),
                                                       w2c.data_ptr(), b2c.data_ptr(), h2.data_ptr(),
@@ -104,7 +113,7 @@ class PotesStackFunction(torch.autograd.Function):
                     "pcgmix_potes_stack_bwd_f32")
             gw1, gb1 = grads[0:40].view(8, 1, 5), grads[40:48]
             gw2, gb2 = grads[48:208].view(4, 8, 5), grads[208:212]
-        return gx, gw1, gb1, gw2, gb2
+        return gx, gw1, gb1, gw2, gb2, None, None
 
 
 class SkinnyLinearFunction(torch.autograd.Function):
@@ -153,6 +162,22 @@ def dropout_threshold(p: float, max_bits: int = 8):
     bits = max_bits
     thr = min((1 << bits) - 1, max(0, int(round(p * (1 << bits)))))
     return bits, thr, float(1 << bits) / float((1 << bits) - thr)
+
+
+def next_dropout_key(device: torch.device) -> int:
+    """A 64-bit key for one training forward's dropout bytes, from torch's device generator —
+    splitmix64 of (seed, Philox offset), the offset advanced by 4 — on the host, without a launch:
+    ``torch.manual_seed`` / ``torch.cuda.manual_seed`` reproduce the masks as they do for
+    nn.Dropout (models.py:364, 380), and the reference's reseeding before every optimiser step
+    (train_model.py:565) gives every step the same masks here too."""
+    gen = torch.cuda.default_generators[device.index if device.index is not None
+                                        else torch.cuda.current_device()]
+    off = gen.get_offset()
+    gen.set_offset(off + 4)
+    z = (gen.initial_seed() + 0x9E3779B97F4A7C15 * (off // 4 + 1)) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
 
 
 def head_dropout_bytes(B: int, K: int, p1: float = 0.25) -> int:
@@ -361,7 +386,8 @@ class CNN_potes(nn.Module):
         self.dropout = nn.Dropout(0.5)
         self.linear = nn.Linear(20, c_out)
         self.fused = True       # use the fused HIP conv stack on a HIP device (see _fused)
-        self.dropout_bytes = None   # static random bytes of a captured training step (see _logits_fused)
+        self.dropout_bytes = None   # static random bytes of a captured training step and
+        self.dropout_key = None     # the device key they come from (see _static_dropout)
 
     def _fused(self, x: torch.Tensor) -> bool:
         """The hand-written HIP stack applies to the reference configuration (layers [8,4], float32)
@@ -384,17 +410,33 @@ class CNN_potes(nn.Module):
                 and self.linear.in_features == 20 and self.linear.out_features <= 8
                 and self.dimreduc.in_features % 4 == 0)
 
+    def _dropout_source(self, x: torch.Tensor):
+        """(bytes, key) for the training-mode dropouts of the fused path: the conv stack's forward
+        kernel fills ``bytes`` from ``key`` on the side and the head kernels read them.  While a
+        training step is being captured (GraphedTrainStep) both are static device tensors — the
+        step writes a fresh key before every replay; in eager training ``bytes`` is a scratch
+        buffer and ``key`` an int drawn from torch's device generator (``next_dropout_key``).
+        (None, None) in eval mode or without autograd: the head then needs none, or draws bytes
+        itself (``random_()``)."""
+        if not self.training or not torch.is_grad_enabled() or not PotesStackFunction.use_masks:
+            return None, None
+        if torch.cuda.is_current_stream_capturing():
+            if self.dropout_bytes is not None and self.dropout_key is not None:
+                return self.dropout_bytes, self.dropout_key
+            return None, None
+        drop = self.cnn1[1][3] if len(self.cnn1[1]) > 3 else None
+        n = head_dropout_bytes(x.shape[0], self.dimreduc.in_features, float(drop.p) if drop else 0.0)
+        return (torch.empty((n + 15) // 16 * 16, dtype=torch.uint8, device=x.device),
+                next_dropout_key(x.device))
+
     def _logits_fused(self, x: torch.Tensor) -> torch.Tensor:
         """Whole network on the HIP path: conv stack kernel + head kernels."""
         B, C, T = x.shape
         c1, c2 = self.cnn1[0][0], self.cnn1[1][0]
         rows = x[:, :4, :].reshape(B * 4, T)
-        z = PotesStackFunction.apply(rows.contiguous(), c1.weight, c1.bias, c2.weight, c2.bias)
+        rnd, key = self._dropout_source(x)
+        z = PotesStackFunction.apply(rows.contiguous(), c1.weight, c1.bias, c2.weight, c2.bias, rnd, key)
         drop = self.cnn1[1][3] if len(self.cnn1[1]) > 3 else None
-        # the captured training step hands over a static buffer of random bytes that it refills
-        # before every replay (GraphedTrainStep); everywhere else the head draws its own
-        rnd = self.dropout_bytes if (self.dropout_bytes is not None and self.training
-                                     and torch.cuda.is_current_stream_capturing()) else None
         return PotesHeadFunction.apply(z.reshape(B, -1), self.dimreduc.weight, self.dimreduc.bias,
                                        self.linear.weight, self.linear.bias,
                                        float(drop.p) if drop is not None else 0.0,
@@ -407,10 +449,9 @@ class CNN_potes(nn.Module):
         B, C, T = x.shape
         c1, c2 = self.cnn1[0][0], self.cnn1[1][0]
         rows = x[:, :4, :].reshape(B * 4, T)
-        z = PotesStackFunction.apply(rows.contiguous(), c1.weight, c1.bias, c2.weight, c2.bias)
+        rnd, key = self._dropout_source(x)
+        z = PotesStackFunction.apply(rows.contiguous(), c1.weight, c1.bias, c2.weight, c2.bias, rnd, key)
         drop = self.cnn1[1][3] if len(self.cnn1[1]) > 3 else None
-        rnd = self.dropout_bytes if (self.dropout_bytes is not None and self.training
-                                     and torch.cuda.is_current_stream_capturing()) else None
         return PotesHeadLossFunction.apply(z.reshape(B, -1), self.dimreduc.weight, self.dimreduc.bias,
                                            self.linear.weight, self.linear.bias, target,
                                            float(drop.p) if drop is not None else 0.0,

@@ -122,54 +122,130 @@ class ClipAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.clip_value = float(clip_value or 0.0)
         self._tables = {}
+        self._cap_params, self._cap_grads, self._cap_step, self._cap_dirty = None, None, 0, False
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._tables = {}                      # the moment tensors were replaced
+        if getattr(self, "_cap_params", None):
+            raise RuntimeError("ClipAdam: load the state before the step is captured (the graph "
+                               "holds the addresses of the old moment tensors)")
+
+    def _init_state(self, params):
+        for p in params:
+            st = self.state[p]
+            if not st:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+    def _table(self, gi, live, grads):
+        """Host pointer tables of the group's static tensors (rebuilt when a tensor moved)."""
+        import ctypes
+        key = tuple(p.data_ptr() for p in live)
+        tab = self._tables.get(gi)
+        if tab is None or tab[0] != key:
+            n = len(live)
+            arr = ctypes.c_void_p * n
+            tab = (key, arr(*key), arr(*[self.state[p]["exp_avg"].data_ptr() for p in live]),
+                   arr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in live]),
+                   (ctypes.c_longlong * n)(*[p.numel() for p in live]), arr())
+            self._tables[gi] = tab
+        gptr = tab[5]
+        for i, g in enumerate(grads):
+            gptr[i] = g.data_ptr()
+        return tab
+
+    @staticmethod
+    def _dense_grads(live):
+        # flat iteration over raw memory: p, grad, m, v must share one dense layout
+        return [p.grad if p.grad.stride() == p.stride() else torch.empty_like(p).copy_(p.grad)
+                for p in live]
 
     @torch.no_grad()
     def step(self, closure=None):
         import ctypes
         from . import _lib
         lib = _lib.load()
+        self._flush_captured_steps()
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             live = [p for p in group["params"] if p.grad is not None]
             if not live:
                 continue
+            self._init_state(live)
             for p in live:
-                st = self.state[p]
-                if not st:
-                    st["step"] = torch.tensor(0.0)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
+                self.state[p]["step"] += 1
             steps = {int(self.state[p]["step"]) for p in live}
             if len(steps) != 1:
                 raise RuntimeError("ClipAdam: parameters of one group must share the step count")
-            # flat iteration over raw memory: p, grad, m, v must share one dense layout
-            grads = [p.grad if p.grad.stride() == p.stride() else torch.empty_like(p).copy_(p.grad)
-                     for p in live]
-            key = tuple(p.data_ptr() for p in live)
-            tab = self._tables.get(gi)
-            if tab is None or tab[0] != key:          # pointer tables of the static tensors
-                n = len(live)
-                arr = ctypes.c_void_p * n
-                tab = (key, arr(*key), arr(*[self.state[p]["exp_avg"].data_ptr() for p in live]),
-                       arr(*[self.state[p]["exp_avg_sq"].data_ptr() for p in live]),
-                       (ctypes.c_longlong * n)(*[p.numel() for p in live]), arr())
-                self._tables[gi] = tab
-            gptr = tab[5]
-            for i, g in enumerate(grads):
-                gptr[i] = g.data_ptr()
+            tab = self._table(gi, live, self._dense_grads(live))
             dev = live[0].device
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(lib.pcgmix_adam_clip_multi_f32(
-                len(live), tab[1], gptr, tab[2], tab[3], tab[4], ctypes.c_float(self.clip_value),
+                len(live), tab[1], tab[5], tab[2], tab[3], tab[4], ctypes.c_float(self.clip_value),
                 ctypes.c_float(float(group["lr"])), ctypes.c_float(b1), ctypes.c_float(b2),
                 ctypes.c_float(group["eps"]), ctypes.c_float(group["weight_decay"]),
                 steps.pop(), stream), "pcgmix_adam_clip_multi_f32")
         return None
+
+    # ---- the update as a node of a captured training step (GraphedTrainStep) -----------------
+    # Kernel arguments are frozen at capture, OneCycleLR moves lr and beta1 every step and the
+    # bias corrections move with the step count: the captured launch reads its eight scalars from
+    # device memory (``pcgmix_adam_clip_multi_dev_f32``); ``next_hyper`` computes them on the host
+    # for the coming replay and advances the step count.
+    def can_capture(self) -> bool:
+        return len(self.param_groups) == 1
+
+    def prepare_capture(self, params):
+        """Before the capture: allocate the moments of ``params`` (the tensors that will carry a
+        gradient) — an allocation inside the capture would be re-zeroed by every replay."""
+        self._init_state(params)
+        steps = {int(self.state[p]["step"]) for p in params}
+        if len(steps) != 1:
+            raise RuntimeError("ClipAdam: parameters of one group must share the step count")
+        self._cap_params = list(params)
+        self._cap_step = steps.pop()
+
+    @torch.no_grad()
+    def capture_update(self, hyper_dev: torch.Tensor):
+        """Inside the capture, after backward: the update of all ``prepare_capture`` tensors."""
+        import ctypes
+        from . import _lib
+        live = self._cap_params
+        if any(p.grad is None for p in live):
+            raise RuntimeError("ClipAdam.capture_update: a prepared parameter has no gradient")
+        self._cap_grads = self._dense_grads(live)            # keep graph memory referenced
+        tab = self._table(0, live, self._cap_grads)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(live[0].device).cuda_stream)
+        _lib.check(_lib.load().pcgmix_adam_clip_multi_dev_f32(
+            len(live), tab[1], tab[5], tab[2], tab[3], tab[4], hyper_dev.data_ptr(), stream),
+            "pcgmix_adam_clip_multi_dev_f32")
+
+    def next_hyper(self, out8) -> None:
+        """Host: the eight scalars of the NEXT update into ``out8`` (float32[8], numpy), from the
+        param group as the scheduler left it; counts the step.  ``state[p]['step']`` is brought
+        up to date lazily (``state_dict`` / an eager ``step``)."""
+        import ctypes
+        from . import _lib
+        g = self.param_groups[0]
+        self._cap_step += 1
+        self._cap_dirty = True
+        self._opt_called = True                  # what LRScheduler's wrapper of step() records
+        _lib.check(_lib.load().pcgmix_adam_hyper(
+            ctypes.c_float(self.clip_value), ctypes.c_float(float(g["lr"])),
+            ctypes.c_float(g["betas"][0]), ctypes.c_float(g["betas"][1]), ctypes.c_float(g["eps"]),
+            ctypes.c_float(g["weight_decay"]), self._cap_step, out8.ctypes.data), "pcgmix_adam_hyper")
+
+    def _flush_captured_steps(self):
+        if getattr(self, "_cap_dirty", False):
+            for p in self._cap_params:
+                self.state[p]["step"].fill_(float(self._cap_step))
+            self._cap_dirty = False
+
+    def state_dict(self):
+        self._flush_captured_steps()
+        return super().state_dict()
 
 
 def selc_turning_point(args) -> int:
@@ -391,22 +467,43 @@ class GraphedTrainStep:
         self.device = device
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.x = torch.zeros(batch_size, channels, sig_len, device=device)
-        self.t = torch.zeros(batch_size, args.num_classes, device=device)
+        # Everything small the replay reads and the host decides per step lives in ONE static
+        # block, ``aux`` (float32 words): [0:2] dropout key (bits) | [4:12] Adam scalars |
+        # [12:12+B*classes] the float targets.  ``_payload`` is its host image; a plain splice
+        # carries it with its index block (``pcgmix_ctx_set_payload``: no copy of its own),
+        # other steps upload it with one H2D.
+        n_t = batch_size * args.num_classes
+        self.aux = torch.zeros(12 + (n_t + 3) // 4 * 4, device=device)
+        self.t = self.aux[12:12 + n_t].view(batch_size, args.num_classes)
         self.t[:, 0] = 1
+        self._payload = np.zeros(self.aux.numel(), dtype=np.float32)
+        self._pay_key = self._payload[0:2].view(np.uint32)
+        self._pay_hyper = self._payload[4:12]
+        self._pay_t = self._payload[12:12 + n_t].reshape(batch_size, args.num_classes)
+        self._rows = np.arange(batch_size)
         self.sync = sync
         self.bwd_seed = torch.full((), sync.backward_scale if sync else 1.0, device=device)
         # Dropout inside a captured region costs two extra fill launches per replay (torch's
         # graph-safe Philox state) on top of the mask kernels.  The Potes head reads random BYTES
-        # instead: a static buffer the captured kernels read, refilled by ONE eager `random_()` on
-        # torch's generator before every replay — seeding behaves as with nn.Dropout.
+        # instead, from a static buffer that the conv stack's forward kernel fills as a side job
+        # (``pcgmix_potes_stack_fwd_save_f32``: a keyed counter hash).  The key is drawn on the
+        # host from torch's device generator — (seed, offset), offset advanced by 4 per step — so
+        # ``torch.cuda.manual_seed`` behaves as with nn.Dropout, the reference's reseeding before
+        # every optimiser step (``reseed_device_rng``) included.
         self.rnd = None
         inner = model.module if hasattr(model, "module") else model
         if isinstance(inner, models.CNN_potes) and device.type == "cuda":
             K = inner.dimreduc.in_features
             drop = inner.cnn1[1][3] if len(inner.cnn1[1]) > 3 else None
-            self.rnd = torch.empty(models.head_dropout_bytes(batch_size, K, float(drop.p) if drop else 0.0),
-                                   dtype=torch.uint8, device=device)
+            n_rnd = models.head_dropout_bytes(batch_size, K, float(drop.p) if drop else 0.0)
+            self.rnd = torch.empty((n_rnd + 15) // 16 * 16, dtype=torch.uint8, device=device)
             inner.dropout_bytes = self.rnd
+            inner.dropout_key = self.aux[0:2].view(torch.int32)
+        # The optimiser update is the graph's last node when nothing has to happen between
+        # backward and update (no gradient all-reduce) and the optimiser can read its scalars
+        # from ``aux`` (ClipAdam).
+        self.adam_in_graph = sync is None and isinstance(optimizer, ClipAdam) \
+            and optimizer.can_capture() and device.type == "cuda"
         # The warm-up passes run the network on the all-zero placeholder batch: they must leave no
         # trace.  Weights are not updated (no optimiser step); BatchNorm running statistics and
         # num_batches_tracked, and the device RNG stream the dropout masks come from, are put
@@ -421,6 +518,8 @@ class GraphedTrainStep:
                 self._fwd_bwd()
             if sync is not None:
                 sync.attach()
+            if self.adam_in_graph:
+                self.opt.prepare_capture([p for p in self.params if p.grad is not None])
         torch.cuda.current_stream(device).wait_stream(side)
         with torch.no_grad():
             for b, saved in buffers:
@@ -436,6 +535,8 @@ class GraphedTrainStep:
         # thread_local: HIP calls of other threads (RCCL's watchdog) must not abort the capture
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss, self.out = self._fwd_bwd()
+            if self.adam_in_graph:
+                self.opt.capture_update(self.aux[4:12])
 
     def _fwd_bwd(self):
         fused = fused_loss_model(self.model, self.ce, self.x, self.t, None) \
@@ -452,8 +553,14 @@ class GraphedTrainStep:
             nn.utils.clip_grad_value_(self.params, clip_value=self.args.grad_clip)
         return loss.detach(), out.detach()
 
+    def _next_key(self) -> None:
+        """This step's dropout key from torch's device generator (host only, no launch)."""
+        z = models.next_dropout_key(self.device)
+        self._pay_key[0] = z & 0xFFFFFFFF
+        self._pay_key[1] = z >> 32
+
     def step(self, batch, epoch, step_counter, stats: Optional[dict] = None):
-        from . import hostprep
+        from . import hostprep, _lib
         data, target, frames, wav, _sq, _idx = batch
         if self.es is not None and epoch > self.es:
             raise NotImplementedError("SELC phase is not captured; use train_step")
@@ -462,14 +569,25 @@ class GraphedTrainStep:
         frames_np = augmentations._as_numpy_frames(frames)
         B, C, T = data.shape
         step = int(step_counter.count)
+        # host image of the static block: one-hot float targets, dropout key, Adam scalars
+        labels_np = target.numpy() if not target.is_cuda else target.cpu().numpy()
+        self._pay_t.fill(0.0)
+        self._pay_t[self._rows, labels_np] = 1.0
+        if self.rnd is not None and self.model.training:
+            self._next_key()
+        if self.adam_in_graph:
+            self.opt.next_hyper(self._pay_hyper)
         recipe = hostprep.plain_recipe(args.method, False)
+        lib, ctx = _lib.load(), augmentations.step_context(data.device.index)
+        _lib.check(lib.pcgmix_ctx_set_payload(ctx, self._payload.ctypes.data, self._payload.nbytes,
+                                              self.aux.data_ptr()), "pcgmix_ctx_set_payload")
         if recipe is not None and B > 0:                # plain splice: one library call
             fired = augmentations.gate_passes(recipe, args.method, step, data.device.index)
             plan = hostprep.MixPlan(fired=False)
-            if fired:
-                augmentations.splice_plain(recipe, data, target.numpy(), frames_np, step, out=self.x)
+            if fired:                                   # ... which carries the payload along
+                augmentations.splice_plain(recipe, data, labels_np, frames_np, step, out=self.x)
         else:
-            plan = hostprep.make_plan(args.method, target.numpy(), frames_np, wav, step, B, C) \
+            plan = hostprep.make_plan(args.method, labels_np, frames_np, wav, step, B, C) \
                 if hostprep.select_method(args.method, False) else hostprep.MixPlan(fired=False)
             if plan.salopt_mode is not None:
                 raise NotImplementedError("saliency-guided steps are not captured; use train_step")
@@ -478,23 +596,20 @@ class GraphedTrainStep:
                 augmentations.apply_plan(plan, data, frames_np, out=self.x)
         if not fired:
             self.x.copy_(data, non_blocking=True)
+        # any other step: the payload goes on its own (no-op when the splice took it)
+        _lib.check(lib.pcgmix_ctx_flush_payload(
+            ctx, torch.cuda.current_stream(self.device).cuda_stream), "pcgmix_ctx_flush_payload")
         if plan.fired and plan.mix_all:                 # float blend of the one-hot rows
             t_ohe = F.one_hot(target, args.num_classes).to(self.device, non_blocking=True)
             self.t.copy_(augmentations.blend_targets(t_ohe, plan))
-        elif target.is_cuda:
-            self.t.copy_(F.one_hot(target, args.num_classes))
-        else:                                           # one-hot in float on the host: one small
-            self.t.copy_(F.one_hot(target, args.num_classes).to(torch.float32),   # H2D, no kernel
-                         non_blocking=True)
-        if self.rnd is not None and self.model.training:
-            self.rnd.random_()                          # this step's dropout masks
         self.graph.replay()
-        if self.sync is not None:
-            self.sync.reduce_and_bind()
-            if self.args.grad_clip and not isinstance(self.opt, ClipAdam):
-                nn.utils.clip_grad_value_(self.sync.params, clip_value=self.args.grad_clip)
         reseed_device_rng(self.args, self.device)
-        self.opt.step()
+        if not self.adam_in_graph:
+            if self.sync is not None:
+                self.sync.reduce_and_bind()
+                if self.args.grad_clip and not isinstance(self.opt, ClipAdam):
+                    nn.utils.clip_grad_value_(self.sync.params, clip_value=self.args.grad_clip)
+            self.opt.step()
         if self.sched is not None:
             self.sched.step()
         step_counter.add()

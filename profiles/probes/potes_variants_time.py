@@ -30,8 +30,8 @@ def timeit(name, fn, n=200):
 
 
 timeit("fwd", lambda: lib.pcgmix_potes_stack_fwd_f32(P(x), P(w1), P(b1), P(w2), P(b2), P(h2), N, T, st))
-timeit("fwd + m2", lambda: lib.pcgmix_potes_stack_fwd_save_f32(P(x), P(w1), P(b1), P(w2), P(b2), P(h2), P(m2), None, N, T, st))
-timeit("fwd + m2 + s1", lambda: lib.pcgmix_potes_stack_fwd_save_f32(P(x), P(w1), P(b1), P(w2), P(b2), P(h2), P(m2), P(s1), N, T, st))
+timeit("fwd + m2", lambda: lib.pcgmix_potes_stack_fwd_save_f32(P(x), P(w1), P(b1), P(w2), P(b2), P(h2), P(m2), None, N, T, None, 0, None, 0, st))
+timeit("fwd + m2 + s1", lambda: lib.pcgmix_potes_stack_fwd_save_f32(P(x), P(w1), P(b1), P(w2), P(b2), P(h2), P(m2), P(s1), N, T, None, 0, None, 0, st))
 timeit("input_grad (recompute)", lambda: lib.pcgmix_potes_stack_input_grad_f32(P(x), P(g), P(w1), P(b1), P(w2), P(b2), P(gx), N, T, st))
 timeit("input_grad (masks)", lambda: lib.pcgmix_potes_stack_input_grad_mask_f32(P(g), P(m2), P(s1), P(w1), P(w2), P(gx), N, T, st))
 for blocks in (512, 768, 1024, 1280, 1536, 2048, 3072):

@@ -198,3 +198,39 @@ def test_full_size_2d_against_oracle(device):
         g = dict(x=x, labels=labels, frames=fs, wav=wav, step=step, method=method)
         _, _, (y, _, mix, _) = run(augmentations2d, g, device)
         assert np.array_equal(mix, ref["mix"]) and np.array_equal(y.cpu().numpy(), ref["y"])
+
+
+def test_step_payload_rides_with_the_splice(device):
+    """pcgmix_ctx_set_payload: bytes handed over before a plain step arrive at their device
+    address with that step's single H2D copy (block (0,0,0) of the splice kernel forwards them);
+    one shot; the splice itself is unchanged."""
+    from pcgmix_amd import _lib, hostprep
+    lib = _lib.load()
+    x, frames, labels, _ = synthetic.make_batch(16, 4, 2500, seed=12)
+    data = torch.from_numpy(x).to(device)
+    recipe = hostprep.plain_recipe("durmixmagwarp(0.2,4)", False)
+    ref, mix_ref = augmentations.splice_plain(recipe, data, labels, frames, 5)
+    ctx = augmentations.step_context(device.index)
+    for nbytes in (8, 48, 4096 + 24):                        # not multiples of 16 as well
+        pay = np.random.RandomState(nbytes).randint(0, 256, nbytes).astype(np.uint8)
+        dst = torch.full(((nbytes + 15) // 16 * 16 + 16,), 7, dtype=torch.uint8, device=device)
+        _lib.check(lib.pcgmix_ctx_set_payload(ctx, pay.ctypes.data, nbytes, dst.data_ptr()), "payload")
+        out, mix = augmentations.splice_plain(recipe, data, labels, frames, 5)
+        got = dst.cpu().numpy()
+        assert np.array_equal(got[:nbytes], pay)
+        assert (got[nbytes:(nbytes + 15) // 16 * 16] == 0).all() and (got[-16:] == 7).all()
+        assert torch.equal(out, ref) and np.array_equal(mix, mix_ref)
+        dst.fill_(9)                                         # consumed: the next step carries nothing
+        augmentations.splice_plain(recipe, data, labels, frames, 5)
+        assert (dst.cpu().numpy() == 9).all()
+    # a payload whose step does not come is sent on its own
+    pay = np.arange(40, dtype=np.uint8)
+    dst = torch.full((64,), 7, dtype=torch.uint8, device=device)
+    st = torch.cuda.current_stream(device).cuda_stream
+    _lib.check(lib.pcgmix_ctx_set_payload(ctx, pay.ctypes.data, 40, dst.data_ptr()), "payload")
+    _lib.check(lib.pcgmix_ctx_flush_payload(ctx, st), "flush")
+    _lib.check(lib.pcgmix_ctx_flush_payload(ctx, st), "flush")          # nothing pending: no-op
+    got = dst.cpu().numpy()
+    assert np.array_equal(got[:40], pay) and (got[40:48] == 0).all() and (got[48:] == 7).all()
+    with pytest.raises(RuntimeError):                       # destination not 16-byte aligned
+        _lib.check(lib.pcgmix_ctx_set_payload(ctx, pay.ctypes.data, 8, dst.data_ptr() + 4), "payload")

@@ -147,3 +147,64 @@ def test_saved_masks_equal_recomputed_routing(device):
     assert torch.equal(res[True][0], res[False][0])
     for a, b in zip(res[True][1], res[False][1]):
         assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-6)
+
+
+def _counter_hash(n_words, key):
+    """numpy restatement of counter_hash (csrc/pcgmix_potes.hip): murmur3's 32-bit finaliser, keyed."""
+    k0, k1 = np.uint32(key & 0xFFFFFFFF), np.uint32(key >> 32)
+    with np.errstate(over="ignore"):
+        h = np.arange(n_words, dtype=np.uint32) * np.uint32(0x9E3779B1) + k0
+        h ^= h >> np.uint32(16)
+        h *= np.uint32(0x85EBCA6B)
+        h ^= h >> np.uint32(13)
+        h ^= k1
+        h *= np.uint32(0xC2B2AE35)
+        h ^= h >> np.uint32(16)
+    return h
+
+
+@pytest.mark.parametrize("key_on_device", [False, True])
+def test_forward_fills_dropout_bytes(key_on_device, device):
+    """The mask-saving forward also fills the head's dropout bytes: word w = counter_hash(key, w),
+    key by value or from device memory; the forward's own outputs do not change; the bytes are
+    uniform enough for dropout (mean, per-bit balance) and differ between keys."""
+    import ctypes
+    from pcgmix_amd import _lib
+    lib = _lib.load()
+    N, T = 64, 2500
+    m = make(T, device)
+    c1, c2 = m.cnn1[0][0], m.cnn1[1][0]
+    x = torch.randn(N, T, device=device)
+    P2 = lib.pcgmix_potes_out_len(T)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def forward(rnd, key):
+        h2 = torch.empty(N, 4, P2, device=device)
+        m2 = torch.empty(lib.pcgmix_potes_mask_bytes(N, T, 2), dtype=torch.uint8, device=device)
+        kd = torch.tensor([key & 0xFFFFFFFF, key >> 32], dtype=torch.int64).to(torch.int32).to(device) \
+            if (key_on_device and rnd is not None) else None
+        _lib.check(lib.pcgmix_potes_stack_fwd_save_f32(
+            x.data_ptr(), c1.weight.data_ptr(), c1.bias.data_ptr(), c2.weight.data_ptr(),
+            c2.bias.data_ptr(), h2.data_ptr(), m2.data_ptr(), None, N, T,
+            rnd.data_ptr() if rnd is not None else None, rnd.numel() if rnd is not None else 0,
+            kd.data_ptr() if kd is not None else None, 0 if kd is not None else key, st), "fwd")
+        return h2, m2
+
+    h_ref, m_ref = forward(None, 0)
+    words = []
+    for key, nbytes in ((0x0123456789ABCDEF, 16), (0xFEDCBA9876543210, 3 * 1024 * 1024 + 16)):
+        rnd = torch.zeros(nbytes + 16, dtype=torch.uint8, device=device)
+        h2, m2 = forward(rnd[:nbytes], key)
+        got = rnd.cpu().numpy()
+        assert (got[nbytes:] == 0).all()
+        w = got[:nbytes].view(np.uint32)
+        assert np.array_equal(w, _counter_hash(nbytes // 4, key))
+        assert torch.equal(h2, h_ref) and torch.equal(m2, m_ref)
+        words.append(w)
+    big = words[1]
+    assert abs(big.view(np.uint8).mean() - 127.5) < 0.5
+    bits = np.unpackbits(big.view(np.uint8)[:1 << 20]).reshape(-1, 8).mean(0)
+    assert np.abs(bits - 0.5).max() < 0.01
+    assert (_counter_hash(4096, 1) != _counter_hash(4096, 2)).mean() > 0.99
+    with pytest.raises(RuntimeError):                       # not a multiple of 16 bytes
+        forward(torch.zeros(24, dtype=torch.uint8, device=device), 1)

@@ -311,7 +311,7 @@ def _driver_rank(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ds = _learnable_dataset(n_rec=24)
     args = argparse.Namespace(dataset="PhysioNet", model="Potes", method="durratiomixup+0.8",
-                              num_epochs=3, batch_size=32, op="adam", use_sched=True, lr_max=0.003,
+                              num_epochs=6, batch_size=32, op="adam", use_sched=True, lr_max=0.003,
                               weight_decay=1e-4, grad_clip=0.1, seed=4, seed_data=1100001,
                               n_fraction=1.0, train_balance=True, num_classes=2, sample_rate=1000,
                               num_channels=4, valid=False, depth=0, EXPERIMENTS=out_dir)
@@ -336,10 +336,12 @@ def test_train_model_driver_two_ranks_graphed(device, tmp_path):
     mp.spawn(_driver_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(str(tmp_path / "rank0.pt"), weights_only=True)
     r1 = torch.load(str(tmp_path / "rank1.pt"), weights_only=True)
-    assert r0["steps"] == r1["steps"] and r0["steps"][-1] == 3 * (96 // 32)
+    assert r0["steps"] == r1["steps"] and r0["steps"][-1] == 6 * (96 // 32)
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)
-    assert r0["loss"][-1] < r0["loss"][0]
+    # (the reference's reseeding gives every step the SAME dropout masks: the first few steps of
+    # a run can go either way — profiles/probes/loss_probe_2rank.py; six epochs do not)
+    assert r0["loss"][-1] < 0.75 * r0["loss"][0]
     assert len(glob.glob(str(tmp_path / "*" / "model.pth"))) == 1
 
 
@@ -512,3 +514,44 @@ def test_graphed_step_matches_eager_with_dropout(device):
     assert len(set(results[0][0])) == 5
     for a, b in zip(results[0][1], results[1][1]):
         assert torch.allclose(a, b, rtol=1e-3, atol=1e-4)
+
+
+def test_clip_adam_captured_update_matches_eager(device):
+    """ClipAdam as a hipGraph node (scalars read from device memory, computed on the host by
+    next_hyper before every replay) == the eager ClipAdam.step, bit for bit, under OneCycleLR
+    (lr and beta1 change every step); the step count reaches the state dict."""
+    torch.manual_seed(0)
+    shapes = [(20, 19968), (8, 1, 5), (20,), (2, 20)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=device)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = tm.ClipAdam(pa, lr=0.01, weight_decay=1e-4, clip_value=0.1)
+    ob = tm.ClipAdam(pb, lr=0.01, weight_decay=1e-4, clip_value=0.1)
+    sa = torch.optim.lr_scheduler.OneCycleLR(oa, max_lr=0.01, total_steps=12)
+    sb = torch.optim.lr_scheduler.OneCycleLR(ob, max_lr=0.01, total_steps=12)
+    grads = [torch.zeros_like(p) for p in pa]
+    for p, g in zip(pa, grads):
+        p.grad = g
+    hyper = torch.zeros(8, device=device)
+    host = np.zeros(8, dtype=np.float32)
+    assert oa.can_capture()
+    oa.prepare_capture(pa)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        oa.capture_update(hyper)
+    for it in range(10):
+        for g, y in zip(grads, pb):
+            g.copy_(torch.randn_like(g) * (0.3 if it % 2 else 0.05))
+            y.grad = g.clone()
+        oa.next_hyper(host)
+        hyper.copy_(torch.from_numpy(host))
+        graph.replay()
+        ob.step(); sa.step(); sb.step()
+        assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)
+        assert torch.equal(oa.state[x]["exp_avg"], ob.state[y]["exp_avg"])
+        assert torch.equal(oa.state[x]["exp_avg_sq"], ob.state[y]["exp_avg_sq"])
+    sd = oa.state_dict()
+    assert all(float(v["step"]) == 10.0 for v in sd["state"].values())
+    with pytest.raises(RuntimeError):
+        oa.load_state_dict(sd)                               # the graph holds the old moments
