@@ -26,8 +26,12 @@ def dur(r):
     return int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 
 
-shutil.copy(os.path.join(src, "prof_r2_bench", "b_kernel_stats.csv"), os.path.join(HERE, "r2_bench_kernel_stats.csv"))
-rows = list(csv.DictReader(open(os.path.join(src, "prof_r2_bench", "b_kernel_trace.csv"))))
+# the bench alone is re-profiled more often than the ResNet probes (run_r2_bench_profile.sh writes
+# prof_r2_bench2): take the newer of the two traces
+bench_dir = max((os.path.join(src, d) for d in ("prof_r2_bench", "prof_r2_bench2")
+                 if os.path.exists(os.path.join(src, d, "b_kernel_trace.csv"))), key=os.path.getmtime)
+shutil.copy(os.path.join(bench_dir, "b_kernel_stats.csv"), os.path.join(HERE, "r2_bench_kernel_stats.csv"))
+rows = list(csv.DictReader(open(os.path.join(bench_dir, "b_kernel_trace.csv"))))
 groups = collections.defaultdict(list)
 for r in rows:
     if "pcgmix::" in r["Kernel_Name"] or "label_argmax" in r["Kernel_Name"]:
