@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 10
+#define PCGMIX_ABI_VERSION 11
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -179,6 +179,16 @@ long long pcgmix_salopt_workspace_bytes(int B);
 int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames, const int32_t* mix_idx,
                            float lam, int mode, int32_t* disp, void* workspace, int max_len, int B,
                            int T, pcgmix_stream_t stream);
+/* The saliency-guided splice — mixup_keepdur_multidim_tensors_salopt for the whole batch
+ * (augmentations.py:210-287 with :60-128, the loop at :909-917, magnitude_warp :674-683) — in one
+ * call: the search above, then pcgmix_mix_warp_f32's kernel, whose blocks reduce the search's
+ * per-block results for their own sample themselves (no launch in between).  knots / spline_op /
+ * n_knots as in pcgmix_mix_warp_f32 (NULL, NULL, 0: no warp).  disp_out: NULL, or int32 (B,4) that
+ * receives the displacements from a small launch BEHIND the splice.                            */
+int pcgmix_salopt_mix_warp_f32(const float* x, float* y, const float* sal, const int32_t* frames,
+                               const int32_t* mix_idx, float lam, int mode, const double* knots,
+                               const double* spline_op, int n_knots, void* workspace, int max_len,
+                               int32_t* disp_out, int B, int C, int T, pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Log-mel front end.                                                    [host tables + device]
@@ -401,6 +411,14 @@ int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, const uint8_
  *   backward: gscale = device scalar d L / d loss (NULL = 1): dx and dW1 from dz * gscale in one pass
  *             over x (as pcgmix_potes_head_bwd_f32), small_out = small_in * gscale.
  */
+/* The head of a FROZEN model in eval mode, for d score / d input (saliency.py:52-61): features ->
+ * split-K product -> dz = (z > 0) * (seed W2) -> dx = dz W1, three launches, no logits, no weight
+ * gradients.  seed (B,C) = d score / d logits (the one-hot of the label; pcgmix_ctx_labels_begin
+ * can write it); partial as for pcgmix_potes_head_fwd_f32; dz (B,20) scratch, 16-byte aligned;
+ * dx (B,K) out.                                                                              */
+int pcgmix_potes_head_saliency_f32(const float* x, const float* w1, const float* b1, const float* w2,
+                                   const float* seed, float* partial, float* dz, float* dx, int B,
+                                   int K, int C, pcgmix_stream_t stream);
 long long pcgmix_potes_head_loss_workspace_floats(int B);
 int pcgmix_potes_head_loss_fwd_f32(const float* x, const uint8_t* mask1, float scale1, int thr1,
                                    int bits1, const float* w1, const float* b1, const uint8_t* mask2,
@@ -507,11 +525,35 @@ int pcgmix_ctx_set_payload(pcgmix_ctx* ctx, const void* host, size_t bytes, void
  * gate): one H2D copy from the context's pinned ring straight to dst_dev on `stream`.  No-op
  * when nothing is pending. */
 int pcgmix_ctx_flush_payload(pcgmix_ctx* ctx, pcgmix_stream_t stream);
+/* The saliency-guided step ('(saloptenv)…' / '(saloptsum)…' with same-label partners,
+ * augmentations.py:874-928) as two calls around the caller's saliency pass:
+ *   begin   label arg-max kernel (labels -> host-mapped memory; float one-hot -> seed_out, DEVICE
+ *           (B, num_classes), the saliency model's gradient seed, may be NULL); `frames` (HOST
+ *           int64 (B,5)) validated, packed to int32 and copied to frames_dst_dev (DEVICE, B*5
+ *           int32: what saliency post-processing, search and splice read).  target_ohe_dev may be
+ *           NULL when the labels will be handed over to finish.
+ *   ...     the caller enqueues the frozen model's forward + input gradient + post-processing
+ *           (get_saliency_maps, saliency.py:20-91) and draws lambda and the warp knots
+ *   finish  labels picked up (labels_host NULL) or taken from labels_host; partners drawn as
+ *           get_same_label_mix_indices does; [partners | knots] in one H2D copy; displacement
+ *           search + fused splice(+warp) as in pcgmix_salopt_mix_warp_f32; mix_out (HOST int64
+ *           (B)) = the partner indices.
+ * Returns 0, -1 / -2 for malformed boundaries (begin; nothing is copied), or a hipError_t.       */
+int pcgmix_ctx_salopt_begin(pcgmix_ctx* ctx, const int64_t* target_ohe_dev, int num_classes,
+                            float* seed_out, const int64_t* frames, int32_t* frames_dst_dev, int B,
+                            int T, pcgmix_stream_t stream);
+int pcgmix_ctx_salopt_finish(pcgmix_ctx* ctx, const float* x, float* y, const float* sal,
+                             const int32_t* frames_dev, const int64_t* labels_host, uint64_t step,
+                             float lam, int mode, const double* knots, int n_knots, int64_t* mix_out,
+                             int B, int C, int T, pcgmix_stream_t stream);
 /* The label read-back alone, in two halves, for steps that have GPU work to enqueue in between
  * (the saliency-guided step, augmentations.py:881-907): begin = the arg-max kernel on `stream`;
- * wait = the spin on the flag word, then int64 class labels in labels_out (HOST, B). */
+ * wait = the spin on the flag word, then int64 class labels in labels_out (HOST, B).
+ * seed_out (DEVICE, float (B, num_classes), may be NULL): the same kernel also writes the one-hot
+ * of the labels as floats — d score[label] / d logits, the seed of the saliency model's input
+ * gradient (saliency.py:52-61) — sparing the max / zeros / scatter launches that build it. */
 int pcgmix_ctx_labels_begin(pcgmix_ctx* ctx, const int64_t* target_ohe_dev, int num_classes, int B,
-                            pcgmix_stream_t stream);
+                            float* seed_out, pcgmix_stream_t stream);
 int pcgmix_ctx_labels_wait(pcgmix_ctx* ctx, int64_t* labels_out, int B, pcgmix_stream_t stream);
 int pcgmix_augment_plain_f32(pcgmix_ctx* ctx, const float* x, float* y,
                              const int64_t* target_ohe_dev, int num_classes,

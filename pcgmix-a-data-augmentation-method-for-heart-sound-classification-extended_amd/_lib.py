@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -35,6 +35,9 @@ SIGNATURES = {
     "pcgmix_salopt_workspace_bytes": (ctypes.c_longlong, [_c_int]),
     "pcgmix_salopt_disp_f32": (_c_int, [_ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _ptr, _c_int, _c_int,
                                         _c_int, _ptr]),
+    "pcgmix_salopt_mix_warp_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _ptr,
+                                            _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr]),
+    "pcgmix_potes_head_saliency_f32": (_c_int, [_ptr] * 8 + [_c_int, _c_int, _c_int, _ptr]),
     "pcgmix_logmel_tables_size": (ctypes.c_longlong, [_c_int, _c_int]),
     "pcgmix_logmel_tables": (_c_int, [_c_int, _c_int, _c_float, _c_float, _c_float, _ptr]),
     "pcgmix_logmel_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
@@ -89,8 +92,11 @@ SIGNATURES = {
     "pcgmix_ctx_gate": (ctypes.c_double, [_ptr, ctypes.c_uint64]),
     "pcgmix_ctx_set_payload": (_c_int, [_ptr, _ptr, ctypes.c_size_t, _ptr]),
     "pcgmix_ctx_flush_payload": (_c_int, [_ptr, _ptr]),
+    "pcgmix_ctx_salopt_begin": (_c_int, [_ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),
+    "pcgmix_ctx_salopt_finish": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_uint64, _c_float,
+                                          _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_ctx_phase_times": (ctypes.c_longlong, [_ptr, _ptr]),
-    "pcgmix_ctx_labels_begin": (_c_int, [_ptr, _ptr, _c_int, _c_int, _ptr]),
+    "pcgmix_ctx_labels_begin": (_c_int, [_ptr, _ptr, _c_int, _c_int, _ptr, _ptr]),
     "pcgmix_ctx_labels_wait": (_c_int, [_ptr, _ptr, _c_int, _ptr]),
     "pcgmix_augment_plain_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _ptr, ctypes.c_uint64,
                                           _c_float, _ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr]),

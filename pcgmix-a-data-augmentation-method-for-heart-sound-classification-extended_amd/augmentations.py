@@ -125,6 +125,20 @@ def upload_array(arr: np.ndarray, device: torch.device) -> torch.Tensor:
     return dev[:nbytes].view(torch.from_numpy(arr[:0].reshape(-1)).dtype).view(arr.shape)
 
 
+def upload_into(dst: torch.Tensor, arr: np.ndarray) -> None:
+    """Async H2D copy of a small host array straight into the device tensor ``dst`` (same byte
+    size) through the pinned staging ring.  Must be called with ``dst``'s device current."""
+    arr = np.ascontiguousarray(arr)
+    nbytes = arr.nbytes
+    if nbytes != dst.numel() * dst.element_size() or not dst.is_contiguous():
+        raise ValueError("upload_into: size mismatch")
+    ring = _RINGS.setdefault(dst.device.index, _StagingRing())
+    slot, pinned = ring.stage(max(nbytes, 1))
+    pinned.numpy()[:nbytes] = arr.reshape(-1).view(np.uint8)
+    dst.view(torch.uint8).view(-1).copy_(pinned[:nbytes], non_blocking=True)
+    ring.sent(slot, torch.cuda.current_stream(dst.device))
+
+
 _PACK_ERRORS = {1: "frames must be non-decreasing and non-negative",
                 2: "heart cycle ends beyond the signal length",
                 3: "partner index out of range"}
@@ -190,15 +204,8 @@ def apply_plan(plan: MixPlan, data: torch.Tensor, frames: np.ndarray,
         frames_ptr, mix_ptr = base + offs["frames"], base + offs["mix"]
         off_ptr = base + offs["off"] if offs["off"] is not None else None
         keep = [dev]
-        if plan.salopt_mode is not None:
-            if saliency_maps is None:
-                raise ValueError("saliency-guided mixing needs saliency maps")
-            from . import saliency as _sal
-            disp = _sal.optimal_displacements(saliency_maps, frames_ptr, mix_ptr,
-                                              float(plan.lam32), plan.salopt_mode, B, T,
-                                              max_len=int(np.diff(frames, axis=1).max()))
-            keep.append(disp)
-            off_ptr = disp.data_ptr()
+        if plan.salopt_mode is not None and saliency_maps is None:
+            raise ValueError("saliency-guided mixing needs saliency maps")
         knots_ptr = op_ptr = None
         if plan.knots is not None:
             op = spline_operator(device, T, plan.n_knots)
@@ -210,8 +217,25 @@ def apply_plan(plan: MixPlan, data: torch.Tensor, frames: np.ndarray,
                 or out.data_ptr() == data.data_ptr():
             raise ValueError("out must be a distinct contiguous tensor shaped like data")
         rect_ptr = base + offs["rect"] if offs["rect"] is not None else None
-        launch_mix(data, out, frames_ptr, mix_ptr, off_ptr, float(plan.lam32), knots_ptr, op_ptr,
-                   plan.n_knots, B, C, T, rect_ptr)
+        if plan.salopt_mode is not None:
+            # displacement search + splice in one call: the splice kernel reduces the search's
+            # per-block results itself (pcgmix_salopt_mix_warp_f32)
+            sal = saliency_maps
+            if sal.shape != (B, T) or sal.dtype != torch.float32 or not sal.is_contiguous() \
+                    or sal.device != device:
+                raise ValueError("saliency maps must be a contiguous float32 (B, T) device tensor")
+            lib = _lib.load()
+            ws = torch.empty(max(1, lib.pcgmix_salopt_workspace_bytes(B) // 8), dtype=torch.int64,
+                             device=device)
+            keep.append(ws)
+            _lib.check(lib.pcgmix_salopt_mix_warp_f32(
+                data.data_ptr(), out.data_ptr(), sal.data_ptr(), frames_ptr, mix_ptr,
+                ctypes.c_float(float(plan.lam32)), plan.salopt_mode, knots_ptr, op_ptr, plan.n_knots,
+                ws.data_ptr(), int(np.diff(frames, axis=1).max()), None, B, C, T,
+                ctypes.c_void_p(_raw_stream(device))), "pcgmix_salopt_mix_warp_f32")
+        else:
+            launch_mix(data, out, frames_ptr, mix_ptr, off_ptr, float(plan.lam32), knots_ptr, op_ptr,
+                       plan.n_knots, B, C, T, rect_ptr)
         # the small buffers are only read by work already enqueued on this stream; torch's
         # caching allocator reuses them in stream order, so dropping the references is safe
         del keep
@@ -303,6 +327,56 @@ def splice_plain(recipe, data: torch.Tensor, labels, frames, step: int,
         if err < 0:
             raise ValueError(_SPLICE_ERRORS.get(err, f"pcgmix_augment_plain_f32 error {err}"))
         _lib.check(err, "pcgmix_augment_plain_f32")
+    return out, mix
+
+
+def _salopt_step(srec, g, data: torch.Tensor, ohe: torch.Tensor, labels, frames, step: int):
+    """One fired saliency-guided step with same-label partners: two library calls around the
+    captured saliency pass.  ``pcgmix_ctx_salopt_begin``: label arg-max kernel (labels to the
+    host, gradient seed to the graph) + boundaries to the device; replay; lambda and knots from
+    numpy's global stream (they do not depend on the labels) while the GPU works;
+    ``pcgmix_ctx_salopt_finish``: labels picked up, partners drawn, one H2D copy, displacement
+    search and fused splice(+warp).  Returns (out, mix_indices)."""
+    mode, alpha, sigma, n_knots = srec
+    B, C, T = data.shape
+    idx = data.device.index
+    lib = _lib.load()
+    ctx = _CTX.get(idx) or step_context(idx)
+    stream = _get_raw_stream(idx) if _get_raw_stream is not None \
+        else torch.cuda.current_stream(data.device).cuda_stream
+    fr_ptr, fr_keep = _frames_ptr(frames, B)
+    lab_ptr = None
+    if labels is not None:
+        labels = np.ascontiguousarray(np.asarray(labels).reshape(-1), dtype=np.int64)
+        if labels.shape[0] != B:
+            raise ValueError("labels/frames do not match the batch size")
+        lab_ptr = labels.ctypes.data
+    err = lib.pcgmix_ctx_salopt_begin(ctx, ohe.data_ptr(), ohe.shape[1], g.seed.data_ptr(), fr_ptr,
+                                      g.fr.data_ptr(), B, T, stream)
+    if err:
+        if err < 0:
+            raise ValueError(_SPLICE_ERRORS.get(err, f"pcgmix_ctx_salopt_begin error {err}"))
+        _lib.check(err, "pcgmix_ctx_salopt_begin")
+    if torch.cuda.current_device() == idx:
+        sal = g.replay(data)
+    else:
+        with torch.cuda.device(data.device):
+            sal = g.replay(data)
+    if alpha > 0.0:
+        np.random.seed(step)                      # global stream, as the reference
+        lam = np.random.beta(alpha, alpha)        # c_float rounds like np.float32 (:903)
+    else:
+        lam = 1.0
+    knots = knots_ptr = None
+    if n_knots:
+        knots = np.random.normal(loc=1.0, scale=sigma, size=(B, n_knots, C))
+        knots_ptr = knots.ctypes.data
+    out = torch.empty_like(data)
+    mix = np.empty(B, dtype=np.int64)
+    _lib.check(lib.pcgmix_ctx_salopt_finish(
+        ctx, data.data_ptr(), out.data_ptr(), sal.data_ptr(), g.fr.data_ptr(), lab_ptr, step,
+        _c_float(lam), mode, knots_ptr, n_knots, mix.ctypes.data, B, C, T, stream),
+        "pcgmix_ctx_salopt_finish")
     return out, mix
 
 
@@ -399,31 +473,40 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
         if not hostprep.gate_fires(method, step):
             return data, target_ohe, [], None
         from . import saliency as _sal
-        if host_labels is None:
-            # the read-back must wait for whatever produced target_ohe, but not for the saliency
-            # graph: the label arg-max kernel goes first (it writes the labels into host-mapped
-            # memory), then the graph; the host picks the labels up when it needs them — by then
-            # the kernel has long finished and the GPU is inside the graph
-            ohe = target_ohe.detach()
-            if ohe.is_cuda and ohe.dtype == torch.int64 and ohe.dim() == 2 and ohe.is_contiguous() \
-                    and ohe.shape[0] == B:
-                lib = _lib.load()
-                idx = data.device.index
-                ctx = _CTX.get(idx) or step_context(idx)
-                stream = _raw_stream(data.device)
-                _lib.check(lib.pcgmix_ctx_labels_begin(ctx, ohe.data_ptr(), ohe.shape[1], B, stream),
-                           "pcgmix_ctx_labels_begin")
-                sal = _sal.get_saliency_maps(args, data.device, data, target_ohe, frames_np, dim=1,
-                                             gauss_k_n=101)
-                labels = np.empty(B, dtype=np.int64)
-                _lib.check(lib.pcgmix_ctx_labels_wait(ctx, labels.ctypes.data, B, stream),
-                           "pcgmix_ctx_labels_wait")
-            else:
-                mark = torch.cuda.Event()
-                mark.record(torch.cuda.current_stream(data.device))
-                sal = _sal.get_saliency_maps(args, data.device, data, target_ohe, frames_np, dim=1,
-                                             gauss_k_n=101)
-                labels = labels_from_ohe(target_ohe, after=mark)
+        # The label arg-max kernel of the step context goes first: it writes the labels into
+        # host-mapped memory (the read-back must wait for whatever produced target_ohe, but not
+        # for the saliency pass) and, on the way, the saliency pass's gradient seed; then the
+        # captured pass; the host picks the labels up when it needs them — by then the kernel has
+        # long finished and the GPU is inside the graph.
+        ohe = target_ohe.detach()
+        g = _sal.step_graph(args, data, ohe.shape[1]) if ohe.dim() == 2 else None
+        ohe_ok = ohe.dim() == 2 and ohe.is_cuda and ohe.dtype == torch.int64 and ohe.is_contiguous() \
+            and ohe.shape[0] == B
+        srec = hostprep.salopt_recipe(method)
+        if g is not None and ohe_ok and srec is not None:
+            out, mix = _salopt_step(srec, g, data, ohe, host_labels, frames, step)
+            return out, target_ohe, mix, None
+        if g is not None and ohe_ok:
+            lib = _lib.load()
+            idx = data.device.index
+            ctx = _CTX.get(idx) or step_context(idx)
+            stream = _raw_stream(data.device)
+            _lib.check(lib.pcgmix_ctx_labels_begin(ctx, ohe.data_ptr(), ohe.shape[1], B,
+                                                   g.seed.data_ptr(), stream), "pcgmix_ctx_labels_begin")
+            with torch.cuda.device(data.device):
+                sal = g.run(data, frames_np, keep=False)         # consumed below, in this call
+            if host_labels is None:
+                def labels():           # asked for by make_plan after its numpy draws
+                    out = np.empty(B, dtype=np.int64)
+                    _lib.check(lib.pcgmix_ctx_labels_wait(ctx, out.ctypes.data, B, stream),
+                               "pcgmix_ctx_labels_wait")
+                    return out
+        elif host_labels is None:
+            mark = torch.cuda.Event()
+            mark.record(torch.cuda.current_stream(data.device))
+            sal = _sal.get_saliency_maps(args, data.device, data, target_ohe, frames_np, dim=1,
+                                         gauss_k_n=101)
+            labels = labels_from_ohe(target_ohe, after=mark)
         else:
             sal = _sal.get_saliency_maps(args, data.device, data, target_ohe, frames_np, dim=1,
                                          gauss_k_n=101)

@@ -86,6 +86,40 @@ __global__ __launch_bounds__(kTailRows* kHeadO * 4) void potes_tail_fwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------ tail, saliency
+// Frozen model in eval mode, gradient of a class score w.r.t. the input (saliency.py:52-61): the
+// logits themselves are not needed, only dz = (z > 0) * (seed W2) with seed = d score / d logits
+// (one-hot of the label).  One kernel instead of potes_tail_fwd_kernel + potes_tail_bwd_kernel;
+// same summation order of the partials as the forward tail, same fmaf chain over the classes as
+// the backward tail.
+__global__ __launch_bounds__(kTailRows* kHeadO * 4) void potes_tail_saliency_kernel(
+    const float* __restrict__ partial, int KS, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ seed, float* __restrict__ dz, int B,
+    int C) {
+  const int t = threadIdx.x, q = t & 3, e = t >> 2;            // e = r * kHeadO + o
+  const int r = e / kHeadO, o = e - r * kHeadO;
+  const int row = blockIdx.x * kTailRows + r;
+  const size_t i = (size_t)(row < B ? row : 0) * kHeadO + o;
+  const size_t plane = (size_t)B * kHeadO;
+  float v = 0.f;
+  int ks = q;
+  for (; ks + 12 < KS; ks += 16) {
+    const float t0 = partial[(size_t)ks * plane + i], t1 = partial[(size_t)(ks + 4) * plane + i],
+                t2 = partial[(size_t)(ks + 8) * plane + i], t3 = partial[(size_t)(ks + 12) * plane + i];
+    v += t0; v += t1; v += t2; v += t3;
+  }
+  for (; ks < KS; ks += 4) v += partial[(size_t)ks * plane + i];
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  if (row < B && q == 0) {
+    v += b1 ? b1[o] : 0.f;
+    const float fac = v > 0.f ? 1.f : 0.f;
+    float sacc = 0.f;
+    for (int c = 0; c < C; ++c) sacc = fmaf(seed[(size_t)row * C + c], w2[c * kHeadO + o], sacc);
+    dz[i] = sacc * fac;
+  }
+}
+
 // ------------------------------------------------------------------------------ tail, backward
 // Block 0 (the others only zero dW1's buffer for potes_head_bwd_kernel).  Thread (g, o): rows g, g+48, ... of column o.  dz = (z > 0) * m2 * (dlogits W2);
 // dW2[c][o] = sum_b dlogits[b][c] h[b][o]; db1[o] = sum_b dz[b][o]; db2[c] = sum_b dlogits[b][c].
@@ -544,6 +578,26 @@ extern "C" int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, c
     hipLaunchKernelGGL((potes_head_bwd_kernel<false, true>), grid, block, 0, s, dz, x, mask1, 1.0f, 0,
                        8, w1, dw1, dx, B, K, nullptr, nullptr, nullptr, 0);
   }
+  return (int)hipGetLastError();
+}
+
+extern "C" int pcgmix_potes_head_saliency_f32(const float* x, const float* w1, const float* b1,
+                                              const float* w2, const float* seed, float* partial,
+                                              float* dz, float* dx, int B, int K, int C,
+                                              pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!x || !w1 || !w2 || !seed || !partial || !dz || !dx || B <= 0 || K <= 0 || (K & 3) || C <= 0 ||
+      C > kHeadMaxC || (reinterpret_cast<uintptr_t>(dz) & 15))
+    return hipErrorInvalidValue;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const hipError_t e = launch_skinny_partial(x, w1, partial, B, K, kHeadO, s, nullptr, 1.0f, 0, 8);
+  if (e != hipSuccess) return (int)e;
+  const int KS = pcgmix_skinny_linear_splits(B, K);
+  hipLaunchKernelGGL(potes_tail_saliency_kernel, dim3((unsigned)((B + kTailRows - 1) / kTailRows)),
+                     dim3(kTailRows * kHeadO * 4), 0, s, partial, KS, b1, w2, seed, dz, B, C);
+  const dim3 grid((unsigned)((K + kHbCols - 1) / kHbCols), kHbSplit), block(kHbWaves * 64);
+  hipLaunchKernelGGL((potes_head_bwd_kernel<false, false>), grid, block, 0, s, dz, x, nullptr, 1.0f, 0,
+                     8, w1, nullptr, dx, B, K, nullptr, nullptr, nullptr, 0);
   return (int)hipGetLastError();
 }
 

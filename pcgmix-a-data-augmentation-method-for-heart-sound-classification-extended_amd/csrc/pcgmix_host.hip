@@ -407,9 +407,12 @@ struct Slot {
 // Class labels from a one-hot (B, K) int64 matrix: first maximum per row (torch.max / np.argmax
 // semantics, augmentations.py:501), written to host-mapped memory, then a system-scope release
 // of `token` into the flag word the host spins on.  One block: B is a few hundred.
+// seed (device, may be nullptr): float (B, K), 1 at the row's label and 0 elsewhere — the
+// gradient seed of the saliency model's class score (saliency.py:52-61), for free.
 __global__ __launch_bounds__(256) void label_argmax_kernel(const int64_t* __restrict__ ohe, int K,
                                                            int B, int32_t* __restrict__ lab,
-                                                           uint32_t* flag, uint32_t token) {
+                                                           uint32_t* flag, uint32_t token,
+                                                           float* __restrict__ seed) {
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     const int64_t* row = ohe + (size_t)b * K;
     int best = 0;
@@ -419,6 +422,8 @@ __global__ __launch_bounds__(256) void label_argmax_kernel(const int64_t* __rest
       if (v > bv) { bv = v; best = c; }
     }
     lab[b] = best;
+    if (seed)
+      for (int c = 0; c < K; ++c) seed[(size_t)b * K + c] = c == best ? 1.f : 0.f;
   }
   __threadfence_system();
   __syncthreads();
@@ -445,6 +450,9 @@ struct pcgmix_ctx {
   std::vector<int> gid;
   std::vector<char> payload;       // pcgmix_ctx_set_payload: rides with the next index block
   void* payload_dst = nullptr;
+  void* ws = nullptr;              // displacement-search workspace of the saliency-guided step
+  size_t ws_cap = 0;
+  int sal_B = 0, sal_max_len = 0;  // what pcgmix_ctx_salopt_begin saw
 };
 
 extern "C" int pcgmix_ctx_create(int device, pcgmix_ctx** out) {
@@ -481,6 +489,7 @@ extern "C" void pcgmix_ctx_destroy(pcgmix_ctx* c) {
   }
   if (c->lab) (void)hipHostFree(c->lab);
   if (c->flag) (void)hipHostFree(c->flag);
+  if (c->ws) (void)hipFree(c->ws);
   for (auto& kv : c->ops) (void)hipFree(kv.second);
   ::operator delete(c->seeded);
   (void)hipSetDevice(prev);
@@ -546,9 +555,83 @@ hipError_t spline_op_device(pcgmix_ctx* c, int T, int n_knots, const double** ou
 
 namespace {
 
+// Boundaries (int64 (B,5), host) validated against the signal length and packed as int32.
+// Returns 0, -1 (negative / decreasing) or -2 (cycle end beyond T); *max_len = longest state.
+int pack_frames(const int64_t* frames, int B, int T, int32_t* st, int* max_len) {
+  int bad = 0;
+  int64_t longest = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t* r = frames + (size_t)b * 5;
+    if (r[0] < 0) bad = bad ? bad : -1;
+    for (int k = 0; k < 4; ++k) {
+      if (r[k + 1] < r[k]) bad = bad ? bad : -1;
+      if (r[k + 1] - r[k] > longest) longest = r[k + 1] - r[k];
+    }
+    if (r[4] > T) bad = bad ? bad : -2;
+    for (int k = 0; k < 5; ++k) st[b * 5 + k] = (int32_t)r[k];
+  }
+  if (max_len) *max_len = (int)(longest > T ? T : longest);
+  return bad;
+}
+
+// Groups of equal label in order of first appearance (augmentations.py:500-510), each permuted by
+// a fresh Random(step).sample: one initialisation (c->seeded), state copied per group.  Scratch
+// lives in the context (no allocation per step): gid[b] = group of sample b, members of group g =
+// the samples b with gid[b] == g in ascending order.
+void draw_partners(pcgmix_ctx* c, const int64_t* labels, int B, int64_t* mix_out, int32_t* mixp) {
+  c->keys.clear();
+  c->gid.resize((size_t)B);
+  c->pool.resize((size_t)B);
+  c->idx.resize((size_t)B);
+  for (int b = 0; b < B; ++b) {
+    size_t g = 0;
+    while (g < c->keys.size() && c->keys[g] != labels[b]) ++g;
+    if (g == c->keys.size()) c->keys.push_back(labels[b]);
+    c->gid[(size_t)b] = (int)g;
+  }
+  for (size_t g = 0; g < c->keys.size(); ++g) {
+    size_t n = 0;
+    for (int b = 0; b < B; ++b)
+      if (c->gid[(size_t)b] == (int)g) c->idx[n++] = b;
+    PyRandom rng = *c->seeded;
+    std::memcpy(c->pool.data(), c->idx.data(), n * sizeof(int64_t));
+    for (size_t i = 0; i < n; ++i) {                 // sample(population, k = n): pool branch
+      const uint64_t j = rng.randbelow((uint64_t)(n - i));
+      mix_out[c->idx[i]] = c->pool[j];
+      mixp[c->idx[i]] = (int32_t)c->pool[j];
+      c->pool[j] = c->pool[n - i - 1];
+    }
+  }
+}
+
+// An event per GROUP of kSlotGroup slots: recorded behind the group's last enqueued work, waited
+// for before the group's first reuse (one stream-order point covers all four: fewer API calls).
+hipError_t slot_commit(pcgmix_ctx* c, int my_slot, hipStream_t s) {
+  if (my_slot % kSlotGroup == kSlotGroup - 1) {
+    const hipError_t e = hipEventRecord(c->slot[my_slot].ev, s);
+    if (e != hipSuccess) return e;
+    c->slot[my_slot].busy = true;
+  }
+  c->next = (my_slot + 1) % kSlots;
+  return hipSuccess;
+}
+
+struct DeviceGuard {      // make the context's device current for the call
+  int cur = 0, dev = 0;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) : dev(device) {
+    err = hipGetDevice(&cur);
+    if (err == hipSuccess && cur != dev) err = hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    if (cur != dev) (void)hipSetDevice(cur);
+  }
+};
+
 // Enqueue the label arg-max for a (B, K) one-hot matrix on `s`; the labels land in c->lab and the
 // flag word takes the returned token.
-hipError_t labels_begin(pcgmix_ctx* c, const int64_t* ohe_dev, int K, int B, hipStream_t s) {
+hipError_t labels_begin(pcgmix_ctx* c, const int64_t* ohe_dev, int K, int B, hipStream_t s,
+                        float* seed = nullptr) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
     return hipErrorStreamCaptureUnsupported;     // a host wait cannot be captured
@@ -566,7 +649,7 @@ hipError_t labels_begin(pcgmix_ctx* c, const int64_t* ohe_dev, int K, int B, hip
   ++c->token;
   if (c->token == 0) c->token = 1;
   hipLaunchKernelGGL(label_argmax_kernel, dim3(1), dim3(256), 0, s, ohe_dev, K, B, c->lab, c->flag,
-                     c->token);
+                     c->token, seed);
   return hipGetLastError();
 }
 
@@ -593,13 +676,13 @@ hipError_t labels_wait(pcgmix_ctx* c, hipStream_t s) {
 // between (the saliency-guided step enqueues the frozen model's graph): begin = the arg-max kernel
 // on `stream`; wait = the spin, then int64 class labels in `labels_out` (host, B).
 extern "C" int pcgmix_ctx_labels_begin(pcgmix_ctx* c, const int64_t* target_ohe_dev, int num_classes,
-                                       int B, pcgmix_stream_t stream) {
+                                       int B, float* seed_out, pcgmix_stream_t stream) {
   if (!c || !target_ohe_dev || num_classes <= 0 || B <= 0) return hipErrorInvalidValue;
   int cur = 0;
   hipError_t e = hipGetDevice(&cur);
   if (e != hipSuccess) return (int)e;
   if (cur != c->device && (e = hipSetDevice(c->device)) != hipSuccess) return (int)e;
-  e = labels_begin(c, target_ohe_dev, num_classes, B, reinterpret_cast<hipStream_t>(stream));
+  e = labels_begin(c, target_ohe_dev, num_classes, B, reinterpret_cast<hipStream_t>(stream), seed_out);
   if (cur != c->device) (void)hipSetDevice(cur);
   return (int)e;
 }
@@ -701,15 +784,7 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   if ((e = slot_reserve(c, my_slot, nbytes)) != hipSuccess) return (int)e;
   lap(1);
   int32_t* st = reinterpret_cast<int32_t*>(sl.pinned);
-  int bad = 0;
-  for (int b = 0; b < B; ++b) {
-    const int64_t* r = frames + (size_t)b * 5;
-    if (r[0] < 0) bad = bad ? bad : -1;
-    for (int k = 0; k < 4; ++k)
-      if (r[k + 1] < r[k]) bad = bad ? bad : -1;
-    if (r[4] > T) bad = bad ? bad : -2;
-    for (int k = 0; k < 5; ++k) st[b * 5 + k] = (int32_t)r[k];
-  }
+  const int bad = pack_frames(frames, B, T, st, nullptr);
   const double* op_dev = nullptr;
   const double* knots_dev = nullptr;
   if (knots) {
@@ -738,34 +813,8 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   lap(3);
   if (bad) return bad;                       // malformed boundaries: nothing else is enqueued
 
-  // 4. groups of equal label in order of first appearance (augmentations.py:500-510), each
-  //    permuted by a fresh Random(step).sample: one initialisation, state copied per group.
-  //    Scratch lives in the context (no allocation per step): gid[b] = group of sample b,
-  //    members of group g = the samples b with gid[b] == g in ascending order.
-  c->keys.clear();
-  c->gid.resize((size_t)B);
-  c->pool.resize((size_t)B);
-  c->idx.resize((size_t)B);
-  for (int b = 0; b < B; ++b) {
-    size_t g = 0;
-    while (g < c->keys.size() && c->keys[g] != labels[b]) ++g;
-    if (g == c->keys.size()) c->keys.push_back(labels[b]);
-    c->gid[(size_t)b] = (int)g;
-  }
-  int32_t* mixp = st + (size_t)B * 5;
-  for (size_t g = 0; g < c->keys.size(); ++g) {
-    size_t n = 0;
-    for (int b = 0; b < B; ++b)
-      if (c->gid[(size_t)b] == (int)g) c->idx[n++] = b;
-    PyRandom rng = *c->seeded;
-    std::memcpy(c->pool.data(), c->idx.data(), n * sizeof(int64_t));
-    for (size_t i = 0; i < n; ++i) {                 // sample(population, k = n): pool branch
-      const uint64_t j = rng.randbelow((uint64_t)(n - i));
-      mix_out[c->idx[i]] = c->pool[j];
-      mixp[c->idx[i]] = (int32_t)c->pool[j];
-      c->pool[j] = c->pool[n - i - 1];
-    }
-  }
+  // 4. partners: groups of equal label, each permuted by a fresh Random(step).sample
+  draw_partners(c, labels, B, mix_out, st + (size_t)B * 5);
   lap(4);
   // 5. one H2D copy, the launch, the slot's event behind it
   if ((e = hipMemcpyAsync(sl.dev, sl.pinned, nbytes, hipMemcpyHostToDevice, s)) != hipSuccess)
@@ -780,16 +829,107 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   c->payload.clear();
   c->payload_dst = nullptr;
   lap(6);
-  // An event per GROUP of kSlotGroup slots: recorded behind the group's last launch, waited for
-  // before the group's first reuse (one stream-order point covers all four: fewer API calls).
-  if (my_slot % kSlotGroup == kSlotGroup - 1) {
-    if ((e = hipEventRecord(sl.ev, s)) != hipSuccess) return (int)e;
-    sl.busy = true;
-  }
-  c->next = (my_slot + 1) % kSlots;
+  if ((e = slot_commit(c, my_slot, s)) != hipSuccess) return (int)e;
   lap(7);
   ++c->calls;
   return hipSuccess;
+}
+
+// ---- the saliency-guided step in two calls, with the caller's saliency pass in between ----------
+// begin: the label arg-max kernel (labels -> host-mapped memory, float one-hot -> seed_out: the
+// saliency pass's gradient seed), the boundaries validated, packed and sent to frames_dst_dev
+// (what the saliency post-processing, the search and the splice read).
+extern "C" int pcgmix_ctx_salopt_begin(pcgmix_ctx* c, const int64_t* target_ohe_dev, int num_classes,
+                                       float* seed_out, const int64_t* frames,
+                                       int32_t* frames_dst_dev, int B, int T,
+                                       pcgmix_stream_t stream) {
+  if (!c || !frames || !frames_dst_dev || B <= 0 || T <= 0 || (target_ohe_dev && num_classes <= 0))
+    return hipErrorInvalidValue;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DeviceGuard guard(c->device);
+  hipError_t e = guard.err;
+  if (e != hipSuccess) return (int)e;
+  if (target_ohe_dev && (e = labels_begin(c, target_ohe_dev, num_classes, B, s, seed_out)) != hipSuccess)
+    return (int)e;
+  const int my_slot = c->next;
+  if ((e = slot_reserve(c, my_slot, (size_t)B * 20)) != hipSuccess) return (int)e;
+  Slot& sl = c->slot[my_slot];
+  int max_len = 0;
+  const int bad = pack_frames(frames, B, T, reinterpret_cast<int32_t*>(sl.pinned), &max_len);
+  if (bad) return bad;
+  if ((e = hipMemcpyAsync(frames_dst_dev, sl.pinned, (size_t)B * 20, hipMemcpyHostToDevice, s)) !=
+      hipSuccess)
+    return (int)e;
+  c->sal_B = B;
+  c->sal_max_len = max_len;
+  return (int)slot_commit(c, my_slot, s);
+}
+
+// finish: labels picked up (or handed over), same-label partners drawn, [mix | knots] sent in one
+// copy, displacement search and fused splice(+warp) enqueued (pcgmix_salopt_mix_warp_f32's pair
+// of kernels; the search workspace is the context's).  frames_dev = begin's frames_dst_dev.
+extern "C" int pcgmix_ctx_salopt_finish(pcgmix_ctx* c, const float* x, float* y, const float* sal,
+                                        const int32_t* frames_dev, const int64_t* labels_host,
+                                        uint64_t step, float lam, int mode, const double* knots,
+                                        int n_knots, int64_t* mix_out, int B, int C, int T,
+                                        pcgmix_stream_t stream) {
+  if (!c || !x || !y || !sal || !frames_dev || !mix_out || B <= 0 || C <= 0 || T <= 0 ||
+      (knots && n_knots < 2) || (mode != 0 && mode != 1) || (!labels_host && (size_t)B > c->lab_cap))
+    return hipErrorInvalidValue;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DeviceGuard guard(c->device);
+  hipError_t e = guard.err;
+  if (e != hipSuccess) return (int)e;
+  // slot: [partners int32 B | pad to 16 bytes | knots float64].  The partners go down in a small
+  // hipMemcpyAsync (blit kernel); the knots (49 KB at bs 256: SDMA territory, ~25 us of stream
+  // stall) are fetched from the pinned slot by an idle block of the search kernel instead.
+  const size_t n_mix_pad = ((size_t)B + 3) & ~(size_t)3;
+  const size_t nk = knots ? (((size_t)B * n_knots * C + 1) & ~(size_t)1) : 0;   // whole 16-byte words
+  const size_t nbytes = n_mix_pad * 4 + nk * sizeof(double);
+  const int my_slot = c->next;
+  if ((e = slot_reserve(c, my_slot, nbytes)) != hipSuccess) return (int)e;
+  Slot& sl = c->slot[my_slot];
+  const double* op_dev = nullptr;
+  const double* knots_dev = nullptr;
+  if (knots) {
+    if ((e = spline_op_device(c, T, n_knots, &op_dev)) != hipSuccess) return (int)e;
+    std::memcpy(sl.pinned + n_mix_pad * 4, knots, (size_t)B * n_knots * C * sizeof(double));
+    knots_dev = reinterpret_cast<const double*>(sl.dev + n_mix_pad * 4);
+  }
+  const size_t ws_bytes = (size_t)pcgmix_salopt_workspace_bytes(B);
+  if (c->ws_cap < ws_bytes) {
+    if (c->ws) (void)hipFree(c->ws);   // synchronises: nothing in flight still reads it afterwards
+    c->ws = nullptr;
+    c->ws_cap = 0;
+    if ((e = hipMalloc(&c->ws, ws_bytes)) != hipSuccess) return (int)e;
+    c->ws_cap = ws_bytes;
+  }
+  if (c->gate_step != step) {
+    new (c->seeded) PyRandom(step);
+    c->gate_step = step;
+  }
+  std::vector<int64_t> lab64;
+  const int64_t* labels = labels_host;
+  if (!labels) {
+    if ((e = labels_wait(c, s)) != hipSuccess) return (int)e;
+    lab64.resize((size_t)B);
+    for (int b = 0; b < B; ++b) lab64[(size_t)b] = c->lab[b];
+    labels = lab64.data();
+  }
+  draw_partners(c, labels, B, mix_out, reinterpret_cast<int32_t*>(sl.pinned));
+  if ((e = hipMemcpyAsync(sl.dev, sl.pinned, n_mix_pad * 4, hipMemcpyHostToDevice, s)) != hipSuccess)
+    return (int)e;
+  const int32_t* mix_dev = reinterpret_cast<const int32_t*>(sl.dev);
+  int err = pcgmix::launch_salopt_search(sal, frames_dev, mix_dev, lam, mode, nullptr, c->ws,
+                                         c->sal_B == B ? c->sal_max_len : 0, B, T, s,
+                                         sl.pinned + n_mix_pad * 4, sl.dev + n_mix_pad * 4,
+                                         (int)(nk * sizeof(double) / 16));
+  if (err) return err;
+  err = pcgmix::launch_mix_warp(x, y, frames_dev, mix_dev, nullptr, lam, knots_dev, op_dev,
+                                knots ? n_knots : 0, nullptr, B, C, T, s, nullptr, nullptr, 0,
+                                static_cast<const float2*>(c->ws));
+  if (err) return err;
+  return (int)slot_commit(c, my_slot, s);
 }
 
 // Diagnostic: mean host nanoseconds per call spent in the 8 phases of pcgmix_augment_plain_f32

@@ -29,10 +29,24 @@ hipError_t launch_skinny_partial(const float* h, const float* W, float* partial,
 
 // pcgmix_mix.hip: pcgmix_mix_warp_f32 plus an optional payload of pay_n16 16-byte words that
 // block (0,0,0) copies from pay_src to pay_dst (both 16-byte aligned device addresses).
+// disp_part != nullptr: the per-state offsets are not read from `off` but reduced by every block
+// from the displacement search's per-block results (kDispSplit float2 {value, displacement bits}
+// per (sample, state); pcgmix_saliency.hip) — the search's own finalize launch is then not needed.
+constexpr int kDispSplit = 4;
 int launch_mix_warp(const float* x, float* y, const int32_t* frames, const int32_t* mix_idx,
                     const int32_t* off, float lam, const double* knots, const double* spline_op,
                     int n_knots, const int32_t* zero_rect, int B, int C, int T, hipStream_t s,
-                    const void* pay_src, void* pay_dst, int pay_n16);
+                    const void* pay_src, void* pay_dst, int pay_n16,
+                    const float2* disp_part = nullptr);
+
+// pcgmix_saliency.hip: the displacement search of pcgmix_salopt_disp_f32; disp == nullptr leaves
+// the per-block results in `workspace` for launch_mix_warp's disp_part.
+// pay_*: pay_n16 16-byte words that one otherwise idle block copies from pay_src (device-readable
+// host memory) to pay_dst while the search runs.
+int launch_salopt_search(const float* sal, const int32_t* frames, const int32_t* mix_idx, float lam,
+                         int mode, int32_t* disp, void* workspace, int max_len, int B, int T,
+                         hipStream_t s, const void* pay_src = nullptr, void* pay_dst = nullptr,
+                         int pay_n16 = 0);
 
 }  // namespace pcgmix
 #endif

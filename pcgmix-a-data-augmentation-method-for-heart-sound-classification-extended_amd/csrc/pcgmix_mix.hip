@@ -37,7 +37,7 @@ struct StateMap {
 // Boundaries of sample b and its partner -> blended ranges.  All inputs are block-uniform.
 __device__ __forceinline__ StateMap make_state_map(const int32_t* __restrict__ frames,
                                                    const int32_t* __restrict__ off, int b, int m,
-                                                   int T) {
+                                                   int T, const float2* __restrict__ part = nullptr) {
   StateMap sm;
   int f1[5], f2[5];
 #pragma unroll
@@ -52,6 +52,20 @@ __device__ __forceinline__ StateMap make_state_map(const int32_t* __restrict__ f
     int gap = len2 - len1;
     int agap = gap < 0 ? -gap : gap;
     int o = off ? off[b * 4 + k] : 0;
+    if (part) {  // salopt_finalize_kernel's rule: greatest value, smallest displacement on ties
+      float bv = -INFINITY;
+      int bd = 0x7fffffff;
+#pragma unroll
+      for (int z = 0; z < kDispSplit; ++z) {
+        const float2 p = part[((size_t)b * 4 + k) * kDispSplit + z];
+        const int dd = __float_as_int(p.y);
+        if (p.x > bv || (p.x == bv && dd < bd)) {
+          bv = p.x;
+          bd = dd;
+        }
+      }
+      o = bd == 0x7fffffff ? 0 : bd;
+    }
     o = o < 0 ? 0 : (o > agap ? agap : o);
     int a = f1[k] + (gap < 0 ? o : 0);
     int s = f2[k] + (gap > 0 ? o : 0);
@@ -140,7 +154,8 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
     const int32_t* __restrict__ mix_idx, const int32_t* __restrict__ off, float lam, float oml,
     const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots,
     const int32_t* __restrict__ zero_rect, int B, int C, int T, int epb,
-    const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst, int pay_n16) {
+    const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst, int pay_n16,
+    const float2* __restrict__ disp_part) {
   extern __shared__ __align__(16) double lds[];  // spline records per channel, then thresholds
 
   // Step payload (pcgmix_ctx_set_payload): a few KB that travelled with the index block and
@@ -152,7 +167,7 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
   if (b >= B) return;  // block-uniform
   int m = mix_idx[b];
   m = (m < 0 || m >= B) ? b : m;  // memory safety; validated on the host as well
-  const StateMap sm = make_state_map(frames, off, b, m, T);
+  const StateMap sm = make_state_map(frames, off, b, m, T, disp_part);
   // optional zeroed rectangle (rows = index along C, columns = index along T), block-uniform
   int zr0 = 0, zr1 = 0, zc0 = 0, zc1 = 0;
   if (zero_rect) {
@@ -326,7 +341,7 @@ int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, con
                             const int32_t* off, float lam, const double* knots,
                             const double* spline_op, int n_knots, const int32_t* zero_rect, int B,
                             int C, int T, hipStream_t s, const void* pay_src_v, void* pay_dst_v,
-                            int pay_n16) {
+                            int pay_n16, const float2* disp_part) {
   using namespace pcgmix;
   const uint4* pay_src = static_cast<const uint4*>(pay_src_v);
   uint4* pay_dst = static_cast<uint4*>(pay_dst_v);
@@ -361,7 +376,7 @@ int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, con
 #define PCGMIX_LAUNCH(V, W, UU)                                                              \
   hipLaunchKernelGGL((mix_warp_kernel<V, W, UU>), grid, block, lds, s, x, y, frames, mix_idx, \
                      off, lam, oml, knots, spline_op, n_knots, zero_rect, B, C, T, epb, pay_src,  \
-                     pay_dst, pay_n16)
+                     pay_dst, pay_n16, disp_part)
 #define PCGMIX_LAUNCH_U(W)                                \
   do {                                                    \
     if (U == 4) PCGMIX_LAUNCH(4, W, 4);                   \

@@ -256,14 +256,22 @@ __device__ __forceinline__ float pw_sum(F elem, int n) {
 // the greatest value, smallest displacement on ties — the first strict maximum of the reference's
 // ascending scan (augmentations.py:76).
 // LDS: lng[nL] (the longer state's saliency), sht[nS] (the shorter one's).
-constexpr int kDispSplit = 4;
+// (kDispSplit = 4 blocks per pair: pcgmix_kernels.h — the splice kernel can read `part` itself.)
 
 template <int MODE>  // 0: envelope (max), 1: lambda-weighted sum
 __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
     const float* __restrict__ sal, const int32_t* __restrict__ frames,
     const int32_t* __restrict__ mix_idx, float lam, float oml, float2* __restrict__ part, int B,
-    int T, int max_len) {
+    int T, int max_len, const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst,
+    int pay_n16) {
   extern __shared__ __align__(16) float smem[];
+  // Side job of the LAST block in launch order (shortest state, last candidate slice: it almost
+  // never has candidates of its own): copy pay_n16 16-byte words from pay_src — host memory the
+  // device can read, e.g. the warp knots in the step context's pinned slot — to pay_dst.  The
+  // splice kernel launched behind this one reads them from device memory; a hipMemcpyAsync of
+  // this size (49 KB at bs 256) takes the SDMA path and stalls the stream for ~25 us.
+  if (pay_n16 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 3 && blockIdx.z == gridDim.z - 1)
+    for (int i = threadIdx.x; i < pay_n16; i += kDispThreads) pay_dst[i] = pay_src[i];
   __shared__ float best_v[kDispThreads / 64];
   __shared__ int best_d[kDispThreads / 64];
   // Sample index fastest, states ordered by expected work (diastole, systole, S1, S2): with the
@@ -408,8 +416,49 @@ extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
                                       const int32_t* mix_idx, float lam, int mode, int32_t* disp,
                                       void* workspace, int max_len, int B, int T,
                                       pcgmix_stream_t stream) {
+  if (!disp) return hipErrorInvalidValue;
+  return pcgmix::launch_salopt_search(sal, frames, mix_idx, lam, mode, disp, workspace, max_len, B, T,
+                                      reinterpret_cast<hipStream_t>(stream));
+}
+
+// The saliency-guided splice in one call: the displacement search, then the fused splice(+warp)
+// kernel, whose blocks reduce the search's per-block results for their own sample themselves —
+// no finalize launch between the two.  disp_out (optional): the displacements as int32 (B,4),
+// written by a finalize launch BEHIND the splice (off the critical path).
+extern "C" int pcgmix_salopt_mix_warp_f32(const float* x, float* y, const float* sal,
+                                          const int32_t* frames, const int32_t* mix_idx, float lam,
+                                          int mode, const double* knots, const double* spline_op,
+                                          int n_knots, void* workspace, int max_len,
+                                          int32_t* disp_out, int B, int C, int T,
+                                          pcgmix_stream_t stream) {
   using namespace pcgmix;
-  if (!sal || !frames || !mix_idx || !disp || !workspace) return hipErrorInvalidValue;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (!x || !y || B < 0) return hipErrorInvalidValue;
+  if (B == 0) return hipSuccess;
+  int err = launch_salopt_search(sal, frames, mix_idx, lam, mode, nullptr, workspace, max_len, B, T, s);
+  if (err) return err;
+  const float2* part = static_cast<const float2*>(workspace);
+  err = launch_mix_warp(x, y, frames, mix_idx, nullptr, lam, knots, spline_op, n_knots, nullptr, B, C,
+                        T, s, nullptr, nullptr, 0, part);
+  if (err || !disp_out) return err;
+  hipLaunchKernelGGL(salopt_finalize_kernel, dim3((unsigned)((B * 4 + 255) / 256)), dim3(256), 0, s,
+                     part, disp_out, B * 4);
+  return (int)hipGetLastError();
+}
+
+// disp == nullptr: the per-block results stay in `workspace` (no finalize launch).
+int pcgmix::launch_salopt_search(const float* sal, const int32_t* frames, const int32_t* mix_idx,
+                                 float lam, int mode, int32_t* disp, void* workspace, int max_len,
+                                 int B, int T, hipStream_t s, const void* pay_src_v, void* pay_dst_v,
+                                 int pay_n16) {
+  using namespace pcgmix;
+  const uint4* pay_src = static_cast<const uint4*>(pay_src_v);
+  uint4* pay_dst = static_cast<uint4*>(pay_dst_v);
+  if (pay_n16 < 0 || (pay_n16 > 0 && (!pay_src || !pay_dst ||
+                                      ((reinterpret_cast<uintptr_t>(pay_src) |
+                                        reinterpret_cast<uintptr_t>(pay_dst)) & 15))))
+    return hipErrorInvalidValue;
+  if (!sal || !frames || !mix_idx || !workspace) return hipErrorInvalidValue;
   if (B < 0 || B > 65535 || T <= 0 || (mode != 0 && mode != 1)) return hipErrorInvalidValue;
   if (reinterpret_cast<uintptr_t>(workspace) & 7) return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
@@ -425,15 +474,15 @@ extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
     return (int)e;
   const float oml = 1.0f - lam;
   dim3 grid((unsigned)B, 4, kDispSplit), block(kDispThreads);
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   float2* part = static_cast<float2*>(workspace);
   if (mode == 0)
     hipLaunchKernelGGL(salopt_disp_kernel<0>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
-                       part, B, T, max_len);
+                       part, B, T, max_len, pay_src, pay_dst, pay_n16);
   else
     hipLaunchKernelGGL(salopt_disp_kernel<1>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
-                       part, B, T, max_len);
-  hipLaunchKernelGGL(salopt_finalize_kernel, dim3((unsigned)((B * 4 + 255) / 256)), dim3(256), 0, s,
-                     part, disp, B * 4);
+                       part, B, T, max_len, pay_src, pay_dst, pay_n16);
+  if (disp)
+    hipLaunchKernelGGL(salopt_finalize_kernel, dim3((unsigned)((B * 4 + 255) / 256)), dim3(256), 0, s,
+                       part, disp, B * 4);
   return (int)hipGetLastError();
 }

@@ -130,6 +130,26 @@ def plain_recipe(method: str, is2d: bool):
     return name, parse_probability(method), parse_alpha(method, name), sigma, knot + 2
 
 
+@functools.lru_cache(maxsize=256)
+def salopt_recipe(method: str):
+    """(mode, alpha, sigma, knots) when ``method`` is a saliency-guided splice with same-label
+    partners — what ``pcgmix_ctx_salopt_begin/_finish`` do around the saliency pass; None otherwise
+    ('(samePCG)', '(sameDataset)', '(mixAll)': the general ``make_plan`` path)."""
+    name = select_method(method, False)
+    if name is None or "(salopt" not in method:
+        return None
+    if any(t in method for t in ("(samePCG)", "(sameDataset)", "(mixAll)")):
+        return None
+    if "(saloptenv" in method:
+        mode = 0
+    elif "(saloptsum" in method:
+        mode = 1
+    else:
+        raise NotImplementedError("only (saloptenv…) and (saloptsum…) exist in the reference")
+    sigma, knot = parse_magwarp(method) if name == "durmixmagwarp" else (0.0, -2)
+    return mode, parse_alpha(method, name), sigma, knot + 2
+
+
 def gate_fires(method: str, step: int) -> bool:
     """Fresh ``Random(step)``; the method runs iff u < p (augmentations.py:869-872).  The draw is
     the library's bit-exact restatement of ``random.Random(step).uniform(0, 1)``."""
@@ -251,13 +271,13 @@ def make_plan(method: str, labels, frames: np.ndarray, wav: Sequence[str], step:
     name = select_method(method, is2d)
     if name is None or not gate_fires(method, step):
         return MixPlan(fired=False, step=step)
-    if callable(labels):
-        labels = labels()
-    labels = np.asarray(labels).reshape(-1)
-    if labels.shape[0] != batch or frames.shape[0] != batch:
+    if frames.shape[0] != batch:
         raise ValueError("labels/frames do not match the batch size")
     plan = MixPlan(fired=True, name=name, step=step)
-    plan.mix = partner_indices(method, labels, wav, step, is2d)
+    # numpy's global stream first (lambda, then the warp knots right behind it): neither depends
+    # on the labels, and python's random.Random (partners, offsets, masks) is a separate stream,
+    # so the order BETWEEN the two streams is free — a callable `labels` that has to wait for the
+    # GPU is asked as late as possible, after the ~0.1 ms of normal draws.
     alpha = 1.0 if is2d else parse_alpha(method, name)                      # augmentations2d.py:411
     if alpha > 0.0:                                                         # augmentations.py:661-663
         np.random.seed(step)            # global stream, as the reference (side effect kept)
@@ -265,6 +285,17 @@ def make_plan(method: str, labels, frames: np.ndarray, wav: Sequence[str], step:
     else:
         plan.lam64 = 1.0
     plan.lam32 = np.float32(plan.lam64)                                     # augmentations.py:903
+    if not is2d and name == "durmixmagwarp":
+        sigma, knot = parse_magwarp(method)
+        plan.n_knots = knot + 2
+        # continues the global stream right after the beta draw (augmentations.py:677)
+        plan.knots = np.random.normal(loc=1.0, scale=sigma, size=(batch, knot + 2, channels))
+    if callable(labels):
+        labels = labels()
+    labels = np.asarray(labels).reshape(-1)
+    if labels.shape[0] != batch:
+        raise ValueError("labels/frames do not match the batch size")
+    plan.mix = partner_indices(method, labels, wav, step, is2d)
     if is2d and name != "durratiomixup":
         plan.zero_rect = mask_rectangles(method, name, frames, step, channels, n_cols)
     if not is2d:
@@ -277,9 +308,4 @@ def make_plan(method: str, labels, frames: np.ndarray, wav: Sequence[str], step:
         elif "(salopt" in method:
             raise NotImplementedError("only (saloptenv…) and (saloptsum…) exist in the reference")
         plan.mix_all = "(mixAll)" in method
-        if name == "durmixmagwarp":
-            sigma, knot = parse_magwarp(method)
-            plan.n_knots = knot + 2
-            # continues the global stream right after the beta draw (augmentations.py:677)
-            plan.knots = np.random.normal(loc=1.0, scale=sigma, size=(batch, knot + 2, channels))
     return plan

@@ -96,17 +96,83 @@ def _baseline_model(args, device, dim: int) -> torch.nn.Module:
     return model
 
 
-def input_gradient(model: torch.nn.Module, data: torch.Tensor, target_ohe: torch.Tensor):
-    """d score[true class] / d input (saliency.py:52-61); model is in eval mode and frozen."""
-    target = target_ohe.max(1, keepdim=True)[1]            # first maximum, as the reference
+def _potes_direct(model: torch.nn.Module, data: torch.Tensor):
+    """The CNN_potes whose input gradient can be written as a fixed chain of HIP launches
+    (eval mode, fused conv stack and head, four band channels, saved-routing kernels), or None."""
+    from . import models
+    m = model.module if isinstance(model, (torch.nn.DataParallel,
+                                           torch.nn.parallel.DistributedDataParallel)) else model
+    if (isinstance(m, models.CNN_potes) and not m.training and data.dim() == 3 and data.shape[1] == 4
+            and data.shape[0] > 0 and data.is_contiguous() and models.PotesStackFunction.use_masks
+            and m._fused_head(data)):
+        return m
+    return None
+
+
+def _potes_input_gradient(m, data: torch.Tensor, seed: torch.Tensor) -> torch.Tensor:
+    """d (sum_b seed_b . logits_b) / d input of a frozen CNN_potes without autograd: conv stack
+    forward saving its ReLU / max-pool routing -> head (split-K product, dz = (z > 0) * (seed W2),
+    dx = dz W1: ``pcgmix_potes_head_saliency_f32``) -> input gradient from the saved routing.
+    Six launches; the logits are never formed (models.py:444-465 forward, autograd backward)."""
+    B, C, T = data.shape
+    lib = _lib.load()
+    dev = data.device
+    c1, c2 = m.cnn1[0][0], m.cnn1[1][0]
+    w1, b1, w2, b2 = (t.detach().contiguous() for t in (c1.weight, c1.bias, c2.weight, c2.bias))
+    W1, W2 = m.dimreduc.weight.detach().contiguous(), m.linear.weight.detach().contiguous()
+    bh = m.dimreduc.bias.detach() if m.dimreduc.bias is not None else None
+    N, P2, K, ncls = B * 4, lib.pcgmix_potes_out_len(T), m.dimreduc.in_features, W2.shape[0]
+    if K != 16 * P2 or seed.shape != (B, ncls) or seed.dtype != torch.float32 or not seed.is_contiguous():
+        raise ValueError("saliency seed / model head do not match the input shape")
+    f32 = dict(dtype=torch.float32, device=dev)
+    u8 = dict(dtype=torch.uint8, device=dev)
+    h2 = torch.empty((N, 4, P2), **f32)
+    m2 = torch.empty(lib.pcgmix_potes_mask_bytes(N, T, 2), **u8)
+    s1 = torch.empty(lib.pcgmix_potes_mask_bytes(N, T, 1), **u8)
+    partial = torch.empty((lib.pcgmix_skinny_linear_splits(B, K), B, 20), **f32)
+    dz, gfeat, gx = torch.empty((B, 20), **f32), torch.empty((B, K), **f32), torch.empty_like(data)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    x = data.detach()
+    _lib.check(lib.pcgmix_potes_stack_fwd_save_f32(
+        x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), h2.data_ptr(),
+        m2.data_ptr(), s1.data_ptr(), N, T, None, 0, None, 0, stream), "pcgmix_potes_stack_fwd_save_f32")
+    _lib.check(lib.pcgmix_potes_head_saliency_f32(
+        h2.data_ptr(), W1.data_ptr(), bh.data_ptr() if bh is not None else None, W2.data_ptr(),
+        seed.data_ptr(), partial.data_ptr(), dz.data_ptr(), gfeat.data_ptr(), B, K, ncls, stream),
+        "pcgmix_potes_head_saliency_f32")
+    _lib.check(lib.pcgmix_potes_stack_input_grad_mask_f32(
+        gfeat.data_ptr(), m2.data_ptr(), s1.data_ptr(), w1.data_ptr(), w2.data_ptr(), gx.data_ptr(),
+        N, T, stream), "pcgmix_potes_stack_input_grad_mask_f32")
+    return gx
+
+
+def input_gradient_seeded(model: torch.nn.Module, data: torch.Tensor, seed: torch.Tensor):
+    """Backward of the model's output seeded with ``seed`` (B, classes), w.r.t. the input."""
+    m = _potes_direct(model, data)
+    if m is not None:
+        return _potes_input_gradient(m, data, seed)
     x = data.detach().requires_grad_(True)                 # shares storage; nothing writes to it
     with torch.enable_grad():
         out = model(x)
-        # d(out[b, target_b])/dx summed over b == backward of `out` seeded with one-hot(target):
-        # spares the gather, its backward scatter and the ones() of the reference formulation
-        seed = torch.zeros_like(out).scatter_(1, target, 1.0)
         (grad,) = torch.autograd.grad(out, x, seed)
     return grad.contiguous()
+
+
+def class_seed(target_ohe: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """one_hot(first maximum of each row) as float32 — d(out[b, target_b])/d out.  Backward of
+    `out` seeded with it == the reference's gather + sum + backward (saliency.py:52-61) without
+    the gather, its backward scatter and the ones()."""
+    target = target_ohe.max(1, keepdim=True)[1]            # first maximum, as the reference
+    if out is None:
+        out = torch.zeros(target_ohe.shape, dtype=torch.float32, device=target_ohe.device)
+    else:
+        out.zero_()
+    return out.scatter_(1, target, 1.0)
+
+
+def input_gradient(model: torch.nn.Module, data: torch.Tensor, target_ohe: torch.Tensor):
+    """d score[true class] / d input (saliency.py:52-61); model is in eval mode and frozen."""
+    return input_gradient_seeded(model, data, class_seed(target_ohe))
 
 
 def saliency_post(grad: torch.Tensor, frames_dev_ptr: int, gauss_k_n: int = 101) -> torch.Tensor:
@@ -125,14 +191,18 @@ def saliency_post(grad: torch.Tensor, frames_dev_ptr: int, gauss_k_n: int = 101)
 class _SaliencyGraph:
     """Forward + input-gradient + post-processing of a FROZEN model for one batch shape, captured
     once in a hipGraph and replayed: the eager chain is ~40 small launches driven by Python
-    autograd (~0.4 ms of host time per step at bs=256) for ~0.2 ms of GPU work."""
+    autograd (~0.4 ms of host time per step at bs=256) for ~0.2 ms of GPU work.
+
+    Static inputs: ``x`` (the batch), ``seed`` (float one-hot of the labels — the label read-back
+    kernel of the step context writes it as a by-product, ``pcgmix_ctx_labels_begin``), ``fr``
+    (int32 boundaries, uploaded straight into place)."""
 
     def __init__(self, model, shape, num_classes, device, gauss_k_n):
         B, C, T = shape
         self.model, self.k = model, gauss_k_n
         self.x = torch.zeros(B, C, T, device=device)
-        self.t = torch.zeros(B, num_classes, dtype=torch.int64, device=device)
-        self.t[:, 0] = 1
+        self.seed = torch.zeros(B, num_classes, device=device)
+        self.seed[:, 0] = 1
         self.fr = torch.zeros(B, 5, dtype=torch.int32, device=device)
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -146,14 +216,49 @@ class _SaliencyGraph:
             self.sal = self._run()
 
     def _run(self):
-        return saliency_post(input_gradient(self.model, self.x, self.t), self.fr.data_ptr(), self.k)
+        return saliency_post(input_gradient_seeded(self.model, self.x, self.seed),
+                             self.fr.data_ptr(), self.k)
 
-    def __call__(self, data, target_ohe, frames_dev):
+    def replay(self, data):
+        """``seed`` and ``fr`` are in place (``pcgmix_ctx_salopt_begin`` on this stream): copy the
+        batch in and replay; returns the graph's static output, valid until the next replay."""
         self.x.copy_(data, non_blocking=True)
-        self.t.copy_(target_ohe, non_blocking=True)
-        self.fr.copy_(frames_dev, non_blocking=True)
         self.graph.replay()
-        return self.sal.clone()
+        return self.sal
+
+    def run(self, data, frames_np, target_ohe=None, keep: bool = True):
+        """``target_ohe`` None: ``seed`` has been written by the caller (on this stream).
+        ``keep`` False: the returned maps are the graph's static output, valid until the next
+        run — for a caller that consumes them right away."""
+        from .augmentations import upload_into
+        self.x.copy_(data, non_blocking=True)
+        if target_ohe is not None:
+            class_seed(target_ohe, self.seed)
+        upload_into(self.fr, frames_np.astype(np.int32))
+        self.graph.replay()
+        return self.sal.clone() if keep else self.sal
+
+
+def step_graph(args, data, num_classes: int, dim: int = 1, gauss_k_n: int = 101,
+               model_sal: Optional[torch.nn.Module] = None) -> Optional[_SaliencyGraph]:
+    """The captured saliency pass for this model and batch shape (captured on first use), or None
+    when graphs are off or the stream is capturing."""
+    if dim != 1:
+        raise NotImplementedError("spectrogram (dim=2) saliency is out of scope")
+    if not data.is_cuda:
+        raise ValueError("data must live on a HIP device")
+    if not USE_GRAPHS or torch.cuda.is_current_stream_capturing():
+        return None
+    model = model_sal or _INJECTED or _baseline_model(args, data.device, dim)
+    key = (id(model), tuple(data.shape), int(num_classes), gauss_k_n, str(data.device))
+    g = _GRAPHS.get(key)
+    if g is None:
+        if len(_GRAPHS) >= 8:
+            _GRAPHS.clear()
+        with torch.cuda.device(data.device):
+            g = _GRAPHS[key] = _SaliencyGraph(model, tuple(data.shape), int(num_classes), data.device,
+                                              gauss_k_n)
+    return g
 
 
 def get_saliency_maps(args, device, data, target_ohe, frames, dim=1, gauss_k_n=101,
@@ -164,20 +269,15 @@ def get_saliency_maps(args, device, data, target_ohe, frames, dim=1, gauss_k_n=1
         raise NotImplementedError("spectrogram (dim=2) saliency is out of scope")
     if not data.is_cuda:
         raise ValueError("data must live on a HIP device")
-    model = model_sal or _INJECTED or _baseline_model(args, data.device, dim)
     frames_np = frames.detach().cpu().numpy() if isinstance(frames, torch.Tensor) else np.asarray(frames)
     with torch.cuda.device(data.device):
+        g = step_graph(args, data, target_ohe.shape[1], dim, gauss_k_n, model_sal) \
+            if target_ohe.dtype == torch.int64 else None
+        if g is not None:
+            return g.run(data, frames_np, target_ohe)
         from .augmentations import upload_array
+        model = model_sal or _INJECTED or _baseline_model(args, data.device, dim)
         fr = upload_array(frames_np.astype(np.int32), data.device)
-        if USE_GRAPHS and target_ohe.dtype == torch.int64 and not torch.cuda.is_current_stream_capturing():
-            key = (id(model), tuple(data.shape), int(target_ohe.shape[1]), gauss_k_n, str(data.device))
-            g = _GRAPHS.get(key)
-            if g is None:
-                if len(_GRAPHS) >= 8:
-                    _GRAPHS.clear()
-                g = _GRAPHS[key] = _SaliencyGraph(model, tuple(data.shape), int(target_ohe.shape[1]),
-                                                  data.device, gauss_k_n)
-            return g(data, target_ohe, fr)
         grad = input_gradient(model, data, target_ohe)
         return saliency_post(grad, fr.data_ptr(), gauss_k_n)
 

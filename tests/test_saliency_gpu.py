@@ -300,3 +300,145 @@ def test_displacements_long_gaps_vs_oracle(mode, device):
                                          float(lam), mode, B, T)
     assert np.array_equal(got.cpu().numpy().astype(np.int64), ref)
     assert ref.max() > 1024 or (np.abs(np.diff(frames, axis=1)[mix] - np.diff(frames, axis=1)).max() > 1024)
+
+
+@pytest.mark.parametrize("B,T", [(8, 2500), (5, 5000)])
+def test_direct_potes_input_gradient_equals_autograd(B, T, device):
+    """The frozen CNN_potes' input gradient as a fixed chain of launches (no autograd, fused
+    tail: dz = (z > 0) * (seed W2) without forming the logits) == the autograd path through
+    PotesStackFunction / PotesHeadFunction, for one-hot and for soft seeds."""
+    torch.manual_seed(B)
+    model = models.CNN_potes_TS(4, 2, "PhysioNet", sig_len=None if T == 2500 else T).to(device).eval()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(B, 4, T, device=device)
+    tgt = torch.nn.functional.one_hot(torch.randint(0, 2, (B,)), 2).to(device)
+    assert saliency._potes_direct(model, x) is model
+    for seed in (saliency.class_seed(tgt), torch.rand(B, 2, device=device)):
+        direct = saliency.input_gradient_seeded(model, x, seed)
+        old = models.PotesStackFunction.use_masks
+        models.PotesStackFunction.use_masks = False          # forces the autograd path
+        try:
+            assert saliency._potes_direct(model, x) is None
+            recompute = saliency.input_gradient_seeded(model, x, seed)
+        finally:
+            models.PotesStackFunction.use_masks = old
+        xa = x.detach().requires_grad_(True)
+        with torch.enable_grad():
+            (auto,) = torch.autograd.grad(model(xa), xa, seed)   # autograd, saved-routing kernels
+        assert torch.equal(direct, auto)
+        scale = float(auto.abs().max())
+        assert float((direct - recompute).abs().max()) <= 1e-5 * scale
+    model.train()                                            # training mode: not the direct chain
+    assert saliency._potes_direct(model, x) is None
+
+
+def test_label_kernel_writes_the_gradient_seed(device):
+    """pcgmix_ctx_labels_begin's by-product: float one-hot of the FIRST maximum of every row."""
+    from pcgmix_amd import _lib
+    lib = _lib.load()
+    B, K = 300, 3
+    rs = np.random.RandomState(0)
+    ohe = np.zeros((B, K), dtype=np.int64)
+    ohe[np.arange(B), rs.randint(0, K, B)] = 1
+    ohe[5] = 0                                               # all equal: first column wins
+    ohe[6] = 1
+    t = torch.from_numpy(ohe).to(device)
+    seed = torch.full((B, K), 7.0, device=device)
+    ctx = augmentations.step_context(device.index)
+    st = torch.cuda.current_stream(device).cuda_stream
+    _lib.check(lib.pcgmix_ctx_labels_begin(ctx, t.data_ptr(), K, B, seed.data_ptr(), st), "begin")
+    labels = np.empty(B, dtype=np.int64)
+    _lib.check(lib.pcgmix_ctx_labels_wait(ctx, labels.ctypes.data, B, st), "wait")
+    assert np.array_equal(labels, ohe.argmax(1))
+    assert torch.equal(seed, saliency.class_seed(t))
+    assert seed[5].tolist() == [1.0, 0.0, 0.0] and seed[6].tolist() == [1.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("mode,warp", [(0, True), (1, False)])
+def test_search_and_splice_in_one_call(mode, warp, device):
+    """pcgmix_salopt_mix_warp_f32 (the splice kernel reduces the search's per-block results
+    itself) == pcgmix_salopt_disp_f32 followed by pcgmix_mix_warp_f32, bit for bit."""
+    from pcgmix_amd import _lib, synthetic
+    lib = _lib.load()
+    B, C, T = 48, 4, 5000
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=2000, seed=21)
+    frames[7] = frames[3]
+    rs = np.random.RandomState(3)
+    sal = rs.rand(B, T).astype(np.float32)
+    sal[np.arange(T)[None, :] >= frames[:, 4:5]] = 0
+    mix = rs.permutation(B)
+    lam = float(np.float32(0.4321))
+    data = torch.from_numpy(x).to(device)
+    sal_d = torch.from_numpy(sal).to(device)
+    fr, mx = dev_i32(frames, device), dev_i32(mix, device)
+    knots = op = None
+    n_knots = 0
+    if warp:
+        n_knots = 6
+        knots = torch.from_numpy(rs.normal(1.0, 0.2, (B, n_knots, C))).to(device)
+        op = augmentations.spline_operator(device, T, n_knots)
+    max_len = int(np.diff(frames, axis=1).max())
+    disp = saliency.optimal_displacements(sal_d, fr.data_ptr(), mx.data_ptr(), lam, mode, B, T,
+                                          max_len=max_len)
+    ref = torch.empty_like(data)
+    augmentations.launch_mix(data, ref, fr.data_ptr(), mx.data_ptr(), disp.data_ptr(), lam,
+                             knots.data_ptr() if warp else None, op.data_ptr() if warp else None,
+                             n_knots, B, C, T)
+    out = torch.empty_like(data)
+    disp2 = torch.full((B, 4), -1, dtype=torch.int32, device=device)
+    ws = torch.empty(lib.pcgmix_salopt_workspace_bytes(B) // 8, dtype=torch.int64, device=device)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    _lib.check(lib.pcgmix_salopt_mix_warp_f32(
+        data.data_ptr(), out.data_ptr(), sal_d.data_ptr(), fr.data_ptr(), mx.data_ptr(),
+        ctypes.c_float(lam), mode, knots.data_ptr() if warp else None, op.data_ptr() if warp else None,
+        n_knots, ws.data_ptr(), max_len, disp2.data_ptr(), B, C, T, st), "salopt_mix")
+    assert torch.equal(disp, disp2)
+    assert int((disp != 0).sum()) > B                        # the search did move things
+    assert torch.equal(out, ref)
+
+
+def test_salopt_fast_path_equals_general_path(device):
+    """The two-call step on the context (pcgmix_ctx_salopt_begin/_finish: seed from the label
+    kernel, knots fetched by the search kernel, no finalize launch) == the general plan path
+    (make_plan + upload_plan + pcgmix_salopt_mix_warp_f32), in strict mode and with the labels
+    handed over; malformed boundaries raise ValueError from either."""
+    from pcgmix_amd import hostprep, synthetic
+    torch.manual_seed(1)
+    saliency.set_saliency_model(models.CNN_potes_TS(4, 2, "PhysioNet", sig_len=5000).to(device))
+    try:
+        x, frames, labels, wav = synthetic.make_batch(40, 4, 5000, sample_rate=2000, seed=31)
+        data = torch.from_numpy(x).to(device)
+        tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)
+        for method in ("(saloptenv)durmixmagwarp(0.2,4)", "(saloptsum)durratiomixup"):
+            a = Args(method)
+            assert hostprep.salopt_recipe(method) is not None
+            fast = augmentations.augment(a, data, tgt, frames, wav, StepCounter(3), None, device, "")
+            fast_h = augmentations.augment(a, data, tgt, frames, wav, StepCounter(3), None, device, "",
+                                           host_labels=labels)
+            real = hostprep.salopt_recipe
+            hostprep.salopt_recipe = lambda m: None            # forces the general path
+            try:
+                slow = augmentations.augment(a, data, tgt, frames, wav, StepCounter(3), None, device, "")
+            finally:
+                hostprep.salopt_recipe = real
+            for got in (fast, fast_h):
+                assert np.array_equal(got[2], slow[2]) and torch.equal(got[0], slow[0])
+                assert got[1] is tgt and got[3] is None
+            assert not torch.equal(fast[0], data)
+        assert hostprep.salopt_recipe("(samePCG)(saloptenv)durratiomixup") is None
+        bad = frames.copy()
+        bad[2, 4] = 5001
+        with pytest.raises(ValueError):
+            augmentations.augment(Args("(saloptenv)durratiomixup"), data, tgt, bad, wav, StepCounter(3),
+                                  None, device, "")
+        bad = frames.copy()
+        bad[1, 2] = bad[1, 1] - 1
+        with pytest.raises(ValueError):
+            augmentations.augment(Args("(saloptenv)durratiomixup"), data, tgt, bad, wav, StepCounter(3),
+                                  None, device, "")
+        ok = augmentations.augment(Args("(saloptenv)durratiomixup"), data, tgt, frames, wav, StepCounter(3),
+                                   None, device, "")          # the context is still usable afterwards
+        assert ok[0].shape == data.shape
+    finally:
+        saliency.set_saliency_model(None)
