@@ -510,6 +510,14 @@ long long pcgmix_splice_staging_bytes(int B, int C, int n_knots);
  * pcgmix_ctx_gate: random.Random(step).uniform(0, 1) (augmentations.py:869-870, 936-937); the
  * seeded generator is kept, so the step call for the same `step` does not seed a second time.
  */
+/* Host-to-device copy as ONE kernel launch: src_pinned = pinned host memory (hipHostMalloc, torch
+ * pin_memory: device-readable at the same address), dst_dev = device memory, both 16-byte aligned;
+ * nbytes is rounded up to whole 16-byte words, which both buffers must hold.  For per-step index
+ * data above 16 KB (e.g. the magnitude-warp knots, augmentations.py:677: 49 KB at bs 256):
+ * hipMemcpyAsync switches from a blit kernel to the SDMA engine there, which on MI355X stalls the
+ * stream for ~25 us per copy.  The step context does this internally.          */
+int pcgmix_fetch_h2d(const void* src_pinned, void* dst_dev, size_t nbytes, pcgmix_stream_t stream);
+
 typedef struct pcgmix_ctx pcgmix_ctx;
 int pcgmix_ctx_create(int device, pcgmix_ctx** out);
 void pcgmix_ctx_destroy(pcgmix_ctx* ctx);

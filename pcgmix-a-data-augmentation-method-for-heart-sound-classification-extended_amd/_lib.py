@@ -89,6 +89,7 @@ SIGNATURES = {
     "pcgmix_splice_staging_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
     "pcgmix_ctx_create": (_c_int, [_c_int, ctypes.POINTER(_ptr)]),
     "pcgmix_ctx_destroy": (None, [_ptr]),
+    "pcgmix_fetch_h2d": (_c_int, [_ptr, _ptr, ctypes.c_size_t, _ptr]),
     "pcgmix_ctx_gate": (ctypes.c_double, [_ptr, ctypes.c_uint64]),
     "pcgmix_ctx_set_payload": (_c_int, [_ptr, _ptr, ctypes.c_size_t, _ptr]),
     "pcgmix_ctx_flush_payload": (_c_int, [_ptr, _ptr]),

@@ -108,6 +108,20 @@ class _StagingRing:
 
 
 _RINGS: dict = {}
+_BLIT_LIMIT = 16384       # hipMemcpyAsync uses a blit kernel up to here, the SDMA engine above
+
+
+def _h2d(dev: torch.Tensor, pinned: torch.Tensor, nbytes: int) -> None:
+    """Async copy of the first ``nbytes`` of a pinned staging buffer into the uint8 device tensor
+    ``dev`` on the current stream.  Above 16 KB the copy is one launch of the library's fetch
+    kernel (``pcgmix_fetch_h2d``) instead of an SDMA transfer that stalls the stream for ~25 us;
+    both buffers then have to hold ``nbytes`` rounded up to 16."""
+    if nbytes <= _BLIT_LIMIT:
+        dev[:nbytes].copy_(pinned[:nbytes], non_blocking=True)
+        return
+    _lib.check(_lib.load().pcgmix_fetch_h2d(pinned.data_ptr(), dev.data_ptr(), nbytes,
+                                            ctypes.c_void_p(_raw_stream(dev.device))),
+               "pcgmix_fetch_h2d")
 
 
 def upload_array(arr: np.ndarray, device: torch.device) -> torch.Tensor:
@@ -119,8 +133,8 @@ def upload_array(arr: np.ndarray, device: torch.device) -> torch.Tensor:
     ring = _RINGS.setdefault(device.index, _StagingRing())
     slot, pinned = ring.stage(max(nbytes, 1))
     pinned.numpy()[:nbytes] = arr.reshape(-1).view(np.uint8)
-    dev = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
-    dev.copy_(pinned[:max(nbytes, 1)], non_blocking=True)
+    dev = torch.empty((max(nbytes, 1) + 15) // 16 * 16, dtype=torch.uint8, device=device)
+    _h2d(dev, pinned, max(nbytes, 1))
     ring.sent(slot, torch.cuda.current_stream(device))
     return dev[:nbytes].view(torch.from_numpy(arr[:0].reshape(-1)).dtype).view(arr.shape)
 
@@ -168,8 +182,8 @@ def upload_plan(plan: MixPlan, frames: np.ndarray, device: torch.device, sig_len
         raise ValueError(_PACK_ERRORS.get(err, f"pcgmix_pack_plan_i32 error {err}"))
     if n_kn:
         pinned.numpy()[n_int_pad * 4:nbytes].view(np.float64)[:] = plan.knots.reshape(-1)
-    dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    dev.copy_(pinned[:nbytes], non_blocking=True)
+    dev = torch.empty((nbytes + 15) // 16 * 16, dtype=torch.uint8, device=device)
+    _h2d(dev, pinned, nbytes)
     ring.sent(slot, torch.cuda.current_stream(device))
     offs = {"frames": 0, "mix": B * 5 * 4, "off": B * 6 * 4 if n_off else None,
             "rect": (B * 6 + n_off) * 4 if n_rect else None,

@@ -431,6 +431,15 @@ __global__ __launch_bounds__(256) void label_argmax_kernel(const int64_t* __rest
     __hip_atomic_store(flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Host-to-device copy as a kernel: n16 16-byte words from device-readable host memory (a pinned
+// staging slot) to device memory.  hipMemcpyAsync does the same with a blit kernel up to 16 KB;
+// above that it takes the SDMA path, which costs ~25 us of stream stall per copy on MI355X
+// (profiles/r2_cfg3_step_timeline.txt, first version) — ten times the transfer itself at 50 KB.
+__global__ __launch_bounds__(256) void fetch_kernel(const uint4* __restrict__ src,
+                                                    uint4* __restrict__ dst, int n16) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+
 }  // namespace
 
 struct pcgmix_ctx {
@@ -454,6 +463,24 @@ struct pcgmix_ctx {
   size_t ws_cap = 0;
   int sal_B = 0, sal_max_len = 0;  // what pcgmix_ctx_salopt_begin saw
 };
+
+// Host-to-device copy as a kernel launch (see fetch_kernel) for callers with their own pinned
+// staging: src = pinned host memory (hipHostMalloc / torch pin_memory: device-readable at the same
+// address), both 16-byte aligned; nbytes is rounded up to whole 16-byte words, which both buffers
+// must hold.
+extern "C" int pcgmix_fetch_h2d(const void* src_pinned, void* dst_dev, size_t nbytes,
+                                pcgmix_stream_t stream) {
+  if (!src_pinned || !dst_dev || nbytes > (1ull << 31) ||
+      ((reinterpret_cast<uintptr_t>(src_pinned) | reinterpret_cast<uintptr_t>(dst_dev)) & 15))
+    return hipErrorInvalidValue;
+  if (nbytes == 0) return hipSuccess;
+  const int n16 = (int)((nbytes + 15) / 16);
+  const int blocks = (n16 + 255) / 256 < 32 ? (n16 + 255) / 256 : 32;
+  hipLaunchKernelGGL(fetch_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), static_cast<const uint4*>(src_pinned),
+                     static_cast<uint4*>(dst_dev), n16);
+  return (int)hipGetLastError();
+}
 
 extern "C" int pcgmix_ctx_create(int device, pcgmix_ctx** out) {
   if (!out) return hipErrorInvalidValue;
@@ -554,6 +581,17 @@ hipError_t spline_op_device(pcgmix_ctx* c, int T, int n_knots, const double** ou
 }  // namespace
 
 namespace {
+
+// One staging slot's first `nbytes` to its device twin on `s`.
+hipError_t upload_slot(const Slot& sl, size_t nbytes, hipStream_t s) {
+  if (nbytes <= 16384)
+    return hipMemcpyAsync(sl.dev, sl.pinned, nbytes, hipMemcpyHostToDevice, s);
+  const int n16 = (int)((nbytes + 15) / 16);          // slots are sized in powers of two >= 8 KB
+  const int blocks = (n16 + 255) / 256 < 32 ? (n16 + 255) / 256 : 32;
+  hipLaunchKernelGGL(fetch_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                     reinterpret_cast<const uint4*>(sl.pinned), reinterpret_cast<uint4*>(sl.dev), n16);
+  return hipGetLastError();
+}
 
 // Boundaries (int64 (B,5), host) validated against the signal length and packed as int32.
 // Returns 0, -1 (negative / decreasing) or -2 (cycle end beyond T); *max_len = longest state.
@@ -817,8 +855,7 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   draw_partners(c, labels, B, mix_out, st + (size_t)B * 5);
   lap(4);
   // 5. one H2D copy, the launch, the slot's event behind it
-  if ((e = hipMemcpyAsync(sl.dev, sl.pinned, nbytes, hipMemcpyHostToDevice, s)) != hipSuccess)
-    return (int)e;
+  if ((e = upload_slot(sl, nbytes, s)) != hipSuccess) return (int)e;
   lap(5);
   const int32_t* d = reinterpret_cast<const int32_t*>(sl.dev);
   const int err = pcgmix::launch_mix_warp(x, y, d, d + (size_t)B * 5, nullptr, lam, knots_dev, op_dev,

@@ -10,7 +10,9 @@ sys.path.insert(0, ".")
 import bench  # noqa: E402
 
 dev = torch.device("cuda", 0)
-step, info = bench.build_train_step("durratiomixup", "Potes", 256, 4, 5000, 2000, dev, 5000, 0)
+method = sys.argv[1] if len(sys.argv) > 1 else "durratiomixup"
+print("method", method)
+step, info = bench.build_train_step(method, "Potes", 256, 4, 5000, 2000, dev, 5000, 0)
 for _ in range(50):
     step()
 torch.cuda.synchronize()

@@ -234,3 +234,33 @@ def test_step_payload_rides_with_the_splice(device):
     assert np.array_equal(got[:40], pay) and (got[40:48] == 0).all() and (got[48:] == 7).all()
     with pytest.raises(RuntimeError):                       # destination not 16-byte aligned
         _lib.check(lib.pcgmix_ctx_set_payload(ctx, pay.ctypes.data, 8, dst.data_ptr() + 4), "payload")
+
+
+def test_large_plan_upload_goes_through_the_fetch_kernel(device):
+    """Index data above 16 KB (the warp knots at bs 256: 49 KB) is copied by one launch of the
+    library's fetch kernel from pinned staging instead of an SDMA transfer; the results are those
+    of the oracle.  Covers pcgmix_fetch_h2d with torch's pinned memory, the general plan path
+    ('(rand)': upload_plan) and the one-call path (the step context's own staging)."""
+    from pcgmix_amd import _lib
+    lib = _lib.load()
+    n = 50_000
+    src = torch.empty(65536, dtype=torch.uint8, pin_memory=True)
+    src.numpy()[:] = np.random.RandomState(0).randint(0, 256, 65536)
+    dst = torch.zeros(65536, dtype=torch.uint8, device=device)
+    _lib.check(lib.pcgmix_fetch_h2d(src.data_ptr(), dst.data_ptr(), n,
+                                    torch.cuda.current_stream(device).cuda_stream), "fetch")
+    got = dst.cpu().numpy()
+    n16 = (n + 15) // 16 * 16
+    assert np.array_equal(got[:n16], src.numpy()[:n16]) and (got[n16:] == 0).all()
+    assert lib.pcgmix_fetch_h2d(src.data_ptr() + 4, dst.data_ptr(), 64, None) != 0   # misaligned
+    B, C, T = 256, 4, 5000
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=2000, seed=17)
+    data = torch.from_numpy(x).to(device)
+    tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)
+    for method in ("(rand)durmixmagwarp(0.2,4)", "durmixmagwarp(0.2,4)"):
+        assert B * 6 * C * 8 > augmentations._BLIT_LIMIT
+        y, _, mix, _ = augmentations.augment(Args(method), data, tgt, torch.from_numpy(frames), wav,
+                                             StepCounter(11), None, device, "")
+        ref = O.augment(method, x, labels, frames, wav, 11)
+        assert np.array_equal(mix, ref["mix"])
+        assert np.abs(y.cpu().numpy() - ref["y"]).max() <= WAVE_TOL
