@@ -584,7 +584,11 @@ namespace {
 
 // One staging slot's first `nbytes` to its device twin on `s`.
 hipError_t upload_slot(const Slot& sl, size_t nbytes, hipStream_t s) {
-  if (nbytes <= 16384)
+  static const size_t limit = [] {
+    const char* env = getenv("PCGMIX_BLIT_LIMIT");     // tuning runs
+    return env ? (size_t)atoll(env) : (size_t)16384;
+  }();
+  if (nbytes <= limit)
     return hipMemcpyAsync(sl.dev, sl.pinned, nbytes, hipMemcpyHostToDevice, s);
   const int n16 = (int)((nbytes + 15) / 16);          // slots are sized in powers of two >= 8 KB
   const int blocks = (n16 + 255) / 256 < 32 ? (n16 + 255) / 256 : 32;
