@@ -655,7 +655,9 @@ def main():
         return tr
 
     if not a.no_train:
-        n_tr, w_tr = max(20, a.steps // 4), max(5, a.warmup // 2)
+        # as many steps as the headline leg: a 50-step region (9 ms) carried ~0.4 ms of
+        # start-up and drain, i.e. 3-4 % on the step time
+        n_tr, w_tr = max(20, a.steps), max(5, a.warmup)
         # An exception here is the same code failing on every rank (a rank-local capture failure
         # is settled inside train_steps_per_s through ``agree``): record it, keep the headline.
         try:

@@ -20,6 +20,7 @@
 // All reductions are fixed-order (deterministic).  HBM-bound: 4 bytes per element per pass.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <cmath>
 
@@ -301,6 +302,202 @@ __global__ __launch_bounds__(kBnThreads) void bnrp_bwd_apply_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------ fast paths
+// The three streaming kernels above, specialised for the window shapes ResNet9 uses ((1,1), (1,2),
+// (2,2)) and index ranges that fit 32 bits.  The generic versions walk the window in a loop with
+// runtime bounds: one global load, one s_waitcnt vmcnt(0), the next load — and the backward
+// reduction then waits once more for dz.  A forward pass hides that behind its store (fire and
+// forget), a pure reader does not: bnrp_bwd_reduce_kernel ran at 2.4-2.8 TB/s where the forward
+// apply reaches 6.0 (profiles/r2_resnet1d_step_kernels.csv).  Here every thread handles TWO pooled
+// rows per iteration and issues all of their loads (2 x PH x PW of y, 2 of dz) before the first
+// use; row -> (b, ho, wo) is 32-bit arithmetic (the generic 64-bit divisions are ~100 instructions
+// each).
+template <int PH, int PW>
+__device__ __forceinline__ unsigned window_row(const BnShape& s, unsigned r) {
+  const unsigned wo = r % (unsigned)s.Wo, t = r / (unsigned)s.Wo;
+  const unsigned ho = t % (unsigned)s.Ho, b = t / (unsigned)s.Ho;
+  return (b * (unsigned)s.H + ho * PH) * (unsigned)s.W + wo * PW;      // first input row of the window
+}
+
+template <int PH, int PW>
+__device__ __forceinline__ void window_load(const f4* __restrict__ y, const BnShape& s, unsigned row0,
+                                            int q, f4 (&v)[PH * PW]) {
+#pragma unroll
+  for (int i = 0; i < PH; ++i)
+#pragma unroll
+    for (int j = 0; j < PW; ++j)
+      v[i * PW + j] = y[(size_t)(row0 + (unsigned)i * (unsigned)s.W + (unsigned)j) * s.Q + q];
+}
+
+// window_max on registers: maximum of relu(scale * y + shift), index of its FIRST occurrence, and
+// y itself there.
+template <int N>
+__device__ __forceinline__ f4 window_best(const f4 (&v)[N], f4 scale, f4 shift, int (&arg)[4], f4* raw) {
+  f4 best = {-1.f, -1.f, -1.f, -1.f}, vb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const f4 a = f4_fma(v[k], scale, shift);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float r = a[e] > 0.f ? a[e] : 0.f;
+      if (r > best[e]) {
+        best[e] = r;
+        arg[e] = k;
+        vb[e] = v[k][e];
+      }
+    }
+  }
+  *raw = vb;
+  return best;
+}
+
+template <int PH, int PW>
+__global__ __launch_bounds__(kBnThreads) void bnrp_apply_win_kernel(
+    const f4* __restrict__ y, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const f4* __restrict__ skip,
+    f4* __restrict__ z, BnShape s) {
+  const int q = threadIdx.x % s.Q;
+  const unsigned R = kBnThreads / s.Q, rloc = threadIdx.x / s.Q;
+  const f4 g = *reinterpret_cast<const f4*>(gamma + 4 * q), bt = *reinterpret_cast<const f4*>(beta + 4 * q);
+  const f4 mu = *reinterpret_cast<const f4*>(mean + 4 * q), is = *reinterpret_cast<const f4*>(invstd + 4 * q);
+  const f4 scale = g * is, shift = bt - mu * scale;
+  const unsigned n_rows = (unsigned)s.B * s.Ho * s.Wo, stride = gridDim.x * R;
+  for (unsigned r = blockIdx.x * R + rloc; r < n_rows; r += 2 * stride) {
+    const bool two = r + stride < n_rows;
+    const unsigned r2 = two ? r + stride : r;
+    f4 va[PH * PW], vb[PH * PW];
+    window_load<PH, PW>(y, s, window_row<PH, PW>(s, r), q, va);
+    window_load<PH, PW>(y, s, window_row<PH, PW>(s, r2), q, vb);
+    f4 ka = {0.f, 0.f, 0.f, 0.f}, kb = ka;
+    if (skip) {
+      ka = skip[(size_t)r * s.Q + q];
+      kb = skip[(size_t)r2 * s.Q + q];
+    }
+    int arg[4];
+    f4 raw;
+    z[(size_t)r * s.Q + q] = window_best<PH * PW>(va, scale, shift, arg, &raw) + ka;
+    if (two) z[(size_t)r2 * s.Q + q] = window_best<PH * PW>(vb, scale, shift, arg, &raw) + kb;
+  }
+}
+
+template <int PH, int PW>
+__global__ __launch_bounds__(kBnThreads) void bnrp_bwd_reduce_win_kernel(
+    const f4* __restrict__ y, const f4* __restrict__ dz, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float* __restrict__ partial, BnShape s) {
+  __shared__ f4 lds[2 * kBnThreads];
+  const int q = threadIdx.x % s.Q;
+  const unsigned R = kBnThreads / s.Q, rloc = threadIdx.x / s.Q;
+  const f4 g = *reinterpret_cast<const f4*>(gamma + 4 * q), bt = *reinterpret_cast<const f4*>(beta + 4 * q);
+  const f4 mu = *reinterpret_cast<const f4*>(mean + 4 * q), is = *reinterpret_cast<const f4*>(invstd + 4 * q);
+  const f4 scale = g * is, shift = bt - mu * scale;
+  f4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  const unsigned n_rows = (unsigned)s.B * s.Ho * s.Wo, stride = gridDim.x * R;
+  for (unsigned r = blockIdx.x * R + rloc; r < n_rows; r += 2 * stride) {
+    const bool two = r + stride < n_rows;
+    const unsigned r2 = two ? r + stride : r;
+    f4 va[PH * PW], vb[PH * PW];
+    window_load<PH, PW>(y, s, window_row<PH, PW>(s, r), q, va);
+    window_load<PH, PW>(y, s, window_row<PH, PW>(s, r2), q, vb);
+    const f4 da = dz[(size_t)r * s.Q + q];
+    f4 db = dz[(size_t)r2 * s.Q + q];
+    if (!two) db = f4{0.f, 0.f, 0.f, 0.f};
+    int arg[4];
+    f4 raw;
+    f4 best = window_best<PH * PW>(va, scale, shift, arg, &raw);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = best[e] > 0.f ? da[e] : 0.f;    // ReLU passes the gradient at the arg-max
+      s1[e] += d;
+      s2[e] = fmaf(d, (raw[e] - mu[e]) * is[e], s2[e]);
+    }
+    best = window_best<PH * PW>(vb, scale, shift, arg, &raw);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = best[e] > 0.f ? db[e] : 0.f;
+      s1[e] += d;
+      s2[e] = fmaf(d, (raw[e] - mu[e]) * is[e], s2[e]);
+    }
+  }
+  float* p = partial + (size_t)blockIdx.x * 2 * s.C;
+  quad_reduce_store(s1, s2, s.Q, lds, p, p + s.C);
+}
+
+template <int PH, int PW>
+__global__ __launch_bounds__(kBnThreads) void bnrp_bwd_apply_win_kernel(
+    const f4* __restrict__ y, const f4* __restrict__ dz, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ coef, f4* __restrict__ dx,
+    BnShape s) {
+  const int q = threadIdx.x % s.Q;
+  const unsigned R = kBnThreads / s.Q, rloc = threadIdx.x / s.Q;
+  const f4 g = *reinterpret_cast<const f4*>(gamma + 4 * q), bt = *reinterpret_cast<const f4*>(beta + 4 * q);
+  const f4 mu = *reinterpret_cast<const f4*>(mean + 4 * q), is = *reinterpret_cast<const f4*>(invstd + 4 * q);
+  const f4 c1 = *reinterpret_cast<const f4*>(coef + 4 * q), c2 = *reinterpret_cast<const f4*>(coef + s.C + 4 * q);
+  const f4 scale = g * is, shift = bt - mu * scale;
+  const unsigned n_rows = (unsigned)s.B * s.Ho * s.Wo, stride = gridDim.x * R;
+  auto emit = [&](const f4 (&v)[PH * PW], f4 d, unsigned row0) {
+    int arg[4] = {0, 0, 0, 0};
+    f4 raw;
+    const f4 best = window_best<PH * PW>(v, scale, shift, arg, &raw);
+#pragma unroll
+    for (int i = 0; i < PH; ++i)
+#pragma unroll
+      for (int j = 0; j < PW; ++j) {
+        f4 dy = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (best[e] > 0.f && arg[e] == i * PW + j) dy[e] = d[e];
+        const f4 xh = (v[i * PW + j] - mu) * is;
+        dx[(size_t)(row0 + (unsigned)i * (unsigned)s.W + (unsigned)j) * s.Q + q] = scale * (dy - c1 - xh * c2);
+      }
+  };
+  for (unsigned r = blockIdx.x * R + rloc; r < n_rows; r += 2 * stride) {
+    const bool two = r + stride < n_rows;
+    const unsigned r2 = two ? r + stride : r;
+    const unsigned rowa = window_row<PH, PW>(s, r), rowb = window_row<PH, PW>(s, r2);
+    f4 va[PH * PW], vb[PH * PW];
+    window_load<PH, PW>(y, s, rowa, q, va);
+    window_load<PH, PW>(y, s, rowb, q, vb);
+    const f4 da = dz[(size_t)r * s.Q + q], db = dz[(size_t)r2 * s.Q + q];
+    emit(va, da, rowa);
+    if (two) emit(vb, db, rowb);
+  }
+  // uncovered positions (odd lengths), as in the generic kernel
+  const long long stride4 = (long long)gridDim.x * kBnThreads;
+  const int wc = s.Wo * s.pw, hc = s.Ho * s.ph;
+  const long long n_col = (long long)s.B * s.H * (s.W - wc) * s.Q;
+  for (long long i = (long long)blockIdx.x * kBnThreads + threadIdx.x; i < n_col; i += stride4) {
+    const long long r = i / s.Q;
+    const int w = wc + (int)(r % (s.W - wc));
+    const long long bh = r / (s.W - wc);
+    const long long e = (bh * s.W + w) * s.Q + q;
+    const f4 xh = (y[e] - mu) * is;
+    dx[e] = scale * (-c1 - xh * c2);
+  }
+  const long long n_row = (long long)s.B * (s.H - hc) * wc * s.Q;
+  for (long long i = (long long)blockIdx.x * kBnThreads + threadIdx.x; i < n_row; i += stride4) {
+    const long long r = i / s.Q;
+    const int w = (int)(r % wc);
+    const long long t = r / wc;
+    const int h = hc + (int)(t % (s.H - hc));
+    const long long b = t / (s.H - hc);
+    const long long e = ((b * s.H + h) * s.W + w) * s.Q + q;
+    const f4 xh = (y[e] - mu) * is;
+    dx[e] = scale * (-c1 - xh * c2);
+  }
+}
+
+// 0: generic kernels; 1: (1,1), 2: (1,2), 3: (2,2) windows with 32-bit indexing
+inline int bn_fast_kind(const BnShape& s) {
+  if ((long long)s.B * s.H * s.W * s.Q >= (1ll << 31)) return 0;
+  if (getenv("PCGMIX_BN_GENERIC")) return 0;              // tuning / A-B runs
+  if (s.ph == 1 && s.pw == 1) return 1;
+  if (s.ph == 1 && s.pw == 2) return 2;
+  if (s.ph == 2 && s.pw == 2) return 3;
+  return 0;
+}
+
 inline int bn_blocks(long long n4) {
   long long b = (n4 + (long long)kBnThreads * 8 - 1) / ((long long)kBnThreads * 8);
   if (b < 1) b = 1;
@@ -343,9 +540,16 @@ extern "C" int pcgmix_bnrp_fwd_f32(const float* y, const float* gamma, const flo
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * 16), 0, st, workspace, nblk, C,
                      (double)rows, eps, momentum, mean, invstd, running_mean, running_var);
   const long long n_out = (long long)B * s.Ho * s.Wo * s.Q;
-  hipLaunchKernelGGL(bnrp_apply_kernel, dim3(bn_blocks(n_out * 2)), dim3(kBnThreads), 0, st,
-                     reinterpret_cast<const f4*>(y), gamma, beta, mean, invstd,
-                     reinterpret_cast<const f4*>(skip), reinterpret_cast<f4*>(z), s);
+  const dim3 ag(bn_blocks(n_out * 2)), ab(kBnThreads);
+  const f4* y4 = reinterpret_cast<const f4*>(y);
+  const f4* k4 = reinterpret_cast<const f4*>(skip);
+  f4* z4 = reinterpret_cast<f4*>(z);
+  switch (bn_fast_kind(s)) {
+    case 1: hipLaunchKernelGGL((bnrp_apply_win_kernel<1, 1>), ag, ab, 0, st, y4, gamma, beta, mean, invstd, k4, z4, s); break;
+    case 2: hipLaunchKernelGGL((bnrp_apply_win_kernel<1, 2>), ag, ab, 0, st, y4, gamma, beta, mean, invstd, k4, z4, s); break;
+    case 3: hipLaunchKernelGGL((bnrp_apply_win_kernel<2, 2>), ag, ab, 0, st, y4, gamma, beta, mean, invstd, k4, z4, s); break;
+    default: hipLaunchKernelGGL(bnrp_apply_kernel, ag, ab, 0, st, y4, gamma, beta, mean, invstd, k4, z4, s);
+  }
   return (int)hipGetLastError();
 }
 
@@ -368,13 +572,24 @@ extern "C" int pcgmix_bnrp_bwd_f32(const float* y, const float* dz, const float*
   const long long n_out = (long long)B * s.Ho * s.Wo * s.Q;
   const int nblk = bn_blocks(n_out * 2);
   float* coef = workspace + (size_t)kBnMaxBlocks * 2 * C;
-  hipLaunchKernelGGL(bnrp_bwd_reduce_kernel, dim3(nblk), dim3(kBnThreads), 0, st,
-                     reinterpret_cast<const f4*>(y), reinterpret_cast<const f4*>(dz), gamma, beta,
-                     mean, invstd, workspace, s);
+  const dim3 rg(nblk), rb(kBnThreads);
+  const f4* y4 = reinterpret_cast<const f4*>(y);
+  const f4* dz4 = reinterpret_cast<const f4*>(dz);
+  f4* dx4 = reinterpret_cast<f4*>(dx);
+  const int kind = bn_fast_kind(s);
+  switch (kind) {
+    case 1: hipLaunchKernelGGL((bnrp_bwd_reduce_win_kernel<1, 1>), rg, rb, 0, st, y4, dz4, gamma, beta, mean, invstd, workspace, s); break;
+    case 2: hipLaunchKernelGGL((bnrp_bwd_reduce_win_kernel<1, 2>), rg, rb, 0, st, y4, dz4, gamma, beta, mean, invstd, workspace, s); break;
+    case 3: hipLaunchKernelGGL((bnrp_bwd_reduce_win_kernel<2, 2>), rg, rb, 0, st, y4, dz4, gamma, beta, mean, invstd, workspace, s); break;
+    default: hipLaunchKernelGGL(bnrp_bwd_reduce_kernel, rg, rb, 0, st, y4, dz4, gamma, beta, mean, invstd, workspace, s);
+  }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * 16), 0, st, workspace, nblk,
                      C, (double)rows, dgamma, dbeta, coef);
-  hipLaunchKernelGGL(bnrp_bwd_apply_kernel, dim3(bn_blocks(n_out * 2)), dim3(kBnThreads), 0, st,
-                     reinterpret_cast<const f4*>(y), reinterpret_cast<const f4*>(dz), gamma, beta,
-                     mean, invstd, coef, reinterpret_cast<f4*>(dx), s);
+  switch (kind) {
+    case 1: hipLaunchKernelGGL((bnrp_bwd_apply_win_kernel<1, 1>), rg, rb, 0, st, y4, dz4, gamma, beta, mean, invstd, coef, dx4, s); break;
+    case 2: hipLaunchKernelGGL((bnrp_bwd_apply_win_kernel<1, 2>), rg, rb, 0, st, y4, dz4, gamma, beta, mean, invstd, coef, dx4, s); break;
+    case 3: hipLaunchKernelGGL((bnrp_bwd_apply_win_kernel<2, 2>), rg, rb, 0, st, y4, dz4, gamma, beta, mean, invstd, coef, dx4, s); break;
+    default: hipLaunchKernelGGL(bnrp_bwd_apply_kernel, rg, rb, 0, st, y4, dz4, gamma, beta, mean, invstd, coef, dx4, s);
+  }
   return (int)hipGetLastError();
 }
