@@ -67,7 +67,15 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const f4* __restri
   __shared__ f4 lds[2 * kBnThreads];
   f4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
   const long long stride = (long long)gridDim.x * kBnThreads;     // multiple of Q
-  for (long long i = (long long)blockIdx.x * kBnThreads + threadIdx.x; i < n4; i += stride) {
+  long long i = (long long)blockIdx.x * kBnThreads + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {   // four loads in flight per lane (a pure reader
+    const f4 v0 = y[i], v1 = y[i + stride], v2 = y[i + 2 * stride], v3 = y[i + 3 * stride];
+    s += v0; ss = f4_fma(v0, v0, ss);               // has no store to hide a load-wait-load chain behind)
+    s += v1; ss = f4_fma(v1, v1, ss);
+    s += v2; ss = f4_fma(v2, v2, ss);
+    s += v3; ss = f4_fma(v3, v3, ss);
+  }
+  for (; i < n4; i += stride) {
     const f4 v = y[i];
     s += v;
     ss = f4_fma(v, v, ss);
@@ -83,11 +91,26 @@ __device__ __forceinline__ void partial_sums(const float* __restrict__ partial, 
                                              int c, int lane, double (*lds)[kFinCh][16], double* s0,
                                              double* s1) {
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int k = lane; k < nblk; k += 16) {
+  if (c < C) {
+    int k = lane;
+    for (; k + 7 * 16 < nblk; k += 8 * 16) {       // eight pairs of loads in flight, added in order
+      float va[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        va[u] = partial[(size_t)(k + 16 * u) * 2 * C + c];
+        vb[u] = partial[(size_t)(k + 16 * u) * 2 * C + C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a += (double)va[u];
+        b += (double)vb[u];
+      }
+    }
+    for (; k < nblk; k += 16) {
       a += (double)partial[(size_t)k * 2 * C + c];
       b += (double)partial[(size_t)k * 2 * C + C + c];
     }
+  }
   const int cl = threadIdx.x % kFinCh;
   lds[0][cl][lane] = a;
   lds[1][cl][lane] = b;

@@ -156,14 +156,24 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   // unconditional (a predicated load would serialise the requests); the pad rule is a select.
   // Samples that only frames beyond n_frames would touch are zero.
   const int need = (n_frames - 1) * hop + n_fft;     // samples the valid frames touch
-  for (int i = tid; i < L.xr; i += kMelThreads) {
-    const int sidx = s0 + i;
-    int src = sidx < 0 ? -sidx : (sidx >= len ? 2 * (len - 1) - sidx : sidx);
-    src = src < 0 ? 0 : (src > len - 1 ? len - 1 : src);
-    float v = xg[src];
-    const bool inside = sidx >= 0 && sidx < len;
-    if (i >= need || (!inside && pad_mode == kPadConstant)) v = 0.f;
-    xrow[i] = v;
+  // Eight samples per thread and pass, all eight loads issued before the first LDS store (a loop
+  // with a runtime bound compiles to load, wait, store, load: ~20 serialised round trips here).
+  constexpr int kStagePer = 8;
+  for (int base = 0; base < L.xr; base += kStagePer * kMelThreads) {
+    float v[kStagePer];
+#pragma unroll
+    for (int u = 0; u < kStagePer; ++u) {
+      const int sidx = s0 + base + u * kMelThreads + tid;
+      int src = sidx < 0 ? -sidx : (sidx >= len ? 2 * (len - 1) - sidx : sidx);
+      src = src < 0 ? 0 : (src > len - 1 ? len - 1 : src);
+      v[u] = xg[src];
+    }
+#pragma unroll
+    for (int u = 0; u < kStagePer; ++u) {
+      const int i = base + u * kMelThreads + tid, sidx = s0 + i;
+      const bool inside = sidx >= 0 && sidx < len;
+      if (i < L.xr) xrow[i] = (i >= need || (!inside && pad_mode == kPadConstant)) ? 0.f : v[u];
+    }
   }
   __syncthreads();
 

@@ -61,14 +61,41 @@ __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
   int f4 = frames[b * 5 + 4];
   f4 = f4 < 0 ? 0 : (f4 > T ? T : f4);
 
-  for (int i = threadIdx.x; i < a_len; i += kSalThreads) {
-    const int t = i - half;
-    float acc = 0.f;
-    if (t >= 0 && t < f4) {  // saliency.py:66-67 zeroes t >= f[-1] before the channel sum
-      const float* g = grad + ((size_t)b * C) * T + t;
-      for (int c = 0; c < C; ++c) acc = __fadd_rn(acc, fabsf(g[(size_t)c * T]));
+  if (C == 4) {
+    // The four band channels of the Potes input, up to 8 positions per thread: all 32 loads of a
+    // lane are issued before the first is used.  (The generic loop below compiles to load, wait,
+    // add per channel: 32 serialised L2 round trips per thread with one block per CU — half of
+    // this kernel's time.)  Same order of additions: ((0 + |g0|) + |g1|) + |g2|) + |g3|.
+    constexpr int kPer = 8;
+    for (int base = 0; base < a_len; base += kPer * kSalThreads) {
+      float v[kPer][4];
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        const int t = base + u * kSalThreads + (int)threadIdx.x - half;
+        const bool in = t >= 0 && t < f4;      // saliency.py:66-67 zeroes t >= f[-1] before the sum
+        const float* g = grad + ((size_t)b * 4) * T + (in ? t : 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[u][c] = in ? g[(size_t)c * T] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        const int i = base + u * kSalThreads + (int)threadIdx.x;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc = __fadd_rn(acc, fabsf(v[u][c]));
+        if (i < a_len) a[i] = acc;
+      }
     }
-    a[i] = acc;
+  } else {
+    for (int i = threadIdx.x; i < a_len; i += kSalThreads) {
+      const int t = i - half;
+      float acc = 0.f;
+      if (t >= 0 && t < f4) {  // saliency.py:66-67 zeroes t >= f[-1] before the channel sum
+        const float* g = grad + ((size_t)b * C) * T + t;
+        for (int c = 0; c < C; ++c) acc = __fadd_rn(acc, fabsf(g[(size_t)c * T]));
+      }
+      a[i] = acc;
+    }
   }
   __syncthreads();
 
@@ -306,8 +333,23 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   const float* gs = sal + (size_t)(own_longer ? m : b) * T + (own_longer ? a2 : a1);
   float* lng = smem;
   float* sht = smem + nL;
-  for (int i = threadIdx.x; i < nL; i += kDispThreads) lng[i] = gl[i];
-  for (int i = threadIdx.x; i < nS; i += kDispThreads) sht[i] = gs[i];
+  {  // both segments staged with all of a lane's loads in flight together (a loop with runtime
+     // bounds compiles to load, wait, store, next load: up to eight serialised L2 round trips)
+    constexpr int kMaxPer = 8;                       // covers states up to 2048 samples per pass
+    for (int base = 0; base < nL + nS; base += kMaxPer * kDispThreads) {
+      float v[kMaxPer];
+#pragma unroll
+      for (int u = 0; u < kMaxPer; ++u) {
+        const int i = base + u * kDispThreads + threadIdx.x;
+        v[u] = i < nL ? gl[i] : (i < nL + nS ? gs[i - nL] : 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < kMaxPer; ++u) {
+        const int i = base + u * kDispThreads + threadIdx.x;
+        if (i < nL + nS) smem[i] = v[u];             // sht = smem + nL: one contiguous image
+      }
+    }
+  }
   __syncthreads();
 
   float bv = -INFINITY;
