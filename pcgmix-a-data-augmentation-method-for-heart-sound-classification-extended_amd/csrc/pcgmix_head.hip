@@ -204,6 +204,43 @@ __global__ __launch_bounds__(kTailBwdGroups* kHeadO) void potes_tail_bwd_kernel(
 // order (deterministic); more than two splits would.
 constexpr int kHbWaves = 4, kHbRows = 64, kHbSplit = 2;
 
+// Layout of the fused tail+loss kernel's per-row-block contributions (see potes_tail_loss_kernel):
+constexpr int kTlStride = 192;   // floats per row block: dW2[c*20+o] at 0..159, db2 at 160..167,
+                                 // db1 at 168..187, loss at 188
+constexpr int kTlSeg = 4;        // the row blocks are summed in four segments, then combined in order
+
+// Column t of the contributions of segment sg, summed in a FIXED order with eight loads in flight.
+__device__ __forceinline__ float tl_segment_sum(const float* __restrict__ ws, int nrb, int t, int sg) {
+  const int per = (nrb + kTlSeg - 1) / kTlSeg;
+  const int g0 = sg * per, g1 = g0 + per < nrb ? g0 + per : nrb;
+  float a = 0.f;
+  int g = g0;
+  for (; g + 8 <= g1; g += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ws[(size_t)(g + j) * kTlStride + t];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a += v[j];
+  }
+  for (; g < g1; ++g) a += ws[(size_t)g * kTlStride + t];
+  return a;
+}
+
+// Where column t of the summed contributions goes: index into small = [dW2 (C x 20) | db2 (C) |
+// db1 (20)], -1 for the loss column, -2 for nothing.
+__device__ __forceinline__ int tl_small_index(int t, int C) {
+  if (t < kHeadMaxC * kHeadO) {
+    const int c = t / kHeadO, o = t - c * kHeadO;
+    return c < C ? c * kHeadO + o : -2;
+  }
+  if (t < kHeadMaxC * kHeadO + kHeadMaxC) {
+    const int c = t - kHeadMaxC * kHeadO;
+    return c < C ? C * kHeadO + c : -2;
+  }
+  if (t < kHeadMaxC * kHeadO + kHeadMaxC + kHeadO) return C * kHeadO + C + (t - kHeadMaxC * kHeadO - kHeadMaxC);
+  return t == kHeadMaxC * kHeadO + kHeadMaxC + kHeadO ? -1 : -2;
+}
+
 // NEED_DW = false: the weights are frozen (saliency model): only dx is produced — no read of x,
 // no dW1 accumulators, no reduction, no atomics.
 template <bool MASKED, bool NEED_DW>
@@ -211,15 +248,34 @@ __global__ __launch_bounds__(kHbWaves * 64) void potes_head_bwd_kernel(
     const float* __restrict__ dz, const float* __restrict__ x, const uint8_t* __restrict__ mask1,
     float scale1, int thr1, int bits1, const float* __restrict__ w1, float* __restrict__ dw1,
     float* __restrict__ dx, int B, int K, const float* __restrict__ gscale,
-    const float* __restrict__ small_in, float* __restrict__ small_out, int n_small) {
+    const float* __restrict__ small_in, float* __restrict__ small_out, int n_small,
+    const float* __restrict__ tl_ws, int tl_nrb, float* __restrict__ tl_loss, int tl_C) {
   __shared__ __align__(16) float dzl[kHbRows * kHeadO];
   // gscale (device scalar, may be NULL = 1): the gradient that arrived at the loss — dz was formed
   // for d loss = 1 by the fused tail+loss kernel; everything downstream is linear in it.  Block
   // (0,0) also scales the small gradients (dW2, db2, db1) that kernel produced.
   const float gs = gscale ? gscale[0] : 1.f;
-  if (small_out && blockIdx.x == 0 && blockIdx.y == 0)
-    for (int i = threadIdx.x; i < n_small; i += kHbWaves * 64) small_out[i] = small_in[i] * gs;
   __shared__ float red[kHbWaves][kHeadO][kHbCols];
+  if (small_out && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (tl_ws) {
+      // The fused tail+loss forward left its finalize step to this block (captured training step:
+      // one launch less per replay): column sums of the per-row-block contributions in
+      // potes_tail_loss_finalize_kernel's order, the loss, and the small gradients times gs.
+      float* seg = &red[0][0][0];                     // `red` is not in use before the end
+      for (int it = threadIdx.x; it < kTlSeg * kTlStride; it += kHbWaves * 64)
+        seg[it] = tl_segment_sum(tl_ws, tl_nrb, it % kTlStride, it / kTlStride);
+      __syncthreads();
+      for (int t = threadIdx.x; t < kTlStride; t += kHbWaves * 64) {
+        const float a = ((seg[t] + seg[kTlStride + t]) + seg[2 * kTlStride + t]) + seg[3 * kTlStride + t];
+        const int idx = tl_small_index(t, tl_C);
+        if (idx >= 0) small_out[idx] = a * gs;
+        else if (idx == -1) tl_loss[0] = a / (float)B;
+      }
+      __syncthreads();
+    } else {
+      for (int i = threadIdx.x; i < n_small; i += kHbWaves * 64) small_out[i] = small_in[i] * gs;
+    }
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k0 = blockIdx.x * kHbCols, k = k0 + lane;
   const bool valid = k < K;
@@ -354,9 +410,6 @@ __global__ __launch_bounds__(256) void soft_ce_bwd_kernel(const float* __restric
 // part for 4 rows per block — z, logits, the row's soft-target cross entropy, dlogits, dz (for
 // d loss = 1) — and writes its rows' contributions to the reductions; potes_tail_loss_finalize_kernel
 // adds the per-block contributions in a fixed order.  Two launches instead of four.
-constexpr int kTlStride = 192;   // floats per row block: dW2[c*20+o] at 0..159, db2 at 160..167,
-                                 // db1 at 168..187, loss at 188
-
 __global__ __launch_bounds__(kTailRows* kHeadO * 4) void potes_tail_loss_kernel(
     const float* __restrict__ partial, int KS, const float* __restrict__ b1,
     const uint8_t* __restrict__ mask2, float scale2, int thr2, const float* __restrict__ w2,
@@ -472,40 +525,19 @@ __global__ __launch_bounds__(kTailRows* kHeadO * 4) void potes_tail_loss_kernel(
 // take a quarter of the row blocks each (their loads all in flight together), then thread 0 of
 // the column adds the four partial sums in order.  (One thread walking all 64 row blocks took
 // 16 us: 64 dependent-latency loads.)
-constexpr int kTlSeg = 4;
 __global__ __launch_bounds__(kTlStride* kTlSeg) void potes_tail_loss_finalize_kernel(
     const float* __restrict__ ws, int nrb, float* __restrict__ loss, float* __restrict__ small,
     int B, int C) {
   // small = [dW2 (C x 20) | db2 (C) | db1 (20)], for d loss = 1
   __shared__ float seg[kTlSeg][kTlStride];
   const int t = threadIdx.x % kTlStride, sg = threadIdx.x / kTlStride;
-  const int per = (nrb + kTlSeg - 1) / kTlSeg;
-  const int g0 = sg * per, g1 = g0 + per < nrb ? g0 + per : nrb;
-  float a = 0.f;
-  int g = g0;
-  for (; g + 8 <= g1; g += 8) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = ws[(size_t)(g + j) * kTlStride + t];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a += v[j];
-  }
-  for (; g < g1; ++g) a += ws[(size_t)g * kTlStride + t];
-  seg[sg][t] = a;
+  seg[sg][t] = tl_segment_sum(ws, nrb, t, sg);
   __syncthreads();
-  if (sg != 0 || t > kHeadMaxC * kHeadO + kHeadMaxC + kHeadO) return;
-  a = ((seg[0][t] + seg[1][t]) + seg[2][t]) + seg[3][t];
-  if (t < kHeadMaxC * kHeadO) {
-    const int c = t / kHeadO, o = t - c * kHeadO;
-    if (c < C) small[c * kHeadO + o] = a;
-  } else if (t < kHeadMaxC * kHeadO + kHeadMaxC) {
-    const int c = t - kHeadMaxC * kHeadO;
-    if (c < C) small[C * kHeadO + c] = a;
-  } else if (t < kHeadMaxC * kHeadO + kHeadMaxC + kHeadO) {
-    small[C * kHeadO + C + (t - kHeadMaxC * kHeadO - kHeadMaxC)] = a;
-  } else {
-    loss[0] = a / (float)B;
-  }
+  if (sg != 0) return;
+  const float a = ((seg[0][t] + seg[1][t]) + seg[2][t]) + seg[3][t];
+  const int idx = tl_small_index(t, C);
+  if (idx >= 0) small[idx] = a;
+  else if (idx == -1) loss[0] = a / (float)B;
 }
 
 }  // namespace pcgmix
@@ -567,16 +599,16 @@ extern "C" int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, c
   if (!dw1) {                      // frozen weights: dx only
     if (mask1)
       hipLaunchKernelGGL((potes_head_bwd_kernel<true, false>), grid, block, 0, s, dz, x, mask1, scale1,
-                         thr1, bits1, w1, dw1, dx, B, K, nullptr, nullptr, nullptr, 0);
+                         thr1, bits1, w1, dw1, dx, B, K, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0);
     else
       hipLaunchKernelGGL((potes_head_bwd_kernel<false, false>), grid, block, 0, s, dz, x, mask1, 1.0f,
-                         0, 8, w1, dw1, dx, B, K, nullptr, nullptr, nullptr, 0);
+                         0, 8, w1, dw1, dx, B, K, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0);
   } else if (mask1) {
     hipLaunchKernelGGL((potes_head_bwd_kernel<true, true>), grid, block, 0, s, dz, x, mask1, scale1,
-                       thr1, bits1, w1, dw1, dx, B, K, nullptr, nullptr, nullptr, 0);
+                       thr1, bits1, w1, dw1, dx, B, K, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0);
   } else {
     hipLaunchKernelGGL((potes_head_bwd_kernel<false, true>), grid, block, 0, s, dz, x, mask1, 1.0f, 0,
-                       8, w1, dw1, dx, B, K, nullptr, nullptr, nullptr, 0);
+                       8, w1, dw1, dx, B, K, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0);
   }
   return (int)hipGetLastError();
 }
@@ -597,7 +629,7 @@ extern "C" int pcgmix_potes_head_saliency_f32(const float* x, const float* w1, c
                      dim3(kTailRows * kHeadO * 4), 0, s, partial, KS, b1, w2, seed, dz, B, C);
   const dim3 grid((unsigned)((K + kHbCols - 1) / kHbCols), kHbSplit), block(kHbWaves * 64);
   hipLaunchKernelGGL((potes_head_bwd_kernel<false, false>), grid, block, 0, s, dz, x, nullptr, 1.0f, 0,
-                     8, w1, nullptr, dx, B, K, nullptr, nullptr, nullptr, 0);
+                     8, w1, nullptr, dx, B, K, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, 0);
   return (int)hipGetLastError();
 }
 
@@ -611,7 +643,8 @@ extern "C" int pcgmix_potes_head_loss_fwd_f32(const float* x, const uint8_t* mas
                                               const float* w2, const float* b2, const float* target,
                                               float* partial, float* z, float* logits, float* dz,
                                               float* loss, float* small, float* ws, float* dw1_zero,
-                                              int B, int K, int C, pcgmix_stream_t stream) {
+                                              int defer_finalize, int B, int K, int C,
+                                              pcgmix_stream_t stream) {
   using namespace pcgmix;
   if (!w2 || !target || !z || !logits || !dz || !loss || !small || !ws || C <= 0 || C > kHeadMaxC ||
       (reinterpret_cast<uintptr_t>(dz) & 15))
@@ -627,20 +660,23 @@ extern "C" int pcgmix_potes_head_loss_fwd_f32(const float* x, const uint8_t* mas
   hipLaunchKernelGGL(potes_tail_loss_kernel, dim3((unsigned)nrb + zero_blocks),
                      dim3(kTailRows * kHeadO * 4), 0, s, partial, KS, b1, mask2, scale2, thr2, w2, b2,
                      target, z, logits, dz, ws, dw1_zero, n_zero, B, C, nrb);
-  hipLaunchKernelGGL(potes_tail_loss_finalize_kernel, dim3(1), dim3(kTlStride * kTlSeg), 0, s, ws, nrb,
-                     loss, small, B, C);
+  if (!defer_finalize)
+    hipLaunchKernelGGL(potes_tail_loss_finalize_kernel, dim3(1), dim3(kTlStride * kTlSeg), 0, s, ws,
+                       nrb, loss, small, B, C);
   return (int)hipGetLastError();
 }
 
 extern "C" int pcgmix_potes_head_loss_bwd_f32(const float* dz, const float* gscale, const float* x,
                                               const uint8_t* mask1, float scale1, int thr1, int bits1,
                                               const float* w1, const float* small_in,
-                                              float* small_out, float* dw1, float* dx, int B, int K,
-                                              int C, pcgmix_stream_t stream) {
+                                              float* small_out, float* dw1, float* dx,
+                                              const float* deferred_ws, float* deferred_loss, int B,
+                                              int K, int C, pcgmix_stream_t stream) {
   using namespace pcgmix;
   if (!dz || !x || !w1 || (!dw1 && !dx) || B <= 0 || K <= 0 || (K & 3) || C <= 0 || C > kHeadMaxC ||
       (reinterpret_cast<uintptr_t>(dz) & 15) ||
-      (mask1 && bits1 != 1 && bits1 != 2 && bits1 != 4 && bits1 != 8) || (small_out && !small_in))
+      (mask1 && bits1 != 1 && bits1 != 2 && bits1 != 4 && bits1 != 8) ||
+      (small_out && !small_in && !deferred_ws) || (deferred_ws && (!deferred_loss || !small_out)))
     return hipErrorInvalidValue;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int n_small = C * kHeadO + C + kHeadO;
@@ -648,7 +684,8 @@ extern "C" int pcgmix_potes_head_loss_bwd_f32(const float* dz, const float* gsca
 #define PCGMIX_HB(M, D)                                                                          \
   hipLaunchKernelGGL((potes_head_bwd_kernel<M, D>), grid, block, 0, s, dz, x, mask1,              \
                      mask1 ? scale1 : 1.0f, mask1 ? thr1 : 0, mask1 ? bits1 : 8, w1, dw1, dx, B, K, \
-                     gscale, small_in, small_out, n_small)
+                     gscale, small_in, small_out, n_small, deferred_ws,                          \
+                     (B + kTailRows - 1) / kTailRows, deferred_loss, C)
   if (!dw1) { if (mask1) PCGMIX_HB(true, false); else PCGMIX_HB(false, false); }
   else { if (mask1) PCGMIX_HB(true, true); else PCGMIX_HB(false, true); }
 #undef PCGMIX_HB

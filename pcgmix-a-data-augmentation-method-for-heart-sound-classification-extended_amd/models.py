@@ -274,7 +274,11 @@ class PotesHeadLossFunction(torch.autograd.Function):
     the backward kernel (no extra launch)."""
 
     @staticmethod
-    def forward(ctx, feat, w1, b1, w2, b2, target, p1, p2, training, rnd=None):
+    def forward(ctx, feat, w1, b1, w2, b2, target, p1, p2, training, rnd=None, defer=False):
+        # defer: leave the forward's finalize launch (loss and small gradients from the per-row-block
+        # contributions) to the backward's feature pass — the loss is then only valid after
+        # backward.  For callers whose forward and backward always run together and who cannot
+        # look at the loss in between: a training step being captured (see loss_and_logits).
         B, K = feat.shape
         C = w2.shape[0]
         dev = feat.device
@@ -309,14 +313,18 @@ class PotesHeadLossFunction(torch.autograd.Function):
         dw1 = torch.empty_like(w1c) if need_dw1 else None
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         opt = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        defer = bool(defer and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
         _lib.check(lib.pcgmix_potes_head_loss_fwd_f32(
             x.data_ptr(), opt(mask1), ctypes.c_float(s1), thr1, bits1, w1c.data_ptr(),
             b1.detach().data_ptr() if b1 is not None else None, opt(mask2), ctypes.c_float(s2), thr2,
             w2c.data_ptr(), b2.detach().data_ptr() if b2 is not None else None, tgt.data_ptr(),
             partial.data_ptr(), z.data_ptr(), logits.data_ptr(), dz.data_ptr(), loss.data_ptr(),
-            small.data_ptr(), ws.data_ptr(), opt(dw1), B, K, C, stream),
+            small.data_ptr(), ws.data_ptr(), opt(dw1), int(defer), B, K, C, stream),
             "pcgmix_potes_head_loss_fwd_f32")
         ctx.save_for_backward(x, w1c, dz, small, mask1, dw1)
+        # the backward writes the loss through this alias (no version check: under capture nobody
+        # can have touched it in between)
+        ctx.deferred = (ws, loss.detach()) if defer else (None, None)
         ctx.drop = (thr1, bits1, s1)
         ctx.C = C
         ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
@@ -327,8 +335,9 @@ class PotesHeadLossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, _glogits):
         x, w1, dz, small, mask1, dw1 = ctx.saved_tensors
+        ws, loss = ctx.deferred
         if gloss is None:                       # nothing upstream of the loss
-            return (None,) * 10
+            return (None,) * 11
         thr1, bits1, s1 = ctx.drop
         B, K = x.shape
         C = ctx.C
@@ -340,12 +349,12 @@ class PotesHeadLossFunction(torch.autograd.Function):
         opt = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
         _lib.check(lib.pcgmix_potes_head_loss_bwd_f32(
             dz.data_ptr(), g.data_ptr(), x.data_ptr(), opt(mask1), ctypes.c_float(s1), thr1, bits1,
-            w1.data_ptr(), small.data_ptr(), small_out.data_ptr(), opt(dw1), opt(dx), B, K, C, stream),
-            "pcgmix_potes_head_loss_bwd_f32")
+            w1.data_ptr(), small.data_ptr(), small_out.data_ptr(), opt(dw1), opt(dx), opt(ws), opt(loss),
+            B, K, C, stream), "pcgmix_potes_head_loss_bwd_f32")
         dw2 = small_out[:C * 20].view(C, 20)
         db2 = small_out[C * 20:C * 20 + C] if ctx.has_b2 else None
         db1 = small_out[C * 20 + C:] if ctx.has_b1 else None
-        return dx, dw1, db1, dw2, db2, None, None, None, None, None
+        return dx, dw1, db1, dw2, db2, None, None, None, None, None, None
 
 
 def _potes_block(c_in: int, c_out: int, dropout: float = 0.0) -> nn.Sequential:
@@ -452,10 +461,13 @@ class CNN_potes(nn.Module):
         rnd, key = self._dropout_source(x)
         z = PotesStackFunction.apply(rows.contiguous(), c1.weight, c1.bias, c2.weight, c2.bias, rnd, key)
         drop = self.cnn1[1][3] if len(self.cnn1[1]) > 3 else None
+        # While a training step is being captured, forward and backward always replay together and
+        # nobody can look at the loss in between: one launch less (PotesHeadLossFunction, `defer`).
+        defer = torch.is_grad_enabled() and torch.cuda.is_current_stream_capturing()
         return PotesHeadLossFunction.apply(z.reshape(B, -1), self.dimreduc.weight, self.dimreduc.bias,
                                            self.linear.weight, self.linear.bias, target,
                                            float(drop.p) if drop is not None else 0.0,
-                                           float(self.dropout.p), self.training, rnd)
+                                           float(self.dropout.p), self.training, rnd, defer)
 
     def features(self, x: torch.Tensor) -> torch.Tensor:
         B, C, T = x.shape

@@ -251,3 +251,42 @@ def test_fused_head_loss_equals_head_then_celoss(training, soft, device):
     for k in res[0][3]:
         a, b = res[0][3][k], res[1][3][k]
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-7 + 1e-4 * float(b.abs().max())), k
+
+
+def test_head_loss_finalize_deferred(device):
+    """`defer`: the fused head+loss forward leaves its finalize launch (loss and small gradients
+    from the per-row-block contributions) to the backward's feature pass — what the captured
+    training step asks for (CNN_potes.loss_and_logits while capturing).  The loss is written by
+    the backward; loss, logits and every gradient are bit-identical to the two-launch form.
+    (The captured form itself: test_graphed_step_matches_eager* in test_train_gpu.py.)"""
+    from pcgmix_amd import models
+    from torch.profiler import profile, ProfilerActivity
+    torch.manual_seed(8)
+    B, K, C = 100, 19968, 2                                  # 25 row blocks: uneven segments
+    w1 = (torch.randn(20, K, device=device) * 0.01).requires_grad_(True)
+    b1 = torch.randn(20, device=device).requires_grad_(True)
+    w2 = torch.randn(C, 20, device=device).requires_grad_(True)
+    b2 = torch.randn(C, device=device).requires_grad_(True)
+    feat = torch.randn(B, K, device=device).requires_grad_(True)
+    t = F.one_hot(torch.randint(0, C, (B,), device=device), C).float()
+    gs = torch.tensor(0.5, device=device)
+    params = (feat, w1, b1, w2, b2)
+
+    def forward(defer):
+        return models.PotesHeadLossFunction.apply(feat, w1, b1, w2, b2, t, 0.0, 0.0, True, None, defer)
+
+    loss0, logits0 = forward(False)
+    grads0 = torch.autograd.grad(loss0, params, gs)
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        loss1, logits1 = forward(True)
+        loss1.detach().fill_(-1.0)                           # the forward has not written it ...
+        grads1 = torch.autograd.grad(loss1, params, gs)
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if "potes_tail_loss" in e.name]
+    assert names and not any("finalize" in n for n in names), names      # one launch less
+    assert torch.equal(loss1.detach(), loss0.detach())       # ... the backward does
+    assert torch.equal(logits1, logits0)
+    for a, b in zip(grads1, grads0):
+        assert torch.equal(a, b)
+    # (the Function trusts `defer`; CNN_potes.loss_and_logits sets it only with autograd on and
+    # a capture in progress)
