@@ -112,11 +112,25 @@ def exact_mix_bytes(frames, mix, C, T):
     return 4.0 * C * (2.0 * frames.shape[0] * T + blended)
 
 
+def karg_unroll(B, C, T, warp):
+    """Unroll of the kernarg instantiation the drop-in step launches for this problem (plain
+    splice, B <= 256: the index block travels in the kernel arguments), or 0."""
+    import ctypes
+    from pcgmix_amd import _lib
+    if warp or os.environ.get("PCGMIX_NO_KARG"):
+        return 0
+    u = ctypes.c_int()
+    return u.value if _lib.load().pcgmix_mix_karg_variant(B, C, T, ctypes.byref(u)) else 0
+
+
 def mix_kernel_name(B, C, T, warp):
-    """Name of the instantiation pcgmix_mix_warp_f32 launches for this problem (asked from the
+    """Name of the instantiation the drop-in step launches for this problem (asked from the
     library: the choice of lane width and unroll lives there)."""
     import ctypes
     from pcgmix_amd import _lib
+    u = karg_unroll(B, C, T, warp)
+    if u:
+        return f"pcgmix::mix_warp_karg_kernel<false, {u}>"
     vec, unroll = ctypes.c_int(), ctypes.c_int()
     _lib.check(_lib.load().pcgmix_mix_variant(B, C, T, int(bool(warp)), 1, ctypes.byref(vec),
                                               ctypes.byref(unroll)), "pcgmix_mix_variant")
@@ -148,6 +162,19 @@ def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200, per_launch=
     def launch():
         augmentations.launch_mix(data, out, base + offs["frames"], base + offs["mix"], None,
                                  float(plan.lam32), knots_ptr, op_ptr, plan.n_knots, B, C, T)
+    if karg_unroll(B, C, T, plan.knots is not None):
+        # the instantiation the drop-in step runs at this size: index block in the kernel arguments
+        import ctypes
+        from pcgmix_amd import _lib
+        fr16 = np.ascontiguousarray(frames, dtype=np.int16)
+        mx16 = np.ascontiguousarray(plan.mix, dtype=np.int16)
+        lib, lam_c = _lib.load(), ctypes.c_float(float(plan.lam32))
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+        def launch():                                        # noqa: F811
+            _lib.check(lib.pcgmix_mix_karg_f32(data.data_ptr(), out.data_ptr(), fr16.ctypes.data,
+                                               mx16.ctypes.data, lam_c, B, C, T, stream),
+                       "pcgmix_mix_karg_f32")
     for _ in range(10):
         launch()
     torch.cuda.synchronize()

@@ -135,6 +135,17 @@ int pcgmix_mix_warp_f32(const float* x, float* y,
                         const int32_t* zero_rect,
                         int B, int C, int T, pcgmix_stream_t stream);
 
+/* The plain splice (no '(rand)' offsets, no warp, no rectangle) with its index block in the KERNEL
+ * ARGUMENTS: frames16 (B,5) and mix16 (B) are HOST arrays of int16 that the launch copies into the
+ * kernel's 4 KB argument segment (3 KB used) — the blocks read them with scalar loads, and there is
+ * no host-to-device copy in front of the launch.  Needs B <= 256, T <= 32767, T % 4 == 0, x and y
+ * 16-byte aligned (BASELINE configs[1]); hipErrorInvalidValue otherwise.  Same arithmetic and
+ * results as pcgmix_mix_warp_f32.  pcgmix_augment_plain_f32 takes this path by itself.
+ * pcgmix_mix_karg_variant: 1 and the instantiation's unroll if (B, C, T) qualifies, else 0.    */
+int pcgmix_mix_karg_f32(const float* x, float* y, const int16_t* frames16, const int16_t* mix16,
+                        float lam, int B, int C, int T, pcgmix_stream_t stream);
+int pcgmix_mix_karg_variant(int B, int C, int T, int* unroll);
+
 /* ------------------------------------------------------------------------------------------
  * Saliency post-processing.                                                       [device]
  *

@@ -90,6 +90,8 @@ SIGNATURES = {
     "pcgmix_ctx_create": (_c_int, [_c_int, ctypes.POINTER(_ptr)]),
     "pcgmix_ctx_destroy": (None, [_ptr]),
     "pcgmix_fetch_h2d": (_c_int, [_ptr, _ptr, ctypes.c_size_t, _ptr]),
+    "pcgmix_mix_karg_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_float, _c_int, _c_int, _c_int, _ptr]),
+    "pcgmix_mix_karg_variant": (_c_int, [_c_int, _c_int, _c_int, _ptr]),
     "pcgmix_ctx_gate": (ctypes.c_double, [_ptr, ctypes.c_uint64]),
     "pcgmix_ctx_set_payload": (_c_int, [_ptr, _ptr, ctypes.c_size_t, _ptr]),
     "pcgmix_ctx_flush_payload": (_c_int, [_ptr, _ptr]),

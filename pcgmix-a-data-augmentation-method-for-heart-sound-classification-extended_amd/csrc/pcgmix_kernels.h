@@ -39,6 +39,14 @@ int launch_mix_warp(const float* x, float* y, const int32_t* frames, const int32
                     const void* pay_src, void* pay_dst, int pay_n16,
                     const float2* disp_part = nullptr);
 
+// pcgmix_mix.hip: the plain splice (no offsets, no warp, no rectangle) with its index block in
+// the kernel ARGUMENTS instead of device memory: frames (B,5) and partners (B) as int16 in host
+// memory, B <= kPackB, T <= 32767, T % 4 == 0, x and y 16-byte aligned.  Returns
+// hipErrorInvalidValue when the shape does not qualify (the caller then takes the copy path).
+constexpr int kPackB = 256;
+int launch_mix_karg(const float* x, float* y, const int16_t* frames16, const int16_t* mix16, float lam,
+                    int B, int C, int T, hipStream_t s);
+
 // pcgmix_saliency.hip: the displacement search of pcgmix_salopt_disp_f32; disp == nullptr leaves
 // the per-block results in `workspace` for launch_mix_warp's disp_part.
 // pay_*: pay_n16 16-byte words that one otherwise idle block copies from pay_src (device-readable

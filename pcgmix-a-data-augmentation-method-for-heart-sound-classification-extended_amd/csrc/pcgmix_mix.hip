@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "pcgmix_kernels.h"
 
@@ -148,26 +149,13 @@ __device__ __forceinline__ void spline_apply(float (&out)[VEC], const double* __
 
 // VEC = 4: T % 4 == 0, rows are 16-byte aligned, U quads per lane (epb = 256*4*U).
 // VEC = 1: any T, one element per lane and iteration.
+// The kernel proper: sample b (block-uniform), its partner m and their blended ranges are known.
 template <int VEC, bool WARP, int U>
-__global__ __launch_bounds__(kThreads) void mix_warp_kernel(
-    const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ frames,
-    const int32_t* __restrict__ mix_idx, const int32_t* __restrict__ off, float lam, float oml,
+__device__ __forceinline__ void mix_body(
+    const float* __restrict__ x, float* __restrict__ y, float lam, float oml,
     const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots,
-    const int32_t* __restrict__ zero_rect, int B, int C, int T, int epb,
-    const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst, int pay_n16,
-    const float2* __restrict__ disp_part) {
-  extern __shared__ __align__(16) double lds[];  // spline records per channel, then thresholds
-
-  // Step payload (pcgmix_ctx_set_payload): a few KB that travelled with the index block and
-  // belong somewhere else on the device; block (0,0,0) forwards them.
-  if (pay_n16 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0)
-    for (int i = threadIdx.x; i < pay_n16; i += kThreads) pay_dst[i] = pay_src[i];
-
-  const int b = blockIdx.z * kBatchPerGridZ + blockIdx.y;
-  if (b >= B) return;  // block-uniform
-  int m = mix_idx[b];
-  m = (m < 0 || m >= B) ? b : m;  // memory safety; validated on the host as well
-  const StateMap sm = make_state_map(frames, off, b, m, T, disp_part);
+    const int32_t* __restrict__ zero_rect, int C, int T, int epb, int b, int m, const StateMap& sm,
+    double* lds) {
   // optional zeroed rectangle (rows = index along C, columns = index along T), block-uniform
   int zr0 = 0, zr1 = 0, zc0 = 0, zc1 = 0;
   if (zero_rect) {
@@ -302,6 +290,76 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
   }
 }
 
+template <int VEC, bool WARP, int U>
+__global__ __launch_bounds__(kThreads) void mix_warp_kernel(
+    const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ frames,
+    const int32_t* __restrict__ mix_idx, const int32_t* __restrict__ off, float lam, float oml,
+    const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots,
+    const int32_t* __restrict__ zero_rect, int B, int C, int T, int epb,
+    const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst, int pay_n16,
+    const float2* __restrict__ disp_part) {
+  extern __shared__ __align__(16) double lds[];  // spline records per channel, then thresholds
+
+  // Step payload (pcgmix_ctx_set_payload): a few KB that travelled with the index block and
+  // belong somewhere else on the device; block (0,0,0) forwards them.
+  if (pay_n16 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0)
+    for (int i = threadIdx.x; i < pay_n16; i += kThreads) pay_dst[i] = pay_src[i];
+
+  const int b = blockIdx.z * kBatchPerGridZ + blockIdx.y;
+  if (b >= B) return;  // block-uniform
+  int m = mix_idx[b];
+  m = (m < 0 || m >= B) ? b : m;  // memory safety; validated on the host as well
+  const StateMap sm = make_state_map(frames, off, b, m, T, disp_part);
+  mix_body<VEC, WARP, U>(x, y, lam, oml, knots, spline_op, n_knots, zero_rect, C, T, epb, b, m, sm, lds);
+}
+
+// The same kernel with the whole index block — boundaries and partners of up to kPackB samples
+// as int16 — in its ARGUMENTS (3 KB of the 4 KB kernarg segment): block-uniform data that the
+// blocks read with scalar loads, and no host-to-device copy in front of the launch.  For the
+// step context's plain step at B <= 256, T <= 32767 (BASELINE configs[1]): the 6 KB blit copy
+// was 4.7 us of GPU time in the middle of the label -> host -> copy -> splice chain that bounds a
+// strict-signature step.
+struct IdxPack {            // int16 values two per dword: boundaries fr[b*5+k] at i = b*5+k, partners at
+  int32_t w[kPackB * 3];    // i = kPackB*5 + b.  Dwords so that the block-uniform reads become s_load_dword
+};                          // (there is no scalar 16-bit load; int16 members are fetched through VGPRs).
+__device__ __forceinline__ int pack_get(const IdxPack& p, int i) {
+  const int w = p.w[i >> 1];
+  return (i & 1) ? (w >> 16) : ((int)((unsigned)w << 16) >> 16);
+}
+
+template <bool WARP, int U>
+__global__ __launch_bounds__(kThreads) void mix_warp_karg_kernel(
+    const float* __restrict__ x, float* __restrict__ y, const IdxPack pack, float lam, float oml,
+    const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots, int B,
+    int C, int T, int epb) {
+  extern __shared__ __align__(16) double lds[];
+  const int b = blockIdx.y;
+  if (b >= B) return;
+  int m = pack_get(pack, kPackB * 5 + b);
+  m = (m < 0 || m >= B) ? b : m;
+  int f1[5], f2[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    f1[k] = pack_get(pack, b * 5 + k);
+    f2[k] = pack_get(pack, m * 5 + k);
+  }
+  StateMap sm;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {          // make_state_map without offsets
+    const int a = f1[k], s = f2[k];
+    const int len1 = f1[k + 1] - a, len2 = f2[k + 1] - s;
+    int n = len1 < len2 ? len1 : len2;
+    if (a < 0 || s < 0) n = 0;
+    if (n > T - a) n = T - a;
+    if (n > T - s) n = T - s;
+    if (n < 0) n = 0;
+    sm.a[k] = a;
+    sm.n[k] = n;
+    sm.delta[k] = s - a;
+  }
+  mix_body<4, WARP, U>(x, y, lam, oml, knots, spline_op, n_knots, nullptr, C, T, epb, b, m, sm, lds);
+}
+
 // Elements of one sample's plane per block: 1024 * U.  Fatter blocks amortise the block
 // prologue (dependent index loads, spline records) and keep more loads in flight per lane;
 // thinner ones waste fewer lanes on the last chunk of a short plane.  Chosen from measurements
@@ -335,6 +393,46 @@ extern "C" int pcgmix_mix_warp_f32(const float* x, float* y, const int32_t* fram
   return pcgmix::launch_mix_warp(x, y, frames, mix_idx, off, lam, knots, spline_op, n_knots,
                                  zero_rect, B, C, T, reinterpret_cast<hipStream_t>(stream), nullptr,
                                  nullptr, 0);
+}
+
+extern "C" int pcgmix_mix_karg_f32(const float* x, float* y, const int16_t* frames16,
+                                   const int16_t* mix16, float lam, int B, int C, int T,
+                                   pcgmix_stream_t stream) {
+  return pcgmix::launch_mix_karg(x, y, frames16, mix16, lam, B, C, T,
+                                 reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int pcgmix_mix_karg_variant(int B, int C, int T, int* unroll) {
+  if (B <= 0 || B > pcgmix::kPackB || C <= 0 || T <= 0 || T > 32767 || (T & 3) || !unroll) return 0;
+  *unroll = pcgmix::choose_unroll(B, (long long)C * T, false) >= 2 ? 2 : 1;
+  return 1;
+}
+
+int pcgmix::launch_mix_karg(const float* x, float* y, const int16_t* frames16, const int16_t* mix16,
+                            float lam, int B, int C, int T, hipStream_t s) {
+  using namespace pcgmix;
+  if (!x || !y || !frames16 || !mix16 || x == y || B <= 0 || B > kPackB || C <= 0 || T <= 0 ||
+      T > 32767 || (T & 3) ||
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15))
+    return hipErrorInvalidValue;
+  const long long plane = (long long)C * T;
+  if (plane > 0x7fffffffLL) return hipErrorInvalidValue;
+  IdxPack pack;
+  int16_t* p16 = reinterpret_cast<int16_t*>(pack.w);
+  memcpy(p16, frames16, sizeof(int16_t) * (size_t)B * 5);
+  memcpy(p16 + kPackB * 5, mix16, sizeof(int16_t) * (size_t)B);
+  const int U = choose_unroll(B, plane, false);
+  const int epb = kThreads * 4 * (U == 4 ? 2 : U);
+  const unsigned chunks = (unsigned)((plane + epb - 1) / epb);
+  const float oml = 1.0f - lam;
+  dim3 grid(chunks, (unsigned)B), block(kThreads);
+  if (U >= 2)
+    hipLaunchKernelGGL((mix_warp_karg_kernel<false, 2>), grid, block, 0, s, x, y, pack, lam, oml,
+                       nullptr, nullptr, 0, B, C, T, epb);
+  else
+    hipLaunchKernelGGL((mix_warp_karg_kernel<false, 1>), grid, block, 0, s, x, y, pack, lam, oml,
+                       nullptr, nullptr, 0, B, C, T, epb);
+  return (int)hipGetLastError();
 }
 
 int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, const int32_t* mix_idx,

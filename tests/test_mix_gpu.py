@@ -264,3 +264,40 @@ def test_large_plan_upload_goes_through_the_fetch_kernel(device):
         ref = O.augment(method, x, labels, frames, wav, 11)
         assert np.array_equal(mix, ref["mix"])
         assert np.abs(y.cpu().numpy() - ref["y"]).max() <= WAVE_TOL
+
+
+@pytest.mark.parametrize("B,C,T", [(256, 4, 5000), (7, 1, 2500), (33, 128, 128)])
+def test_kernarg_splice_equals_the_copy_path(B, C, T, device):
+    """pcgmix_mix_karg_f32 (index block as int16 in the kernel arguments, what the drop-in step
+    launches for plain batches up to 256 samples) == pcgmix_mix_warp_f32 on an uploaded index
+    block, bit for bit; shapes it cannot take are refused."""
+    import ctypes
+    from pcgmix_amd import _lib
+    lib = _lib.load()
+    if T >= 2500:
+        x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=2000 if T == 5000 else 1000, seed=B)
+    else:                                                    # spectrogram-shaped: boundaries in columns
+        rs = np.random.RandomState(B)
+        x = rs.standard_normal((B, C, T)).astype(np.float32)
+        frames = np.concatenate([np.zeros((B, 1), np.int64),
+                                 np.sort(rs.randint(1, T + 1, (B, 4)), axis=1)], axis=1)
+    mix = np.random.RandomState(B).permutation(B)
+    lam = float(np.float32(0.2718))
+    data = torch.from_numpy(x).to(device)
+    fr = torch.from_numpy(frames.astype(np.int32)).to(device)
+    mx = torch.from_numpy(mix.astype(np.int32)).to(device)
+    ref, out = torch.empty_like(data), torch.empty_like(data)
+    augmentations.launch_mix(data, ref, fr.data_ptr(), mx.data_ptr(), None, lam, None, None, 0, B, C, T)
+    fr16, mx16 = frames.astype(np.int16), mix.astype(np.int16)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    _lib.check(lib.pcgmix_mix_karg_f32(data.data_ptr(), out.data_ptr(), fr16.ctypes.data, mx16.ctypes.data,
+                                       ctypes.c_float(lam), B, C, T, st), "karg")
+    assert torch.equal(out, ref) and not torch.equal(out, data)
+    u = ctypes.c_int()
+    assert lib.pcgmix_mix_karg_variant(B, C, T, ctypes.byref(u)) == 1 and u.value in (1, 2)
+    assert lib.pcgmix_mix_karg_variant(257, C, T, ctypes.byref(u)) == 0
+    assert lib.pcgmix_mix_karg_variant(B, C, 32768, ctypes.byref(u)) == 0
+    assert lib.pcgmix_mix_karg_f32(data.data_ptr(), out.data_ptr(), fr16.ctypes.data, mx16.ctypes.data,
+                                   ctypes.c_float(lam), 257, C, T, st) != 0
+    assert lib.pcgmix_mix_karg_f32(data.data_ptr(), out.data_ptr(), fr16.ctypes.data, mx16.ctypes.data,
+                                   ctypes.c_float(lam), B, C, T - 1, st) != 0       # T % 4
