@@ -126,11 +126,16 @@ def karg_unroll(B, C, T, warp):
 def mix_kernel_name(B, C, T, warp):
     """Name of the instantiation the drop-in step launches for this problem (asked from the
     library: the choice of lane width and unroll lives there)."""
-    import ctypes
-    from pcgmix_amd import _lib
     u = karg_unroll(B, C, T, warp)
     if u:
         return f"pcgmix::mix_warp_karg_kernel<false, {u}>"
+    return mix_warp_kernel_name(B, C, T, warp)
+
+
+def mix_warp_kernel_name(B, C, T, warp):
+    """Name of the instantiation pcgmix_mix_warp_f32 launches (index block in device memory)."""
+    import ctypes
+    from pcgmix_amd import _lib
     vec, unroll = ctypes.c_int(), ctypes.c_int()
     _lib.check(_lib.load().pcgmix_mix_variant(B, C, T, int(bool(warp)), 1, ctypes.byref(vec),
                                               ctypes.byref(unroll)), "pcgmix_mix_variant")
@@ -478,6 +483,8 @@ def measured_traffic(method, B, C, T):
     committed file, NOT measured in this run, and only for exactly this workload; else None."""
     import glob
     key = f"{method} ({B},{C},{T})"
+    if karg_unroll(B, C, T, "magwarp" in method):
+        key = f"{method} [kernarg] ({B},{C},{T})"           # the instantiation that runs at this size
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mix_roofline.json")), reverse=True):
         try:
             d = json.load(open(path))

@@ -11,6 +11,8 @@ modes   splice   durratiomixup                       (partner read inside blende
         warp     durmixmagwarp(0.2,4)                (same traffic + spline in registers)
         copy     durratiomixup on zero-length states (own read + write only: 8*C*T*B bytes, known
                  exactly — the calibration point for the FETCH_SIZE x2 correction)
+        karg     durratiomixup through pcgmix_mix_karg_f32 (index block in the kernel arguments:
+                 the instantiation the drop-in step launches for B <= 256)
 Writes <mode>_<B>.json next to the traces with the exact byte counts of the batch it ran.
 """
 import json
@@ -45,12 +47,23 @@ knots_ptr = op_ptr = None
 if plan.knots is not None:
     op = augmentations.spline_operator(device, T, plan.n_knots)
     knots_ptr, op_ptr = base + offs["knots"], op.data_ptr()
-for _ in range(iters):
-    augmentations.launch_mix(data, out, base + offs["frames"], base + offs["mix"], None,
-                             float(plan.lam32), knots_ptr, op_ptr, plan.n_knots, B, C, T)
+if mode == "karg":
+    import ctypes
+    from pcgmix_amd import _lib
+    fr16, mx16 = frames.astype(np.int16), plan.mix.astype(np.int16)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    for _ in range(iters):
+        _lib.check(_lib.load().pcgmix_mix_karg_f32(data.data_ptr(), out.data_ptr(), fr16.ctypes.data,
+                                                   mx16.ctypes.data, ctypes.c_float(float(plan.lam32)),
+                                                   B, C, T, st), "pcgmix_mix_karg_f32")
+else:
+    for _ in range(iters):
+        augmentations.launch_mix(data, out, base + offs["frames"], base + offs["mix"], None,
+                                 float(plan.lam32), knots_ptr, op_ptr, plan.n_knots, B, C, T)
 torch.cuda.synchronize()
 info = {"mode": mode, "method": method, "B": B, "C": C, "T": T, "iters": iters,
-        "kernel": bench.mix_kernel_name(B, C, T, plan.knots is not None),
+        "kernel": bench.mix_kernel_name(B, C, T, plan.knots is not None) if mode == "karg" else
+        bench.mix_warp_kernel_name(B, C, T, plan.knots is not None),
         "exact_bytes": bench.exact_mix_bytes(frames, plan.mix, C, T),
         "contract_12CT_bytes": 12.0 * B * C * T, "own_plus_write_bytes": 8.0 * B * C * T}
 os.makedirs(out_dir, exist_ok=True)

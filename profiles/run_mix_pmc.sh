@@ -7,7 +7,9 @@ REPO="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$REPO/gpurun_out/pmc"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for wl in "copy 16384" "splice 16384" "warp 16384" "copy 256" "splice 256" "warp 256"; do
+# PCGMIX_PMC_WORKLOADS="karg 256;splice 256" re-profiles a subset (the summary keeps the rest)
+IFS=';' read -r -a WLS <<< "${PCGMIX_PMC_WORKLOADS:-copy 16384;splice 16384;warp 16384;copy 256;splice 256;warp 256;karg 256}"
+for wl in "${WLS[@]}"; do
   set -- $wl
   mode=$1; B=$2
   iters=20; [ "$B" = "256" ] && iters=200

@@ -21,7 +21,7 @@ csv.field_size_limit(1 << 30)
 PEAK = 8000.0
 
 
-def rows(path_glob, name_filter="mix_warp_kernel"):
+def rows(path_glob, name_filter="mix_warp_"):
     out = []
     for path in glob.glob(path_glob):
         with open(path, newline="") as f:
@@ -35,6 +35,12 @@ def summ(v):
     return {"launches": len(v), "mean": statistics.mean(v), "min": min(v), "max": max(v)}
 
 
+# Workloads collected earlier stay in the file (a later run may re-profile a subset only).
+prev = {}
+try:
+    prev = json.load(open(os.path.join(HERE, "r2_mix_roofline.json"))).get("workloads", {})
+except (OSError, ValueError):
+    pass
 result = {"round": 2, "collected_at": head, "peak_GBs": PEAK,
           "how": "profiles/run_mix_pmc.sh: per workload `rocprofv3 --kernel-trace --stats`, "
                  "`rocprofv3 --pmc FETCH_SIZE`, `rocprofv3 --pmc WRITE_SIZE` (separate passes) around "
@@ -63,7 +69,8 @@ for info_path in sorted(glob.glob(os.path.join(src, "mixprobe_*.json"))):
     fetch_b, write_b = statistics.mean(fetch) * 1024.0, statistics.mean(write) * 1024.0
     hbm = 2.0 * fetch_b + write_b
     B, C, T = info["B"], info["C"], info["T"]
-    name = {"splice": "durratiomixup", "warp": "durmixmagwarp(0.2,4)", "copy": "copy (no blended range)"}[info["mode"]]
+    name = {"splice": "durratiomixup", "warp": "durmixmagwarp(0.2,4)", "copy": "copy (no blended range)",
+            "karg": "durratiomixup [kernarg]"}[info["mode"]]
     w = {"kernel": info["kernel"], "grid": [tr[0]["Grid_Size_X"], tr[0]["Grid_Size_Y"]],
          "vgpr": int(tr[0]["VGPR_Count"]), "launch_ns": summ(dur),
          "FETCH_SIZE_KB": summ(fetch), "WRITE_SIZE_KB": summ(write),
@@ -84,4 +91,10 @@ for info_path in sorted(glob.glob(os.path.join(src, "mixprobe_*.json"))):
           f"{w['read_bytes_expected'] / 1e6:9.1f})  write {write_b / 1e6:9.1f} MB  counter-bytes "
           f"{hbm / ns:7.0f} GB/s = {hbm / ns / PEAK:.3f}  exact {w['frac_on_exact_bytes']:.3f}  12CT "
           f"{w['frac_on_12CT_model']:.3f}")
+for k, v in prev.items():
+    if k not in result["workloads"]:
+        v.setdefault("collected_at", "9a5355a")
+        result["workloads"][k] = v
+for k, v in result["workloads"].items():
+    v.setdefault("collected_at", head)
 json.dump(result, open(os.path.join(HERE, "r2_mix_roofline.json"), "w"), indent=1)
