@@ -109,41 +109,72 @@ def _potes_direct(model: torch.nn.Module, data: torch.Tensor):
     return None
 
 
+class _PotesChain:
+    """d (sum_b seed_b . logits_b) / d input of a frozen CNN_potes without autograd, for one batch
+    shape: conv stack forward saving its ReLU / max-pool routing (``forward``) -> head (split-K
+    product, dz = (z > 0) * (seed W2), dx = dz W1: ``pcgmix_potes_head_saliency_f32``) -> input
+    gradient from the saved routing (``backward``).  Six launches; the logits are never formed
+    (models.py:444-465 forward, autograd backward).  The buffers between the stages are owned by
+    the object, so the two halves can be enqueued separately: the forward is the only kernel that
+    reads the batch — a captured saliency pass launches it eagerly on the caller's tensor and
+    captures the rest, instead of copying 20 MB into a static input first."""
+
+    def __init__(self, m, shape, device):
+        B, C, T = shape
+        lib = _lib.load()
+        self.m, self.shape = m, (B, C, T)
+        self.N, self.P2, self.K = B * 4, lib.pcgmix_potes_out_len(T), m.dimreduc.in_features
+        self.ncls = m.linear.weight.shape[0]
+        if self.K != 16 * self.P2:
+            raise ValueError("model head does not match the input shape")
+        f32 = dict(dtype=torch.float32, device=device)
+        u8 = dict(dtype=torch.uint8, device=device)
+        self.h2 = torch.empty((self.N, 4, self.P2), **f32)
+        self.m2 = torch.empty(lib.pcgmix_potes_mask_bytes(self.N, T, 2), **u8)
+        self.s1 = torch.empty(lib.pcgmix_potes_mask_bytes(self.N, T, 1), **u8)
+        self.partial = torch.empty((lib.pcgmix_skinny_linear_splits(B, self.K), B, 20), **f32)
+        self.dz, self.gfeat = torch.empty((B, 20), **f32), torch.empty((B, self.K), **f32)
+
+    def _weights(self):
+        m = self.m
+        c1, c2 = m.cnn1[0][0], m.cnn1[1][0]
+        return tuple(t.detach().contiguous() for t in (c1.weight, c1.bias, c2.weight, c2.bias))
+
+    def forward(self, data: torch.Tensor) -> None:
+        B, C, T = self.shape
+        if tuple(data.shape) != self.shape or data.dtype != torch.float32 or not data.is_contiguous():
+            raise ValueError("batch does not match the saliency chain's shape")
+        w1, b1, w2, b2 = self._weights()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(data.device).cuda_stream)
+        _lib.check(_lib.load().pcgmix_potes_stack_fwd_save_f32(
+            data.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+            self.h2.data_ptr(), self.m2.data_ptr(), self.s1.data_ptr(), self.N, T, None, 0, None, 0,
+            stream), "pcgmix_potes_stack_fwd_save_f32")
+
+    def backward(self, seed: torch.Tensor) -> torch.Tensor:
+        B, C, T = self.shape
+        m, lib = self.m, _lib.load()
+        if seed.shape != (B, self.ncls) or seed.dtype != torch.float32 or not seed.is_contiguous():
+            raise ValueError("saliency seed does not match the model head")
+        w1, _b1, w2, _b2 = self._weights()
+        W1, W2 = m.dimreduc.weight.detach().contiguous(), m.linear.weight.detach().contiguous()
+        bh = m.dimreduc.bias.detach() if m.dimreduc.bias is not None else None
+        gx = torch.empty((B, C, T), dtype=torch.float32, device=seed.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(seed.device).cuda_stream)
+        _lib.check(lib.pcgmix_potes_head_saliency_f32(
+            self.h2.data_ptr(), W1.data_ptr(), bh.data_ptr() if bh is not None else None, W2.data_ptr(),
+            seed.data_ptr(), self.partial.data_ptr(), self.dz.data_ptr(), self.gfeat.data_ptr(), B,
+            self.K, self.ncls, stream), "pcgmix_potes_head_saliency_f32")
+        _lib.check(lib.pcgmix_potes_stack_input_grad_mask_f32(
+            self.gfeat.data_ptr(), self.m2.data_ptr(), self.s1.data_ptr(), w1.data_ptr(), w2.data_ptr(),
+            gx.data_ptr(), self.N, T, stream), "pcgmix_potes_stack_input_grad_mask_f32")
+        return gx
+
+
 def _potes_input_gradient(m, data: torch.Tensor, seed: torch.Tensor) -> torch.Tensor:
-    """d (sum_b seed_b . logits_b) / d input of a frozen CNN_potes without autograd: conv stack
-    forward saving its ReLU / max-pool routing -> head (split-K product, dz = (z > 0) * (seed W2),
-    dx = dz W1: ``pcgmix_potes_head_saliency_f32``) -> input gradient from the saved routing.
-    Six launches; the logits are never formed (models.py:444-465 forward, autograd backward)."""
-    B, C, T = data.shape
-    lib = _lib.load()
-    dev = data.device
-    c1, c2 = m.cnn1[0][0], m.cnn1[1][0]
-    w1, b1, w2, b2 = (t.detach().contiguous() for t in (c1.weight, c1.bias, c2.weight, c2.bias))
-    W1, W2 = m.dimreduc.weight.detach().contiguous(), m.linear.weight.detach().contiguous()
-    bh = m.dimreduc.bias.detach() if m.dimreduc.bias is not None else None
-    N, P2, K, ncls = B * 4, lib.pcgmix_potes_out_len(T), m.dimreduc.in_features, W2.shape[0]
-    if K != 16 * P2 or seed.shape != (B, ncls) or seed.dtype != torch.float32 or not seed.is_contiguous():
-        raise ValueError("saliency seed / model head do not match the input shape")
-    f32 = dict(dtype=torch.float32, device=dev)
-    u8 = dict(dtype=torch.uint8, device=dev)
-    h2 = torch.empty((N, 4, P2), **f32)
-    m2 = torch.empty(lib.pcgmix_potes_mask_bytes(N, T, 2), **u8)
-    s1 = torch.empty(lib.pcgmix_potes_mask_bytes(N, T, 1), **u8)
-    partial = torch.empty((lib.pcgmix_skinny_linear_splits(B, K), B, 20), **f32)
-    dz, gfeat, gx = torch.empty((B, 20), **f32), torch.empty((B, K), **f32), torch.empty_like(data)
-    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    x = data.detach()
-    _lib.check(lib.pcgmix_potes_stack_fwd_save_f32(
-        x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), h2.data_ptr(),
-        m2.data_ptr(), s1.data_ptr(), N, T, None, 0, None, 0, stream), "pcgmix_potes_stack_fwd_save_f32")
-    _lib.check(lib.pcgmix_potes_head_saliency_f32(
-        h2.data_ptr(), W1.data_ptr(), bh.data_ptr() if bh is not None else None, W2.data_ptr(),
-        seed.data_ptr(), partial.data_ptr(), dz.data_ptr(), gfeat.data_ptr(), B, K, ncls, stream),
-        "pcgmix_potes_head_saliency_f32")
-    _lib.check(lib.pcgmix_potes_stack_input_grad_mask_f32(
-        gfeat.data_ptr(), m2.data_ptr(), s1.data_ptr(), w1.data_ptr(), w2.data_ptr(), gx.data_ptr(),
-        N, T, stream), "pcgmix_potes_stack_input_grad_mask_f32")
-    return gx
+    chain = _PotesChain(m, tuple(data.shape), data.device)
+    chain.forward(data.detach())
+    return chain.backward(seed)
 
 
 def input_gradient_seeded(model: torch.nn.Module, data: torch.Tensor, seed: torch.Tensor):
@@ -204,9 +235,16 @@ class _SaliencyGraph:
         self.seed = torch.zeros(B, num_classes, device=device)
         self.seed[:, 0] = 1
         self.fr = torch.zeros(B, 5, dtype=torch.int32, device=device)
+        # A frozen fused CNN_potes: only the conv stack's forward reads the batch — it is launched
+        # eagerly on the caller's tensor and everything behind it is captured; other models get
+        # the batch copied into the static input and the whole pass captured.
+        m = _potes_direct(model, self.x)
+        self.chain = _PotesChain(m, (B, C, T), device) if m is not None else None
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
+            if self.chain is not None:
+                self.chain.forward(self.x)
             for _ in range(3):
                 self._run()
         torch.cuda.current_stream(device).wait_stream(side)
@@ -216,14 +254,21 @@ class _SaliencyGraph:
             self.sal = self._run()
 
     def _run(self):
-        return saliency_post(input_gradient_seeded(self.model, self.x, self.seed),
-                             self.fr.data_ptr(), self.k)
+        grad = self.chain.backward(self.seed) if self.chain is not None \
+            else input_gradient_seeded(self.model, self.x, self.seed)
+        return saliency_post(grad, self.fr.data_ptr(), self.k)
+
+    def _enqueue(self, data):
+        if self.chain is not None:
+            self.chain.forward(data.detach())
+        else:
+            self.x.copy_(data, non_blocking=True)
+        self.graph.replay()
 
     def replay(self, data):
-        """``seed`` and ``fr`` are in place (``pcgmix_ctx_salopt_begin`` on this stream): copy the
-        batch in and replay; returns the graph's static output, valid until the next replay."""
-        self.x.copy_(data, non_blocking=True)
-        self.graph.replay()
+        """``seed`` and ``fr`` are in place (``pcgmix_ctx_salopt_begin`` on this stream): run the
+        pass on ``data``; returns the graph's static output, valid until the next replay."""
+        self._enqueue(data)
         return self.sal
 
     def run(self, data, frames_np, target_ohe=None, keep: bool = True):
@@ -231,11 +276,10 @@ class _SaliencyGraph:
         ``keep`` False: the returned maps are the graph's static output, valid until the next
         run — for a caller that consumes them right away."""
         from .augmentations import upload_into
-        self.x.copy_(data, non_blocking=True)
         if target_ohe is not None:
             class_seed(target_ohe, self.seed)
         upload_into(self.fr, frames_np.astype(np.int32))
-        self.graph.replay()
+        self._enqueue(data)
         return self.sal.clone() if keep else self.sal
 
 
