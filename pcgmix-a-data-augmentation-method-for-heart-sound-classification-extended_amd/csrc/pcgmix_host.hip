@@ -431,6 +431,42 @@ __global__ __launch_bounds__(256) void label_argmax_kernel(const int64_t* __rest
     __hip_atomic_store(flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// label_argmax_kernel that also delivers the step's boundaries: frames (B,5) arrive as int16 in
+// the kernel ARGUMENTS (2.5 KB; B <= kPackB, T <= 32767) and are written out as the int32 array
+// the saliency post-processing, the search and the splice read — one launch instead of a launch
+// and a 5 KB host-to-device copy.
+struct FramePack {
+  int32_t w[pcgmix::kPackB * 5 / 2];
+};
+__global__ __launch_bounds__(256) void label_frames_kernel(const int64_t* __restrict__ ohe, int K,
+                                                           int B, int32_t* __restrict__ lab,
+                                                           uint32_t* flag, uint32_t token,
+                                                           float* __restrict__ seed,
+                                                           const FramePack fp,
+                                                           int32_t* __restrict__ frames_out) {
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int64_t* row = ohe + (size_t)b * K;
+    int best = 0;
+    int64_t bv = row[0];
+    for (int c = 1; c < K; ++c) {
+      const int64_t v = row[c];
+      if (v > bv) { bv = v; best = c; }
+    }
+    lab[b] = best;
+    if (seed)
+      for (int c = 0; c < K; ++c) seed[(size_t)b * K + c] = c == best ? 1.f : 0.f;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  // the boundaries after the flag: the host does not wait for them
+  for (int i = threadIdx.x; i < B * 5; i += blockDim.x) {
+    const int w = fp.w[i >> 1];
+    frames_out[i] = (i & 1) ? (w >> 16) : ((int)((unsigned)w << 16) >> 16);
+  }
+}
+
 // Host-to-device copy as a kernel: n16 16-byte words from device-readable host memory (a pinned
 // staging slot) to device memory.  hipMemcpyAsync does the same with a blit kernel up to 16 KB;
 // above that it takes the SDMA path, which costs ~25 us of stream stall per copy on MI355X
@@ -674,8 +710,8 @@ struct DeviceGuard {      // make the context's device current for the call
 
 // Enqueue the label arg-max for a (B, K) one-hot matrix on `s`; the labels land in c->lab and the
 // flag word takes the returned token.
-hipError_t labels_begin(pcgmix_ctx* c, const int64_t* ohe_dev, int K, int B, hipStream_t s,
-                        float* seed = nullptr) {
+// Capture check, label memory sized for B, next token: what precedes the launch of a label kernel.
+hipError_t labels_prepare(pcgmix_ctx* c, int B, hipStream_t s) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
     return hipErrorStreamCaptureUnsupported;     // a host wait cannot be captured
@@ -692,6 +728,13 @@ hipError_t labels_begin(pcgmix_ctx* c, const int64_t* ohe_dev, int K, int B, hip
   }
   ++c->token;
   if (c->token == 0) c->token = 1;
+  return hipSuccess;
+}
+
+hipError_t labels_begin(pcgmix_ctx* c, const int64_t* ohe_dev, int K, int B, hipStream_t s,
+                        float* seed = nullptr) {
+  const hipError_t e = labels_prepare(c, B, s);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(label_argmax_kernel, dim3(1), dim3(256), 0, s, ohe_dev, K, B, c->lab, c->flag,
                      c->token, seed);
   return hipGetLastError();
@@ -935,6 +978,31 @@ extern "C" int pcgmix_ctx_salopt_begin(pcgmix_ctx* c, const int64_t* target_ohe_
   DeviceGuard guard(c->device);
   hipError_t e = guard.err;
   if (e != hipSuccess) return (int)e;
+  if (target_ohe_dev && B <= pcgmix::kPackB && T <= 32767) {
+    // boundaries in the label kernel's arguments: one launch, no copy
+    FramePack fp;
+    int16_t* p16 = reinterpret_cast<int16_t*>(fp.w);
+    int bad16 = 0;
+    int64_t longest = 0;
+    for (int b = 0; b < B; ++b) {
+      const int64_t* r = frames + (size_t)b * 5;
+      if (r[0] < 0) bad16 = bad16 ? bad16 : -1;
+      for (int k = 0; k < 4; ++k) {
+        if (r[k + 1] < r[k]) bad16 = bad16 ? bad16 : -1;
+        if (r[k + 1] - r[k] > longest) longest = r[k + 1] - r[k];
+      }
+      if (r[4] > T) bad16 = bad16 ? bad16 : -2;
+      for (int k = 0; k < 5; ++k) p16[b * 5 + k] = (int16_t)r[k];
+    }
+    if (bad16) return bad16;
+    if ((e = labels_prepare(c, B, s)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(label_frames_kernel, dim3(1), dim3(256), 0, s, target_ohe_dev, num_classes, B,
+                       c->lab, c->flag, c->token, seed_out, fp, frames_dst_dev);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    c->sal_B = B;
+    c->sal_max_len = (int)(longest > T ? T : longest);
+    return hipSuccess;
+  }
   if (target_ohe_dev && (e = labels_begin(c, target_ohe_dev, num_classes, B, s, seed_out)) != hipSuccess)
     return (int)e;
   const int my_slot = c->next;
@@ -1002,18 +1070,25 @@ extern "C" int pcgmix_ctx_salopt_finish(pcgmix_ctx* c, const float* x, float* y,
     for (int b = 0; b < B; ++b) lab64[(size_t)b] = c->lab[b];
     labels = lab64.data();
   }
-  draw_partners(c, labels, B, mix_out, reinterpret_cast<int32_t*>(sl.pinned));
-  if ((e = hipMemcpyAsync(sl.dev, sl.pinned, n_mix_pad * 4, hipMemcpyHostToDevice, s)) != hipSuccess)
-    return (int)e;
-  const int32_t* mix_dev = reinterpret_cast<const int32_t*>(sl.dev);
+  // Up to 256 samples the partners travel in the arguments of the two launches (PartnerPack);
+  // beyond that, in a small copy to the slot's device twin.
+  int16_t mix16[pcgmix::kPackB];
+  const bool in_args = B <= pcgmix::kPackB;
+  draw_partners(c, labels, B, mix_out, reinterpret_cast<int32_t*>(sl.pinned), in_args ? mix16 : nullptr);
+  const int32_t* mix_dev = nullptr;
+  if (!in_args) {
+    if ((e = hipMemcpyAsync(sl.dev, sl.pinned, n_mix_pad * 4, hipMemcpyHostToDevice, s)) != hipSuccess)
+      return (int)e;
+    mix_dev = reinterpret_cast<const int32_t*>(sl.dev);
+  }
   int err = pcgmix::launch_salopt_search(sal, frames_dev, mix_dev, lam, mode, nullptr, c->ws,
                                          c->sal_B == B ? c->sal_max_len : 0, B, T, s,
                                          sl.pinned + n_mix_pad * 4, sl.dev + n_mix_pad * 4,
-                                         (int)(nk * sizeof(double) / 16));
+                                         (int)(nk * sizeof(double) / 16), in_args ? mix16 : nullptr);
   if (err) return err;
   err = pcgmix::launch_mix_warp(x, y, frames_dev, mix_dev, nullptr, lam, knots_dev, op_dev,
                                 knots ? n_knots : 0, nullptr, B, C, T, s, nullptr, nullptr, 0,
-                                static_cast<const float2*>(c->ws));
+                                static_cast<const float2*>(c->ws), in_args ? mix16 : nullptr);
   if (err) return err;
   return (int)slot_commit(c, my_slot, s);
 }

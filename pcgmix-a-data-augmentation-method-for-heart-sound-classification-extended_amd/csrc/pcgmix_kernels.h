@@ -37,13 +37,35 @@ int launch_mix_warp(const float* x, float* y, const int32_t* frames, const int32
                     const int32_t* off, float lam, const double* knots, const double* spline_op,
                     int n_knots, const int32_t* zero_rect, int B, int C, int T, hipStream_t s,
                     const void* pay_src, void* pay_dst, int pay_n16,
-                    const float2* disp_part = nullptr);
+                    const float2* disp_part = nullptr, const int16_t* partners16 = nullptr);
 
 // pcgmix_mix.hip: the plain splice (no offsets, no warp, no rectangle) with its index block in
 // the kernel ARGUMENTS instead of device memory: frames (B,5) and partners (B) as int16 in host
 // memory, B <= kPackB, T <= 32767, T % 4 == 0, x and y 16-byte aligned.  Returns
 // hipErrorInvalidValue when the shape does not qualify (the caller then takes the copy path).
 constexpr int kPackB = 256;
+// Partner indices of up to kPackB samples as int16, two per dword, passed BY VALUE in the kernel
+// arguments of the displacement search and of the splice (saliency-guided step: the partners are
+// the only per-step index data that depends on the labels — carried by the launches themselves,
+// they need no host-to-device copy).  n == 0: not in use, the kernels read mix_idx from memory.
+struct PartnerPack {
+  int32_t w[kPackB / 2];
+  int n;
+};
+__device__ __forceinline__ int partner_get(const PartnerPack& p, int b) {
+  const int w = p.w[b >> 1];
+  return (b & 1) ? (w >> 16) : ((int)((unsigned)w << 16) >> 16);
+}
+inline PartnerPack make_partner_pack(const int16_t* partners16, int B) {
+  PartnerPack pk;
+  pk.n = 0;
+  if (partners16 && B > 0 && B <= kPackB) {
+    int16_t* p16 = reinterpret_cast<int16_t*>(pk.w);
+    for (int b = 0; b < B; ++b) p16[b] = partners16[b];
+    pk.n = B;
+  }
+  return pk;
+}
 int launch_mix_karg(const float* x, float* y, const int16_t* frames16, const int16_t* mix16, float lam,
                     int B, int C, int T, hipStream_t s);
 
@@ -54,7 +76,7 @@ int launch_mix_karg(const float* x, float* y, const int16_t* frames16, const int
 int launch_salopt_search(const float* sal, const int32_t* frames, const int32_t* mix_idx, float lam,
                          int mode, int32_t* disp, void* workspace, int max_len, int B, int T,
                          hipStream_t s, const void* pay_src = nullptr, void* pay_dst = nullptr,
-                         int pay_n16 = 0);
+                         int pay_n16 = 0, const int16_t* partners16 = nullptr);
 
 }  // namespace pcgmix
 #endif

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
     const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots,
     const int32_t* __restrict__ zero_rect, int B, int C, int T, int epb,
     const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst, int pay_n16,
-    const float2* __restrict__ disp_part) {
+    const float2* __restrict__ disp_part, const PartnerPack pk) {
   extern __shared__ __align__(16) double lds[];  // spline records per channel, then thresholds
 
   // Step payload (pcgmix_ctx_set_payload): a few KB that travelled with the index block and
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
 
   const int b = blockIdx.z * kBatchPerGridZ + blockIdx.y;
   if (b >= B) return;  // block-uniform
-  int m = mix_idx[b];
+  int m = pk.n ? partner_get(pk, b) : mix_idx[b];
   m = (m < 0 || m >= B) ? b : m;  // memory safety; validated on the host as well
   const StateMap sm = make_state_map(frames, off, b, m, T, disp_part);
   mix_body<VEC, WARP, U>(x, y, lam, oml, knots, spline_op, n_knots, zero_rect, C, T, epb, b, m, sm, lds);
@@ -439,7 +439,7 @@ int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, con
                             const int32_t* off, float lam, const double* knots,
                             const double* spline_op, int n_knots, const int32_t* zero_rect, int B,
                             int C, int T, hipStream_t s, const void* pay_src_v, void* pay_dst_v,
-                            int pay_n16, const float2* disp_part) {
+                            int pay_n16, const float2* disp_part, const int16_t* partners16) {
   using namespace pcgmix;
   const uint4* pay_src = static_cast<const uint4*>(pay_src_v);
   uint4* pay_dst = static_cast<uint4*>(pay_dst_v);
@@ -447,7 +447,8 @@ int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, con
                                       ((reinterpret_cast<uintptr_t>(pay_src) |
                                         reinterpret_cast<uintptr_t>(pay_dst)) & 15))))
     return hipErrorInvalidValue;
-  if (!x || !y || !frames || !mix_idx || x == y) return hipErrorInvalidValue;
+  const PartnerPack pk = make_partner_pack(partners16, B);
+  if (!x || !y || !frames || (!mix_idx && !pk.n) || x == y) return hipErrorInvalidValue;
   if (B < 0 || C <= 0 || T <= 0) return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
   const bool warp = knots != nullptr;
@@ -474,7 +475,7 @@ int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, con
 #define PCGMIX_LAUNCH(V, W, UU)                                                              \
   hipLaunchKernelGGL((mix_warp_kernel<V, W, UU>), grid, block, lds, s, x, y, frames, mix_idx, \
                      off, lam, oml, knots, spline_op, n_knots, zero_rect, B, C, T, epb, pay_src,  \
-                     pay_dst, pay_n16, disp_part)
+                     pay_dst, pay_n16, disp_part, pk)
 #define PCGMIX_LAUNCH_U(W)                                \
   do {                                                    \
     if (U == 4) PCGMIX_LAUNCH(4, W, 4);                   \

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
     const float* __restrict__ sal, const int32_t* __restrict__ frames,
     const int32_t* __restrict__ mix_idx, float lam, float oml, float2* __restrict__ part, int B,
     int T, int max_len, const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst,
-    int pay_n16) {
+    int pay_n16, const PartnerPack pk) {
   extern __shared__ __align__(16) float smem[];
   // Side job of the LAST block in launch order (shortest state, last candidate slice: it almost
   // never has candidates of its own): copy pay_n16 16-byte words from pay_src — host memory the
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   const int b = (int)((blockIdx.x + (unsigned)z * (gridDim.x / kDispSplit + 3)) % gridDim.x);
   const int k = (0x2013 >> (4 * blockIdx.y)) & 3;   // blockIdx.y 0,1,2,3 -> state 3,1,0,2
   float2* out = part + ((size_t)b * 4 + k) * kDispSplit + z;
-  int m = mix_idx[b];
+  int m = pk.n ? partner_get(pk, b) : mix_idx[b];
   m = (m < 0 || m >= B) ? b : m;
   int a1 = frames[b * 5 + k], e1 = frames[b * 5 + k + 1];
   int a2 = frames[m * 5 + k], e2 = frames[m * 5 + k + 1];
@@ -492,15 +492,16 @@ extern "C" int pcgmix_salopt_mix_warp_f32(const float* x, float* y, const float*
 int pcgmix::launch_salopt_search(const float* sal, const int32_t* frames, const int32_t* mix_idx,
                                  float lam, int mode, int32_t* disp, void* workspace, int max_len,
                                  int B, int T, hipStream_t s, const void* pay_src_v, void* pay_dst_v,
-                                 int pay_n16) {
+                                 int pay_n16, const int16_t* partners16) {
   using namespace pcgmix;
+  const PartnerPack pk = make_partner_pack(partners16, B);
   const uint4* pay_src = static_cast<const uint4*>(pay_src_v);
   uint4* pay_dst = static_cast<uint4*>(pay_dst_v);
   if (pay_n16 < 0 || (pay_n16 > 0 && (!pay_src || !pay_dst ||
                                       ((reinterpret_cast<uintptr_t>(pay_src) |
                                         reinterpret_cast<uintptr_t>(pay_dst)) & 15))))
     return hipErrorInvalidValue;
-  if (!sal || !frames || !mix_idx || !workspace) return hipErrorInvalidValue;
+  if (!sal || !frames || (!mix_idx && !pk.n) || !workspace) return hipErrorInvalidValue;
   if (B < 0 || B > 65535 || T <= 0 || (mode != 0 && mode != 1)) return hipErrorInvalidValue;
   if (reinterpret_cast<uintptr_t>(workspace) & 7) return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
@@ -519,10 +520,10 @@ int pcgmix::launch_salopt_search(const float* sal, const int32_t* frames, const 
   float2* part = static_cast<float2*>(workspace);
   if (mode == 0)
     hipLaunchKernelGGL(salopt_disp_kernel<0>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
-                       part, B, T, max_len, pay_src, pay_dst, pay_n16);
+                       part, B, T, max_len, pay_src, pay_dst, pay_n16, pk);
   else
     hipLaunchKernelGGL(salopt_disp_kernel<1>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
-                       part, B, T, max_len, pay_src, pay_dst, pay_n16);
+                       part, B, T, max_len, pay_src, pay_dst, pay_n16, pk);
   if (disp)
     hipLaunchKernelGGL(salopt_finalize_kernel, dim3((unsigned)((B * 4 + 255) / 256)), dim3(256), 0, s,
                        part, disp, B * 4);
