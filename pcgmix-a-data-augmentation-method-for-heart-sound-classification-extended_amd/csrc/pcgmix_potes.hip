@@ -348,7 +348,7 @@ constexpr int kBwdNJ = 2 * kBwdNP;              // 256 conv2 outputs, j = 2p0-4+
 constexpr int kBwdNQ = 260;                     // a1 positions q = 2p0-5+qq
 constexpr int kBwdNX = 524;                     // x positions 4p0-11+u
 constexpr int kBwdNS = 2 * kBwdTP;              // 250 owned j / owned q
-constexpr int kBwdNI = 4 * kBwdTP;              // 500 owned i
+// (4 * kBwdTP = 500 owned conv1 outputs i per tile)
 constexpr int kBwdNIpad = 512;
 constexpr int kNAcc = 53;                       // private accumulators per lane (see below)
 
@@ -370,7 +370,6 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
   __shared__ __align__(16) float a1s[kC1 * kBwdNQ];
   __shared__ __align__(16) uint8_t sel1[kC1 * kBwdNQ];
   __shared__ __align__(16) float dz2s[kC2 * (kBwdNJ + 12)];   // +12: read window of the last lanes
-  __shared__ __align__(16) float dz1s[kC1 * kBwdNIpad];
   __shared__ float red[4 * kNAcc];
   constexpr int kDz2Row = kBwdNJ + 12;
   const PotesDims d = potes_dims(T);
@@ -503,23 +502,39 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
             for (int k = 0; k < kK; ++k) da1[c][u] = fmaf(dw[u + 5 - k], w[k], da1[c][u]);
         }
       }
+      // ... routed through pool1/ReLU1 to the conv1 outputs i = 4p0 + 8*lane + (0..7), and used
+      // right here for gw1 / gb1: the lane that owns these a1 positions for channels 2w, 2w+1 is
+      // the lane that owns the corresponding conv1 outputs — dz1 never goes through LDS (it did:
+      // 16 KB per block, two 32-byte-stride accesses per lane and a barrier, for nothing).
+      float xw[12];                                    // x index ii+10+k: 8*lane+10 .. 8*lane+21
+      if (r0 < kBwdNS) {
+#pragma unroll
+        for (int u = 0; u < 12; u += 2) {
+          const float2 v = *reinterpret_cast<const float2*>(xs + 2 * r0 + 10 + u);
+          xw[u] = v.x;
+          xw[u + 1] = v.y;
+        }
+      }
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const int ci = ci0 + c;
-        float out[8];
+        float dd[8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int r = r0 + u;
           const uint8_t sc = r < kBwdNS ? sel1[ci * kBwdNQ + r + 5] : 0;   // 0 outside [0,P1) too
-          out[2 * u] = sc == 1 ? da1[c][u] : 0.f;
-          out[2 * u + 1] = sc == 2 ? da1[c][u] : 0.f;
+          dd[2 * u] = sc == 1 ? da1[c][u] : 0.f;
+          dd[2 * u + 1] = sc == 2 ? da1[c][u] : 0.f;
         }
-        f4* dst = reinterpret_cast<f4*>(dz1s + ci * kBwdNIpad + 8 * lane);
-        dst[0] = f4{out[0], out[1], out[2], out[3]};
-        dst[1] = f4{out[4], out[5], out[6], out[7]};
+        if (r0 < kBwdNS) {
+          accb1[c] += ((dd[0] + dd[1]) + (dd[2] + dd[3])) + ((dd[4] + dd[5]) + (dd[6] + dd[7]));
+#pragma unroll
+          for (int k = 0; k < kK; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc1[c][k] = fmaf(dd[u], xw[u + k], acc1[c][k]);
+        }
       }
     }
-    __syncthreads();
     {  // gw2 / gb2: wave = co, lane -> owned s0 = 4*lane .. +3 (s < 250)
       const int co = wave, s0 = 4 * lane;
       const f4 dv = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + s0 + 4);
@@ -537,31 +552,6 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
           for (int k = 0; k < kK; ++k)
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc2[ci][k] = fmaf(dd[u], aw[u + k], acc2[ci][k]);
-        }
-      }
-    }
-    {  // gw1 / gb1: wave w -> channels 2w, 2w+1; lane -> owned ii0 = 8*lane .. +7 (ii < 500)
-      const int ii0 = 8 * lane;
-      if (ii0 < kBwdNI) {
-        float xw[12];                                  // x index ii+10+k: ii0+10 .. ii0+21
-#pragma unroll
-        for (int u = 0; u < 12; u += 2) {
-          const float2 v = *reinterpret_cast<const float2*>(xs + ii0 + 10 + u);
-          xw[u] = v.x;
-          xw[u + 1] = v.y;
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          float dd[8];
-          lds_load8(dz1s + (2 * wave + c) * kBwdNIpad + ii0, dd);
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (ii0 + u >= kBwdNI) dd[u] = 0.f;
-          accb1[c] += ((dd[0] + dd[1]) + (dd[2] + dd[3])) + ((dd[4] + dd[5]) + (dd[6] + dd[7]));
-#pragma unroll
-          for (int k = 0; k < kK; ++k)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc1[c][k] = fmaf(dd[u], xw[u + k], acc1[c][k]);
         }
       }
     }
