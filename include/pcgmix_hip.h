@@ -436,14 +436,17 @@ int pcgmix_potes_head_loss_fwd_f32(const float* x, const uint8_t* mask1, float s
                                    float scale2, int thr2, const float* w2, const float* b2,
                                    const float* target, float* partial, float* z, float* logits,
                                    float* dz, float* loss, float* small, float* ws, float* dw1_zero,
-                                   int defer_finalize, int B, int K, int C, pcgmix_stream_t stream);
+                                   int defer_finalize, int target_kind, int B, int K, int C,
+                                   pcgmix_stream_t stream);
 int pcgmix_potes_head_loss_bwd_f32(const float* dz, const float* gscale, const float* x,
                                    const uint8_t* mask1, float scale1, int thr1, int bits1,
                                    const float* w1, const float* small_in, float* small_out,
                                    float* dw1, float* dx, const float* deferred_ws,
                                    float* deferred_loss, int B, int K, int C,
                                    pcgmix_stream_t stream);
-/* defer_finalize / deferred_ws, deferred_loss: the forward's last launch — the fixed-order sum of
+/* target_kind: 0 = `target` is float (B,C) (soft targets, CELoss' general case); 1 = `target` points
+ * to uint8 class labels (B): hard targets as one byte per row.
+ * defer_finalize / deferred_ws, deferred_loss: the forward's last launch — the fixed-order sum of
  * the per-row-block contributions in `ws` into `loss` and `small` — can be left to the backward,
  * whose feature pass does it in its first block (same order, same values): one launch less per
  * step when forward and backward always run together (a training step captured in a hipGraph).

@@ -75,7 +75,7 @@ SIGNATURES = {
     "pcgmix_potes_head_loss_workspace_floats": (ctypes.c_longlong, [_c_int]),
     "pcgmix_potes_head_loss_fwd_f32": (_c_int, [_ptr, _ptr, _c_float, _c_int, _c_int, _ptr, _ptr, _ptr,
                                                 _c_float, _c_int, _ptr, _ptr, _ptr] + [_ptr] * 8 +
-                                       [_c_int, _c_int, _c_int, _c_int, _ptr]),
+                                       [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_potes_head_loss_bwd_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_float, _c_int, _c_int, _ptr, _ptr,
                                                 _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_soft_ce_fwd_f32": (_c_int, [_ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),

@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kTailRows* kHeadO * 4) void potes_tail_loss_kernel(
     const uint8_t* __restrict__ mask2, float scale2, int thr2, const float* __restrict__ w2,
     const float* __restrict__ b2, const float* __restrict__ target, float* __restrict__ z,
     float* __restrict__ logits, float* __restrict__ dz, float* __restrict__ ws,
-    float* __restrict__ zero, long long n_zero, int B, int C, int nrb) {
+    float* __restrict__ zero, long long n_zero, int B, int C, int nrb, int target_kind) {
   if ((int)blockIdx.x >= nrb) {    // the other blocks clear the buffer head_bwd accumulates dW1 into
     const int nz = (int)gridDim.x - nrb;
     const long long per = (n_zero + nz - 1) / nz;
@@ -471,7 +471,15 @@ __global__ __launch_bounds__(kTailRows* kHeadO * 4) void potes_tail_loss_kernel(
     const int row2 = blockIdx.x * kTailRows + t;
     float loss_r = 0.f;
     if (row2 < B) {
-      const float* tg = target + (size_t)row2 * C;
+      // target_kind 1: `target` is a uint8 class label per row (hard targets: one byte instead of
+      // C floats — small enough to travel in kernel arguments, see GraphedTrainStep)
+      float tg[kHeadMaxC];
+      if (target_kind) {
+        const int lab = reinterpret_cast<const uint8_t*>(target)[row2];
+        for (int c = 0; c < C; ++c) tg[c] = c == lab ? 1.f : 0.f;
+      } else {
+        for (int c = 0; c < C; ++c) tg[c] = target[(size_t)row2 * C + c];
+      }
       float m = lg[t][0];
       for (int c = 1; c < C; ++c) m = fmaxf(m, lg[t][c]);
       float se = 0.f, ts = 0.f;
@@ -643,11 +651,11 @@ extern "C" int pcgmix_potes_head_loss_fwd_f32(const float* x, const uint8_t* mas
                                               const float* w2, const float* b2, const float* target,
                                               float* partial, float* z, float* logits, float* dz,
                                               float* loss, float* small, float* ws, float* dw1_zero,
-                                              int defer_finalize, int B, int K, int C,
-                                              pcgmix_stream_t stream) {
+                                              int defer_finalize, int target_kind, int B, int K,
+                                              int C, pcgmix_stream_t stream) {
   using namespace pcgmix;
   if (!w2 || !target || !z || !logits || !dz || !loss || !small || !ws || C <= 0 || C > kHeadMaxC ||
-      (reinterpret_cast<uintptr_t>(dz) & 15))
+      (reinterpret_cast<uintptr_t>(dz) & 15) || (target_kind != 0 && target_kind != 1))
     return hipErrorInvalidValue;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const hipError_t e =
@@ -659,7 +667,7 @@ extern "C" int pcgmix_potes_head_loss_fwd_f32(const float* x, const uint8_t* mas
   const unsigned zero_blocks = (unsigned)((n_zero + 4095) / 4096);
   hipLaunchKernelGGL(potes_tail_loss_kernel, dim3((unsigned)nrb + zero_blocks),
                      dim3(kTailRows * kHeadO * 4), 0, s, partial, KS, b1, mask2, scale2, thr2, w2, b2,
-                     target, z, logits, dz, ws, dw1_zero, n_zero, B, C, nrb);
+                     target, z, logits, dz, ws, dw1_zero, n_zero, B, C, nrb, target_kind);
   if (!defer_finalize)
     hipLaunchKernelGGL(potes_tail_loss_finalize_kernel, dim3(1), dim3(kTlStride * kTlSeg), 0, s, ws,
                        nrb, loss, small, B, C);

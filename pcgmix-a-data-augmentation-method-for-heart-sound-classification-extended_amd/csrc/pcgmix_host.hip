@@ -865,7 +865,8 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   //     kernel's ARGUMENTS — no staging slot, no host-to-device copy in the chain label kernel ->
   //     host -> splice that bounds a strict-signature step.
   static const bool karg_ok = getenv("PCGMIX_NO_KARG") == nullptr;     // tuning / A-B runs
-  if (karg_ok && !knots && c->payload.empty() && B <= pcgmix::kPackB && T <= 32767 && !(T & 3) &&
+  if (karg_ok && !knots && c->payload.size() <= (size_t)pcgmix::kPackPayBytes && B <= pcgmix::kPackB &&
+      T <= 32767 && !(T & 3) &&
       !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15)) {
     int16_t fr16[pcgmix::kPackB * 5], mix16[pcgmix::kPackB];
     int bad16 = 0;
@@ -896,8 +897,11 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     draw_partners(c, labels_k, B, mix_out, nullptr, mix16);
     lap(4);
     lap(5);
-    const int err = pcgmix::launch_mix_karg(x, y, fr16, mix16, lam, B, C, T, s);
+    const int err = pcgmix::launch_mix_karg(x, y, fr16, mix16, lam, B, C, T, s, c->payload.data(),
+                                            (int)c->payload.size(), c->payload_dst);
     if (err) return err;
+    c->payload.clear();
+    c->payload_dst = nullptr;
     lap(6);
     lap(7);
     ++c->calls;

@@ -44,6 +44,7 @@ int launch_mix_warp(const float* x, float* y, const int32_t* frames, const int32
 // memory, B <= kPackB, T <= 32767, T % 4 == 0, x and y 16-byte aligned.  Returns
 // hipErrorInvalidValue when the shape does not qualify (the caller then takes the copy path).
 constexpr int kPackB = 256;
+constexpr int kPackPayBytes = 320;   // step payload that still fits next to the index block
 // Partner indices of up to kPackB samples as int16, two per dword, passed BY VALUE in the kernel
 // arguments of the displacement search and of the splice (saliency-guided step: the partners are
 // the only per-step index data that depends on the labels — carried by the launches themselves,
@@ -66,8 +67,11 @@ inline PartnerPack make_partner_pack(const int16_t* partners16, int B) {
   }
   return pk;
 }
+// pay: up to kPackPayBytes bytes (host) that also travel in the arguments; block (0,0) writes them,
+// rounded up to 16, to pay_dst (device, 16-byte aligned) — the step payload of pcgmix_ctx_set_payload.
 int launch_mix_karg(const float* x, float* y, const int16_t* frames16, const int16_t* mix16, float lam,
-                    int B, int C, int T, hipStream_t s);
+                    int B, int C, int T, hipStream_t s, const void* pay = nullptr, int pay_bytes = 0,
+                    void* pay_dst = nullptr);
 
 // pcgmix_saliency.hip: the displacement search of pcgmix_salopt_disp_f32; disp == nullptr leaves
 // the per-block results in `workspace` for launch_mix_warp's disp_part.

@@ -327,12 +327,19 @@ __device__ __forceinline__ int pack_get(const IdxPack& p, int i) {
   return (i & 1) ? (w >> 16) : ((int)((unsigned)w << 16) >> 16);
 }
 
+struct PayPack {           // a small step payload in the arguments (see launch_mix_karg)
+  uint4 w[kPackPayBytes / 16];
+  int n16;
+};
+
 template <bool WARP, int U>
 __global__ __launch_bounds__(kThreads) void mix_warp_karg_kernel(
     const float* __restrict__ x, float* __restrict__ y, const IdxPack pack, float lam, float oml,
     const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots, int B,
-    int C, int T, int epb) {
+    int C, int T, int epb, const PayPack pay, uint4* __restrict__ pay_dst) {
   extern __shared__ __align__(16) double lds[];
+  if (pay.n16 && (blockIdx.x | blockIdx.y) == 0 && (int)threadIdx.x < pay.n16)
+    pay_dst[threadIdx.x] = pay.w[threadIdx.x];
   const int b = blockIdx.y;
   if (b >= B) return;
   int m = pack_get(pack, kPackB * 5 + b);
@@ -409,8 +416,18 @@ extern "C" int pcgmix_mix_karg_variant(int B, int C, int T, int* unroll) {
 }
 
 int pcgmix::launch_mix_karg(const float* x, float* y, const int16_t* frames16, const int16_t* mix16,
-                            float lam, int B, int C, int T, hipStream_t s) {
+                            float lam, int B, int C, int T, hipStream_t s, const void* pay_host,
+                            int pay_bytes, void* pay_dst) {
   using namespace pcgmix;
+  if (pay_bytes < 0 || pay_bytes > kPackPayBytes ||
+      (pay_bytes > 0 && (!pay_host || !pay_dst || (reinterpret_cast<uintptr_t>(pay_dst) & 15))))
+    return hipErrorInvalidValue;
+  PayPack pay;
+  pay.n16 = (pay_bytes + 15) / 16;
+  if (pay_bytes) {
+    memset(pay.w, 0, sizeof(pay.w));
+    memcpy(pay.w, pay_host, (size_t)pay_bytes);
+  }
   if (!x || !y || !frames16 || !mix16 || x == y || B <= 0 || B > kPackB || C <= 0 || T <= 0 ||
       T > 32767 || (T & 3) ||
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15))
@@ -428,10 +445,10 @@ int pcgmix::launch_mix_karg(const float* x, float* y, const int16_t* frames16, c
   dim3 grid(chunks, (unsigned)B), block(kThreads);
   if (U >= 2)
     hipLaunchKernelGGL((mix_warp_karg_kernel<false, 2>), grid, block, 0, s, x, y, pack, lam, oml,
-                       nullptr, nullptr, 0, B, C, T, epb);
+                       nullptr, nullptr, 0, B, C, T, epb, pay, static_cast<uint4*>(pay_dst));
   else
     hipLaunchKernelGGL((mix_warp_karg_kernel<false, 1>), grid, block, 0, s, x, y, pack, lam, oml,
-                       nullptr, nullptr, 0, B, C, T, epb);
+                       nullptr, nullptr, 0, B, C, T, epb, pay, static_cast<uint4*>(pay_dst));
   return (int)hipGetLastError();
 }
 

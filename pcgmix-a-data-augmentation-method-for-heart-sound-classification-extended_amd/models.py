@@ -284,7 +284,11 @@ class PotesHeadLossFunction(torch.autograd.Function):
         dev = feat.device
         lib = _lib.load()
         x = feat.contiguous()
-        tgt = target.to(torch.float32).contiguous()
+        # hard targets may come as uint8 class labels (B,): one byte per row instead of C floats
+        hard = target.dtype == torch.uint8 and target.dim() == 1
+        if hard and target.shape[0] != B:
+            raise ValueError("labels do not match the batch size")
+        tgt = target.contiguous() if hard else target.to(torch.float32).contiguous()
         mask1 = mask2 = None
         thr1 = thr2 = 0
         bits1 = 8
@@ -319,7 +323,7 @@ class PotesHeadLossFunction(torch.autograd.Function):
             b1.detach().data_ptr() if b1 is not None else None, opt(mask2), ctypes.c_float(s2), thr2,
             w2c.data_ptr(), b2.detach().data_ptr() if b2 is not None else None, tgt.data_ptr(),
             partial.data_ptr(), z.data_ptr(), logits.data_ptr(), dz.data_ptr(), loss.data_ptr(),
-            small.data_ptr(), ws.data_ptr(), opt(dw1), int(defer), B, K, C, stream),
+            small.data_ptr(), ws.data_ptr(), opt(dw1), int(defer), int(hard), B, K, C, stream),
             "pcgmix_potes_head_loss_fwd_f32")
         ctx.save_for_backward(x, w1c, dz, small, mask1, dw1)
         # the backward writes the loss through this alias (no version check: under capture nobody
@@ -454,7 +458,8 @@ class CNN_potes(nn.Module):
     def loss_and_logits(self, x: torch.Tensor, target: torch.Tensor):
         """(soft-target cross entropy, logits) of the whole network in one chain of HIP kernels
         — the conv stack, then head and loss as ONE autograd node (``PotesHeadLossFunction``).
-        Needs ``_fused_head(x)``; ``target`` is the (B, classes) one-hot / soft target matrix."""
+        Needs ``_fused_head(x)``; ``target`` is the (B, classes) one-hot / soft target matrix, or
+        — hard targets — a uint8 (B,) tensor of class labels."""
         B, C, T = x.shape
         c1, c2 = self.cnn1[0][0], self.cnn1[1][0]
         rows = x[:, :4, :].reshape(B * 4, T)

@@ -472,15 +472,26 @@ class GraphedTrainStep:
         # [12:12+B*classes] the float targets.  ``_payload`` is its host image; a plain splice
         # carries it with its index block (``pcgmix_ctx_set_payload``: no copy of its own),
         # other steps upload it with one H2D.
+        # [12:12+B/4] the class labels as bytes | then the float targets.  Hard targets (everything
+        # but '(mixAll)') reach the fused Potes head+loss as those bytes: the payload is then 48 + B
+        # bytes and travels in the splice kernel's ARGUMENTS with the index block — no copy at all
+        # in front of the replay; other models / soft targets read the float block (one H2D).
         n_t = batch_size * args.num_classes
-        self.aux = torch.zeros(12 + (n_t + 3) // 4 * 4, device=device)
-        self.t = self.aux[12:12 + n_t].view(batch_size, args.num_classes)
+        n_lab = (batch_size + 15) // 16 * 4                   # words, 16-byte granules
+        self.aux = torch.zeros(12 + n_lab + (n_t + 3) // 4 * 4, device=device)
+        self.t_u8 = self.aux[12:12 + n_lab].view(torch.uint8)[:batch_size]
+        self.t = self.aux[12 + n_lab:12 + n_lab + n_t].view(batch_size, args.num_classes)
         self.t[:, 0] = 1
         self._payload = np.zeros(self.aux.numel(), dtype=np.float32)
         self._pay_key = self._payload[0:2].view(np.uint32)
         self._pay_hyper = self._payload[4:12]
-        self._pay_t = self._payload[12:12 + n_t].reshape(batch_size, args.num_classes)
+        self._pay_lab = self._payload[12:12 + n_lab].view(np.uint8)[:batch_size]
+        self._pay_t = self._payload[12 + n_lab:12 + n_lab + n_t].reshape(batch_size, args.num_classes)
         self._rows = np.arange(batch_size)
+        self.labels_mode = bool(                               # same test as _fwd_bwd's
+            isinstance(self.ce, CELoss) and "(mixAll)" not in args.method and args.num_classes <= 255
+            and fused_loss_model(model, self.ce, self.x, self.t, None) is not None)
+        self._pay_bytes = (12 + n_lab) * 4 if self.labels_mode else self._payload.nbytes
         self.sync = sync
         self.bwd_seed = torch.full((), sync.backward_scale if sync else 1.0, device=device)
         # Dropout inside a captured region costs two extra fill launches per replay (torch's
@@ -542,7 +553,7 @@ class GraphedTrainStep:
         fused = fused_loss_model(self.model, self.ce, self.x, self.t, None) \
             if isinstance(self.ce, CELoss) else None
         if fused is not None:
-            loss, out = fused.loss_and_logits(self.x, self.t)
+            loss, out = fused.loss_and_logits(self.x, self.t_u8 if self.labels_mode else self.t)
         else:
             out = self.model(self.x, depth=0, pass_part="second")
             loss = self.ce(out, self.t)
@@ -571,15 +582,18 @@ class GraphedTrainStep:
         step = int(step_counter.count)
         # host image of the static block: one-hot float targets, dropout key, Adam scalars
         labels_np = target.numpy() if not target.is_cuda else target.cpu().numpy()
-        self._pay_t.fill(0.0)
-        self._pay_t[self._rows, labels_np] = 1.0
+        if self.labels_mode:
+            self._pay_lab[:] = labels_np
+        else:
+            self._pay_t.fill(0.0)
+            self._pay_t[self._rows, labels_np] = 1.0
         if self.rnd is not None and self.model.training:
             self._next_key()
         if self.adam_in_graph:
             self.opt.next_hyper(self._pay_hyper)
         recipe = hostprep.plain_recipe(args.method, False)
         lib, ctx = _lib.load(), augmentations.step_context(data.device.index)
-        _lib.check(lib.pcgmix_ctx_set_payload(ctx, self._payload.ctypes.data, self._payload.nbytes,
+        _lib.check(lib.pcgmix_ctx_set_payload(ctx, self._payload.ctypes.data, self._pay_bytes,
                                               self.aux.data_ptr()), "pcgmix_ctx_set_payload")
         if recipe is not None and B > 0:                # plain splice: one library call
             fired = augmentations.gate_passes(recipe, args.method, step, data.device.index)
@@ -616,7 +630,8 @@ class GraphedTrainStep:
         if stats is not None:
             with torch.no_grad():
                 stats["loss_sum"] += self.loss
-                stats["hits"] += (self.out.argmax(1) == self.t.argmax(1)).sum()
+                truth = self.t_u8 if self.labels_mode else self.t.argmax(1)
+                stats["hits"] += (self.out.argmax(1) == truth).sum()
                 stats["seen"] += B
         return self.loss
 

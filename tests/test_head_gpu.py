@@ -290,3 +290,28 @@ def test_head_loss_finalize_deferred(device):
         assert torch.equal(a, b)
     # (the Function trusts `defer`; CNN_potes.loss_and_logits sets it only with autograd on and
     # a capture in progress)
+
+
+def test_head_loss_takes_hard_targets_as_uint8_labels(device):
+    """target = uint8 (B,) class labels == the float one-hot matrix of the same labels: loss,
+    logits and gradients bit-identical (what the captured step sends: B bytes instead of B*C floats)."""
+    from pcgmix_amd import models
+    torch.manual_seed(3)
+    B, K, C = 50, 9968, 2
+    w1 = (torch.randn(20, K, device=device) * 0.01).requires_grad_(True)
+    b1 = torch.randn(20, device=device).requires_grad_(True)
+    w2 = torch.randn(C, 20, device=device).requires_grad_(True)
+    b2 = torch.randn(C, device=device).requires_grad_(True)
+    feat = torch.randn(B, K, device=device).requires_grad_(True)
+    labels = torch.randint(0, C, (B,), device=device)
+    params = (feat, w1, b1, w2, b2)
+    res = []
+    for tgt in (F.one_hot(labels, C).float(), labels.to(torch.uint8)):
+        loss, logits = models.PotesHeadLossFunction.apply(feat, w1, b1, w2, b2, tgt, 0.0, 0.0, True, None)
+        res.append((loss.detach(), logits, torch.autograd.grad(loss, params)))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        models.PotesHeadLossFunction.apply(feat, w1, b1, w2, b2, labels[:-1].to(torch.uint8), 0.0, 0.0,
+                                           True, None)
