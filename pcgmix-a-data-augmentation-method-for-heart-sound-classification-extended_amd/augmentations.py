@@ -19,7 +19,7 @@ labels on the host prepare step n+1 while the GPU still runs step n.
 from __future__ import annotations
 
 import ctypes
-from typing import Optional, Sequence
+from typing import Optional
 
 import numpy as np
 import torch
