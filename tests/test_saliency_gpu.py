@@ -442,3 +442,32 @@ def test_salopt_fast_path_equals_general_path(device):
         assert ok[0].shape == data.shape
     finally:
         saliency.set_saliency_model(None)
+
+
+def test_salopt_fast_path_beyond_the_kernarg_batch(device):
+    """B > 256: boundaries and partners no longer fit the kernel arguments — the two-call step
+    then sends them through the context's staging ring; results == the general plan path."""
+    from pcgmix_amd import hostprep, synthetic
+    torch.manual_seed(2)
+    saliency.set_saliency_model(models.CNN_potes_TS(4, 2, "PhysioNet").to(device))
+    try:
+        B = 300
+        x, frames, labels, wav = synthetic.make_batch(B, 4, 2500, seed=44)
+        data = torch.from_numpy(x).to(device)
+        tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)
+        a = Args("(saloptsum)durmixmagwarp(0.2,4)")
+        fast = augmentations.augment(a, data, tgt, frames, wav, StepCounter(9), None, device, "")
+        real = hostprep.salopt_recipe
+        hostprep.salopt_recipe = lambda m: None
+        try:
+            slow = augmentations.augment(a, data, tgt, frames, wav, StepCounter(9), None, device, "")
+        finally:
+            hostprep.salopt_recipe = real
+        assert np.array_equal(fast[2], slow[2]) and torch.equal(fast[0], slow[0])
+        plain = augmentations.augment(Args("durratiomixup"), data, tgt, frames, wav, StepCounter(9), None,
+                                      device, "")               # plain step beyond 256: staging slot
+        ref = O.augment("durratiomixup", x, labels, frames, wav, 9)
+        assert np.array_equal(plain[2], ref["mix"])
+        assert np.abs(plain[0].cpu().numpy() - ref["y"]).max() <= 1e-4
+    finally:
+        saliency.set_saliency_model(None)
