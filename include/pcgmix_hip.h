@@ -300,8 +300,9 @@ int pcgmix_potes_stack_bwd_f32(const float* x, const float* grad_h2, const float
  * position instead of the activations):
  *   m2   uint8 (N, 4, ceil(P2/4))  second layer: per pooled output 2 bits — 0 ReLU-dead, 1 the
  *        first conv output of the pooled pair won, 2 the second; four outputs per byte
- *   s1   uint8 (N, 8, P1)          first layer: the same selector, one byte per pooled position;
- *        only the input gradient needs it (pass NULL to the forward otherwise)
+ *   s1   uint8 (N, 8, P1/4 + 1)    first layer: the same selector, four positions per byte
+ *        (position q in bits 2*((q+1)&3) of byte (q+1)>>2); only the input gradient needs it
+ *        (pass NULL to the forward otherwise)
  *   sizes in bytes: pcgmix_potes_mask_bytes(N, T, layer = 2 or 1)
  *   pcgmix_potes_stack_fwd_save_f32        the forward above + m2 (+ s1)
  *   pcgmix_potes_stack_bwd_mask_f32        weight gradients: recomputes layer 1 only

@@ -46,6 +46,9 @@ __host__ __device__ inline PotesDims potes_dims(int T) {
   return d;
 }
 
+// Bytes per (row, channel) of the packed first-layer selectors (see layer1_t, s1g).
+__host__ __device__ inline int potes_s1_row_bytes(const PotesDims& d) { return (d.P1 >> 2) + 1; }
+
 struct PotesWeights {  // LDS copy, broadcast-read
   float w1[kNW1], b1[kC1], w2[kNW2], b2[kC2];
 };
@@ -90,8 +93,8 @@ __device__ __forceinline__ void lds_load8(const float* p, float (&v)[8]) {  // p
 // 16-byte reads of a 12-float window starting at float4 index 2g become E[g], O[g], E[g+1]:
 // consecutive lanes read consecutive 16 bytes.  With the plain layout the windows start 32 bytes
 // apart and every ds_read_b128 is a 2-way bank conflict (64 banks x 4 B, 16 lanes per group).
-// s1g (forward kernel only, may be nullptr): global plane (8, P1) of this row that receives the
-// same pool/ReLU selector byte for the positions q in [own_lo, own_hi) — what the mask-based
+// s1g (forward kernel only, may be nullptr): global plane (8, own_hi bytes) of this row that
+// receives the same pool/ReLU selectors, four per byte (own_lo unused) — what the mask-based
 // backward kernels read instead of recomputing this layer.
 template <bool SWZ>
 __device__ __forceinline__ void layer1_t(const PotesWeights& W, const float* xs, float* a1s,
@@ -166,11 +169,14 @@ __device__ __forceinline__ void layer1_t(const PotesWeights& W, const float* xs,
     if (SWZ) {
       *reinterpret_cast<f4*>(a1s + ci * 2 * aplane + (g & 1) * aplane + 4 * (g >> 1)) = out;
       if (s1g) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int q = qlo + 4 * g + u;
-          if (q >= own_lo && q < own_hi) s1g[(size_t)ci * P1 + q] = (uint8_t)((sels >> (8 * u)) & 0xffu);
-        }
+        // Packed: selector of position q in bits 2*((q+1)&3) of byte (q+1)>>2 of the channel's
+        // row (stride own_hi = P1/4 + 1 bytes).  qlo + 1 is a multiple of 4, so a work item's four
+        // positions are exactly one byte; the one group that two neighbouring tiles both compute
+        // (the halo) gets the same byte from both — same inputs, same arithmetic.
+        const int bi = ((qlo + 1) >> 2) + g;
+        if (bi >= 0 && bi < own_hi)
+          s1g[(size_t)ci * own_hi + bi] = (uint8_t)((sels & 3u) | ((sels >> 6) & 0xcu) |
+                                                    ((sels >> 12) & 0x30u) | ((sels >> 18) & 0xc0u));
       }
     } else {
       *reinterpret_cast<f4*>(a1s + ci * nq + 4 * g) = out;
@@ -249,11 +255,9 @@ __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
   }
   __syncthreads();
   if (SAVE && s1) {
-    // every first-layer position is stored by exactly one tile; the last tile also owns the
-    // two or three positions beyond 2*P2 that still feed the last pooled outputs
-    const int own_hi = blockIdx.x == gridDim.x - 1 ? d.P1 : min(2 * p0 + 2 * kFwdTP, d.P1);
+    const int s1row = potes_s1_row_bytes(d);          // four 2-bit selectors per byte
     layer1_t<true>(W, xs, a1s, nullptr, qlo, kFwdNQ, d.P1, kXPlane, kAPlane,
-                   s1 + (size_t)n * kC1 * d.P1, 2 * p0, own_hi);
+                   s1 + (size_t)n * kC1 * s1row, 0, s1row);
   } else {
     layer1_t<true>(W, xs, a1s, nullptr, qlo, kFwdNQ, d.P1, kXPlane, kAPlane);
   }
@@ -744,15 +748,23 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_mask_kernel(
   for (int i = threadIdx.x; i < kNW1; i += kPotThreads) w1s[i] = w1[i];
   // first-layer selectors of this lane's 4 positions q = 2p0-2+4*lane+u for its two channels:
   // issued now, consumed after the first barrier
+  // (packed: position q sits in bits 2*((q+1)&3) of byte (q+1)>>2; q+1 = 2*p0 - 1 + 4*lane + u with
+  // 2*p0 a multiple of 4, so u = 0 is the top pair of one byte and u = 1..3 the low pairs of the next)
   uint32_t sc[2][4];
+  const int s1row = potes_s1_row_bytes(d);
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int c = 0; c < 2; ++c) {
+    const uint8_t* row = s1 + ((size_t)n * kC1 + 2 * wave + c) * s1row;
+    const int b1 = (p0 >> 1) + lane, b0 = b1 - 1;
+    const uint32_t v0 = (b0 >= 0 && b0 < s1row) ? row[b0] : 0u;
+    const uint32_t v1 = (b1 >= 0 && b1 < s1row) ? row[b1] : 0u;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int r = 4 * lane + u, q = 2 * p0 - 2 + r;
-      sc[c][u] = (r < kInNR && q >= 0 && q < d.P1)
-                     ? s1[((size_t)n * kC1 + 2 * wave + c) * d.P1 + q] : 0u;
+      const uint32_t code = u == 0 ? (v0 >> 6) & 3u : (v1 >> (2 * (u - 1))) & 3u;
+      sc[c][u] = (r < kInNR && q >= 0 && q < d.P1) ? code : 0u;
     }
+  }
   {  // dz2 at pe = p0-3+2*lane+u (wave = co); the 12-float pad of each row stays zero
     const int co = wave;
     f4 dz;
@@ -1205,7 +1217,7 @@ extern "C" long long pcgmix_potes_mask_bytes(int N, int T, int layer) {
   if (N <= 0 || T < 14) return 0;
   const pcgmix::PotesDims d = pcgmix::potes_dims(T);
   return layer == 2 ? (long long)N * pcgmix::kC2 * ((d.P2 + 3) / 4)
-                    : (layer == 1 ? (long long)N * pcgmix::kC1 * d.P1 : 0);
+                    : (layer == 1 ? (long long)N * pcgmix::kC1 * pcgmix::potes_s1_row_bytes(d) : 0);
 }
 
 extern "C" int pcgmix_potes_stack_fwd_save_f32(const float* x, const float* w1, const float* b1,
