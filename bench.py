@@ -99,9 +99,9 @@ def run_augment_steps(method, data, tgt, frames, wav, device, steps, warmup, bar
     for _ in range(warmup):
         augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "", **kw)
         sc.add()
+    settle_heap()                                   # before the barrier: its duration differs per rank
     barrier()
     torch.cuda.synchronize()
-    settle_heap()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "", **kw)
@@ -298,9 +298,9 @@ def run_train_steps(step, info, steps, warmup, barrier, tag):
     for i in range(warmup):
         PROGRESS["step"] = i - warmup
         step()
+    settle_heap()                                   # before the barrier: its duration differs per rank
     barrier()
     torch.cuda.synchronize()
-    settle_heap()
     t0 = time.perf_counter()
     for i in range(steps):
         PROGRESS["step"] = i
