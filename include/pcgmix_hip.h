@@ -619,14 +619,20 @@ int pcgmix_mix_variant(int B, int C, int T, int warp, int aligned16, int* vec, i
  * Each direction reads y twice and writes its output once; reductions are fixed-order.
  */
 long long pcgmix_bnrp_workspace_floats(int B, int H, int W, int C);
+/* mean_shift (C, may be NULL): a per-channel constant left out of y — the convolution's bias, which
+ * the normalisation cancels — added to the batch mean in the running-mean update only;
+ * batches_tracked (may be NULL): nn.BatchNorm's num_batches_tracked, incremented by one;
+ * dzero (C, may be NULL): receives zeros, the exact gradient of such a constant (so that the
+ * optimiser still sees the parameter and applies weight decay, as in the reference).            */
 int pcgmix_bnrp_fwd_f32(const float* y, const float* gamma, const float* beta, float* running_mean,
-                        float* running_var, float momentum, float eps, const float* skip, float* z,
-                        float* mean, float* invstd, float* workspace, int B, int H, int W, int C,
-                        int ph, int pw, pcgmix_stream_t stream);
+                        float* running_var, float momentum, float eps, const float* mean_shift,
+                        long long* batches_tracked, const float* skip, float* z, float* mean,
+                        float* invstd, float* workspace, int B, int H, int W, int C, int ph, int pw,
+                        pcgmix_stream_t stream);
 int pcgmix_bnrp_bwd_f32(const float* y, const float* dz, const float* gamma, const float* beta,
                         const float* mean, const float* invstd, float* dx, float* dgamma,
-                        float* dbeta, float* workspace, int B, int H, int W, int C, int ph, int pw,
-                        pcgmix_stream_t stream);
+                        float* dbeta, float* dzero, float* workspace, int B, int H, int W, int C,
+                        int ph, int pw, pcgmix_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -107,8 +107,8 @@ SIGNATURES = {
                                     ctypes.POINTER(_c_int)]),
     "pcgmix_bnrp_workspace_floats": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int]),
     "pcgmix_bnrp_fwd_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_float, _ptr, _ptr, _ptr, _ptr,
-                                     _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr]),
-    "pcgmix_bnrp_bwd_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int,
+                                     _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr]),
+    "pcgmix_bnrp_bwd_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int,
                                      _c_int, _c_int, _c_int, _c_int, _c_int, _ptr]),
 }
 

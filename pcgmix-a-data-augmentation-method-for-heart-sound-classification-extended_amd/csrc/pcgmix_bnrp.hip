@@ -129,7 +129,11 @@ __device__ __forceinline__ void partial_sums(const float* __restrict__ partial, 
 __global__ __launch_bounds__(kFinCh * 16) void bn_finalize_kernel(
     const float* __restrict__ partial, int nblk, int C, double n_rows, float eps, float momentum,
     float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
-    float* __restrict__ running_var) {
+    float* __restrict__ running_var, const float* __restrict__ mean_shift,
+    long long* __restrict__ batches_tracked) {
+  // mean_shift: a per-channel constant that was left out of y (the convolution's bias, which the
+  // normalisation cancels): it belongs in the running mean.  batches_tracked: nn.BatchNorm's counter.
+  if (batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) batches_tracked[0] += 1;
   __shared__ double lds[2][kFinCh][16];
   const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, lane = threadIdx.x / kFinCh;
   double s, ss;
@@ -140,7 +144,9 @@ __global__ __launch_bounds__(kFinCh * 16) void bn_finalize_kernel(
   if (var < 0.0) var = 0.0;
   mean[c] = (float)m;
   invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+  if (running_mean)
+    running_mean[c] = (1.f - momentum) * running_mean[c] +
+                      momentum * ((float)m + (mean_shift ? mean_shift[c] : 0.f));
   if (running_var) {
     const double unbiased = n_rows > 1.0 ? var * n_rows / (n_rows - 1.0) : var;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(kBnThreads) void bnrp_bwd_reduce_kernel(
 
 __global__ __launch_bounds__(kFinCh * 16) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int nblk, int C, double n_rows, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, float* __restrict__ coef) {
+    float* __restrict__ dbeta, float* __restrict__ coef, float* __restrict__ dzero) {
   __shared__ double lds[2][kFinCh][16];
   const int c = blockIdx.x * kFinCh + threadIdx.x % kFinCh, lane = threadIdx.x / kFinCh;
   double s1, s2;
@@ -245,6 +251,7 @@ __global__ __launch_bounds__(kFinCh * 16) void bn_bwd_finalize_kernel(
   if (c >= C || lane != 0) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
+  if (dzero) dzero[c] = 0.f;               // the exact zero gradient of a constant the norm cancels
   coef[c] = (float)(s1 / n_rows);          // mean of dy
   coef[C + c] = (float)(s2 / n_rows);      // mean of dy * xhat
 }
@@ -544,9 +551,10 @@ extern "C" long long pcgmix_bnrp_workspace_floats(int B, int H, int W, int C) {
 
 extern "C" int pcgmix_bnrp_fwd_f32(const float* y, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum,
-                                   float eps, const float* skip, float* z, float* mean,
-                                   float* invstd, float* workspace, int B, int H, int W, int C,
-                                   int ph, int pw, pcgmix_stream_t stream) {
+                                   float eps, const float* mean_shift, long long* batches_tracked,
+                                   const float* skip, float* z, float* mean, float* invstd,
+                                   float* workspace, int B, int H, int W, int C, int ph, int pw,
+                                   pcgmix_stream_t stream) {
   using namespace pcgmix;
   BnShape s;
   if (!y || !gamma || !beta || !z || !mean || !invstd || !workspace || !bn_shape(&s, B, H, W, C, ph, pw))
@@ -561,7 +569,8 @@ extern "C" int pcgmix_bnrp_fwd_f32(const float* y, const float* gamma, const flo
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(kBnThreads), 0, st,
                      reinterpret_cast<const f4*>(y), n4, s.Q, workspace, C);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * 16), 0, st, workspace, nblk, C,
-                     (double)rows, eps, momentum, mean, invstd, running_mean, running_var);
+                     (double)rows, eps, momentum, mean, invstd, running_mean, running_var, mean_shift,
+                     batches_tracked);
   const long long n_out = (long long)B * s.Ho * s.Wo * s.Q;
   const dim3 ag(bn_blocks(n_out * 2)), ab(kBnThreads);
   const f4* y4 = reinterpret_cast<const f4*>(y);
@@ -578,8 +587,9 @@ extern "C" int pcgmix_bnrp_fwd_f32(const float* y, const float* gamma, const flo
 
 extern "C" int pcgmix_bnrp_bwd_f32(const float* y, const float* dz, const float* gamma,
                                    const float* beta, const float* mean, const float* invstd,
-                                   float* dx, float* dgamma, float* dbeta, float* workspace, int B,
-                                   int H, int W, int C, int ph, int pw, pcgmix_stream_t stream) {
+                                   float* dx, float* dgamma, float* dbeta, float* dzero,
+                                   float* workspace, int B, int H, int W, int C, int ph, int pw,
+                                   pcgmix_stream_t stream) {
   using namespace pcgmix;
   BnShape s;
   if (!y || !dz || !gamma || !beta || !mean || !invstd || !dx || !dgamma || !dbeta || !workspace ||
@@ -607,7 +617,7 @@ extern "C" int pcgmix_bnrp_bwd_f32(const float* y, const float* dz, const float*
     default: hipLaunchKernelGGL(bnrp_bwd_reduce_kernel, rg, rb, 0, st, y4, dz4, gamma, beta, mean, invstd, workspace, s);
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh), dim3(kFinCh * 16), 0, st, workspace, nblk,
-                     C, (double)rows, dgamma, dbeta, coef);
+                     C, (double)rows, dgamma, dbeta, coef, dzero);
   switch (kind) {
     case 1: hipLaunchKernelGGL((bnrp_bwd_apply_win_kernel<1, 1>), rg, rb, 0, st, y4, dz4, gamma, beta, mean, invstd, coef, dx4, s); break;
     case 2: hipLaunchKernelGGL((bnrp_bwd_apply_win_kernel<1, 2>), rg, rb, 0, st, y4, dz4, gamma, beta, mean, invstd, coef, dx4, s); break;

@@ -556,7 +556,11 @@ class BNReLUPoolFunction(torch.autograd.Function):
                 and y.is_contiguous(memory_format=torch.channels_last))
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum, eps, ph, pw, skip=None):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum, eps, ph, pw, skip=None,
+                conv_bias=None, batches_tracked=None):
+        # conv_bias: the bias of the convolution that produced y, NOT added to y (the normalisation
+        # cancels it): it only shifts the running mean, and gets an exact zero gradient — both inside
+        # the BatchNorm kernels.  batches_tracked: the module's counter, incremented there too.
         B, C, H, W = y.shape
         if skip is not None and (skip.shape != (B, C, H // ph, W // pw) or skip.dtype != torch.float32
                                  or not skip.is_contiguous(memory_format=torch.channels_last)):
@@ -575,11 +579,14 @@ class BNReLUPoolFunction(torch.autograd.Function):
             running_mean.data_ptr() if running_mean is not None else None,
             running_var.data_ptr() if running_var is not None else None,
             ctypes.c_float(momentum), ctypes.c_float(eps),
+            conv_bias.data_ptr() if conv_bias is not None else None,
+            batches_tracked.data_ptr() if batches_tracked is not None else None,
             skip.data_ptr() if skip is not None else None, z.data_ptr(), mean.data_ptr(),
             invstd.data_ptr(), ws.data_ptr(), B, H, W, C, ph, pw, stream), "pcgmix_bnrp_fwd_f32")
         ctx.save_for_backward(y, g, b, mean, invstd)
         ctx.pool = (ph, pw)
         ctx.has_skip = skip is not None
+        ctx.has_bias = conv_bias is not None
         return z
 
     @staticmethod
@@ -593,14 +600,17 @@ class BNReLUPoolFunction(torch.autograd.Function):
         dx = torch.empty_like(y)                             # preserves channels_last
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        dbias = torch.empty(C, dtype=torch.float32, device=dev) if ctx.has_bias else None
         ws = torch.empty(lib.pcgmix_bnrp_workspace_floats(B, H, W, C), dtype=torch.float32, device=dev)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         _lib.check(lib.pcgmix_bnrp_bwd_f32(
             y.data_ptr(), dz.data_ptr(), g.data_ptr(), b.data_ptr(), mean.data_ptr(),
-            invstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+            invstd.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+            dbias.data_ptr() if dbias is not None else None, ws.data_ptr(),
             B, H, W, C, ph, pw, stream), "pcgmix_bnrp_bwd_f32")
         # the residual input enters by a plain addition: its gradient is dz itself
-        return dx, dgamma, dbeta, None, None, None, None, None, None, (dz if ctx.has_skip else None)
+        return (dx, dgamma, dbeta, None, None, None, None, None, None,
+                (dz if ctx.has_skip else None), dbias, None)
 
 
 def conv_bn_relu_pool(h, weight4, conv_bias, padding, bn, training: bool, pool, skip=None):
@@ -627,6 +637,16 @@ def conv_bn_relu_pool(h, weight4, conv_bias, padding, bn, training: bool, pool, 
         h = F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias, batch_stats,
                          factor, bn.eps)
     elif batch_stats:
+        if FUSED_BN and training and bn.track_running_stats and BNReLUPoolFunction.supported(h) \
+                and conv_bias.is_contiguous() and conv_bias.dtype == torch.float32:
+            # counter, running-mean shift (new = (1-m) * old + m * (mean(conv) + b)) and the bias'
+            # exact zero gradient all happen inside the BatchNorm kernels: no launch of their own
+            ph, pw = (1, 1) if pool is None else ((pool, pool) if isinstance(pool, int) else pool)
+            if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
+                skip = skip.contiguous(memory_format=torch.channels_last)
+            return BNReLUPoolFunction.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                            float(bn.momentum), float(bn.eps), int(ph), int(pw), skip,
+                                            conv_bias, bn.num_batches_tracked)
         if training and bn.track_running_stats:
             bn.num_batches_tracked.add_(1)                  # as nn.BatchNorm.forward does
         beta = bn.bias + 0.0 * conv_bias
@@ -635,12 +655,6 @@ def conv_bn_relu_pool(h, weight4, conv_bias, padding, bn, training: bool, pool, 
             # shifted BEFORE the call: autograd saves the buffer and rejects a later in-place edit
             with torch.no_grad():
                 bn.running_mean.add_(conv_bias, alpha=bn.momentum / (1.0 - bn.momentum))
-        if FUSED_BN and training and bn.track_running_stats and BNReLUPoolFunction.supported(h):
-            ph, pw = (1, 1) if pool is None else ((pool, pool) if isinstance(pool, int) else pool)
-            if skip is not None and not skip.is_contiguous(memory_format=torch.channels_last):
-                skip = skip.contiguous(memory_format=torch.channels_last)
-            return BNReLUPoolFunction.apply(h, bn.weight, beta, bn.running_mean, bn.running_var,
-                                            float(bn.momentum), float(bn.eps), int(ph), int(pw), skip)
         if FUSED_BN and training and h.is_cuda:
             _warn_once(f"conv_bn_relu_pool: activation {tuple(h.shape)} {h.dtype} cannot use the HIP "
                        "BatchNorm+ReLU+pool kernels (needs float32 channels_last, C % 4 == 0, "
@@ -713,6 +727,21 @@ class ResNet9_myrtle(nn.Module):
         # logical (B, C, L') order, as nn.Flatten of the (B, C, L') tensor gives
         return F.max_pool2d(out, (1, self.pool1d.kernel_size)).squeeze(2).flatten(1)
 
+    def _pool_linear(self, out):
+        """MaxPool(4) -> Flatten -> Linear.  On the channels_last path the pooled (B, C, 1, L')
+        tensor is NOT re-laid-out to (B, C, L') for the flatten (a 20 MB copy forward and one
+        backward at bs 256): its memory order [l][c] is flattened as it is and the Linear's weight
+        columns are permuted to match (a 0.6 MB gather)."""
+        if out.dim() == 3:
+            return self.linear(self.flat(self.pool1d(out)))
+        p = F.max_pool2d(out, (1, self.pool1d.kernel_size))
+        B, C, _, L = p.shape
+        if not p.is_contiguous(memory_format=torch.channels_last) or C * L != self.linear.in_features:
+            return self.linear(p.squeeze(2).flatten(1))
+        feat = p.permute(0, 2, 3, 1).reshape(B, L * C)                    # a view
+        w = self.linear.weight.view(-1, C, L).permute(0, 2, 1).reshape(-1, L * C)
+        return F.linear(feat, w, self.linear.bias)
+
     def forward(self, out, depth=None, pass_part=None):
         if pass_part == "first" and depth == 0:
             return out
@@ -737,11 +766,11 @@ class ResNet9_myrtle(nn.Module):
             if depth <= 1:
                 out = self._stage2(out)
             if depth <= 2:
-                out = self._pool_flat(out)
+                return self._pool_linear(out)
             if depth <= 3:
                 out = self.linear(out)
             return out
-        return self.linear(self._pool_flat(self._stage2(self._stage1(out))))
+        return self._pool_linear(self._stage2(self._stage1(out)))
 
 
 def resnet9_flat_features(sig_len: int, width: int = 512) -> int:
