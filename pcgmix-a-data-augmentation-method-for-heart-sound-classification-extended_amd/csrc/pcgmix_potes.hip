@@ -341,6 +341,26 @@ __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
   }
 }
 
+// Sum over the 64 lanes of a wave on the VALU alone (DPP: no LDS traffic), total in lane 63.
+// quad swaps, half-row and row mirrors leave every lane of a row with the row's sum; row_bcast15 /
+// row_bcast31 carry it across the four rows.  The kernel-end reduction of the backward's 53
+// accumulators was 318 ds_bpermute_b32 per wave through __shfl_xor — 6.5 us of a 78 us kernel, all
+// of it in the tail where every block of the launch does nothing else.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                 0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+  v = dpp_add<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);    // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);    // row_mirror
+  v = dpp_add<0x142, 0xa>(v);    // row_bcast15 into rows 1, 3
+  v = dpp_add<0x143, 0xc>(v);    // row_bcast31 into rows 2, 3
+  return v;
+}
+
 // ---------------------------------------------------------------------------------- backward
 // Work item = (row, tile).  A tile OWNS kBwdTP pooled outputs p0 .. p0+TP-1, i.e. conv2 outputs
 // j = 2p0+s (s < 2TP), layer-1 pooled positions q = 2p0+r (r < 2TP) and conv1 outputs
@@ -575,14 +595,9 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
     flat[51 + c] = accb1[c];
   }
 #pragma unroll
-  for (int e = 0; e < kNAcc; ++e) {
-    float v = flat[e];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    flat[e] = v;
-  }
+  for (int e = 0; e < kNAcc; ++e) flat[e] = wave_sum_lane63(flat[e]);
   __syncthreads();
-  if (lane == 0)
+  if (lane == 63)
 #pragma unroll
     for (int e = 0; e < kNAcc; ++e) red[wave * kNAcc + e] = flat[e];
   __syncthreads();
