@@ -887,10 +887,13 @@ constexpr int kSkStride = 68;       // LDS row stride in floats (16-byte aligned
 // parked in LDS: element e = b*K + k owns `bits` (1, 2, 4 or 8) consecutive random bits of `mask`
 // (bit offset e*bits), kept iff their value >= thr, kept values times `scale`.  Spares the
 // separate dropout pass (a 20 MB write and re-read at bs=256).
-template <int O, bool MASK>
+// BITS: 0 = the mask's bits per element is the run-time argument; 2 = compile-time (Dropout(.25),
+// the reference's value: constant shifts and masks in the decode).
+template <int O, bool MASK, int BITS = 0>
 __global__ __launch_bounds__(kSkinnyWaves * 64) void skinny_linear_partial_kernel(
     const float* __restrict__ h, const float* __restrict__ W, float* __restrict__ partial, int B,
-    int K, const uint8_t* __restrict__ mask, float scale, int thr, int bits) {
+    int K, const uint8_t* __restrict__ mask, float scale, int thr, int bits_rt) {
+  const int bits = BITS ? BITS : bits_rt;
   constexpr int kWRows = (O + 3) / 4 * 4;                                // W tile rows in LDS
   constexpr int kWaveFloats = (32 + kWRows) * kSkStride;
   __shared__ __align__(16) float smem[kSkinnyWaves * kWaveFloats];
@@ -1334,7 +1337,10 @@ hipError_t launch_skinny_partial(const float* h, const float* W, float* partial,
   const int KS = pcgmix_skinny_linear_splits(B, K);
   dim3 grid((unsigned)((B + kSkinnyRows - 1) / kSkinnyRows), (unsigned)KS),
       block(kSkinnyWaves * 64);
-  if (O == 20 && mask) {
+  if (O == 20 && mask && bits == 2) {
+    hipLaunchKernelGGL((skinny_linear_partial_kernel<20, true, 2>), grid, block, 0, s, h, W, partial, B,
+                       K, mask, scale, thr, bits);
+  } else if (O == 20 && mask) {
     hipLaunchKernelGGL((skinny_linear_partial_kernel<20, true>), grid, block, 0, s, h, W, partial, B, K,
                        mask, scale, thr, bits);
   } else if (mask) {
