@@ -248,9 +248,27 @@ __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
   load_weights(&W, w1, b1, w2, b2);
   {
     const float* xrow = x + (size_t)n * T;
-    for (int u = threadIdx.x; u < kFwdNX; u += kPotThreads) {
-      const int g = xlo + u, i = u >> 2;
-      xs[(i & 1) * kXPlane + 4 * (i >> 1) + (u & 3)] = (g >= 0 && g < T) ? xrow[g] : 0.f;
+    auto put = [&](int u, float v) {                 // tile element u -> swizzled planes
+      const int i = u >> 2;
+      xs[(i & 1) * kXPlane + 4 * (i >> 1) + (u & 3)] = v;
+    };
+    if (!(T & 3) && !(reinterpret_cast<uintptr_t>(x) & 15)) {
+      // The tile starts at x[4*p0 - 3]: one aligned 16-byte load per thread from x[4*p0 - 4]
+      // (256 threads cover the 1020 elements) instead of four 4-byte loads; rows are 16-byte
+      // aligned and T % 4 == 0, so a quad is wholly inside the row or wholly outside.
+      const int g0 = 4 * p0 - 4 + 4 * (int)threadIdx.x;
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (g0 >= 0 && g0 < T) v = *reinterpret_cast<const f4*>(xrow + g0);
+      const int u0 = 4 * (int)threadIdx.x - 1;       // tile index of v.x
+      if (u0 >= 0) put(u0, v.x);
+      put(u0 + 1, v.y);
+      put(u0 + 2, v.z);
+      if (u0 + 3 < kFwdNX) put(u0 + 3, v.w);
+    } else {
+      for (int u = threadIdx.x; u < kFwdNX; u += kPotThreads) {
+        const int g = xlo + u;
+        put(u, (g >= 0 && g < T) ? xrow[g] : 0.f);
+      }
     }
   }
   __syncthreads();
