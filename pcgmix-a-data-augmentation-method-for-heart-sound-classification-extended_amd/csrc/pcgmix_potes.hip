@@ -770,7 +770,6 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_mask_kernel(
     const float* __restrict__ gh2, const uint8_t* __restrict__ m2, const uint8_t* __restrict__ s1,
     const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ gx, int N,
     int T) {
-  __shared__ float w1s[kNW1];
   constexpr int kDz2Row = kBwdNJ + 12;
   __shared__ __align__(16) float dz2s[kC2 * kDz2Row];
   __shared__ __align__(16) float dz1s[kC1 * kBwdNIpad];
@@ -778,7 +777,6 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_mask_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.y, p0 = blockIdx.x * kInTP;
   const int m2s = (d.P2 + 3) / 4;
-  for (int i = threadIdx.x; i < kNW1; i += kPotThreads) w1s[i] = w1[i];
   // first-layer selectors of this lane's 4 positions q = 2p0-2+4*lane+u for its two channels:
   // issued now, consumed after the first barrier
   // (packed: position q sits in bits 2*((q+1)&3) of byte (q+1)>>2; q+1 = 2*p0 - 1 + 4*lane + u with
@@ -846,30 +844,34 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_mask_kernel(
     }
   }
   __syncthreads();
-  {  // transposed conv1: dx[u] = sum_ci sum_k dz1[ci][u+1-k] * w1[ci][k]; dz1 index v+5-k
-    const int v0 = 2 * threadIdx.x;
+  {  // transposed conv1: dx[u] = sum_ci sum_k dz1[ci][u+1-k] * w1[ci][k]; dz1 index v+5-k.
+     // Thread t takes the outputs v = 2t-1 and 2t: its six dz1 values then start at the EVEN index
+     // 2t — three 8-byte LDS reads per channel instead of six 4-byte ones — and the 40 weights
+     // come through the scalar cache (block-uniform) instead of 40 more LDS reads per thread:
+     // this phase issued 88 LDS reads for its 80 multiply-adds.
+    const int v0 = 2 * (int)threadIdx.x - 1;
     if (v0 < kInNU) {
       float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
       for (int ci = 0; ci < kC1; ++ci) {
-        float dw[6], w[kK];
+        float dw[6];
 #pragma unroll
         for (int j = 0; j < 6; j += 2) {
-          dw[j] = dz1s[ci * kBwdNIpad + v0 + 1 + j];
-          dw[j + 1] = dz1s[ci * kBwdNIpad + v0 + 2 + j];
+          const float2 v = *reinterpret_cast<const float2*>(dz1s + ci * kBwdNIpad + v0 + 1 + j);
+          dw[j] = v.x;
+          dw[j + 1] = v.y;
         }
 #pragma unroll
-        for (int k = 0; k < kK; ++k) w[k] = w1s[ci * kK + k];
-#pragma unroll
         for (int k = 0; k < kK; ++k) {
-          acc0 = fmaf(dw[4 - k], w[k], acc0);
-          acc1 = fmaf(dw[5 - k], w[k], acc1);
+          const float w = w1[ci * kK + k];
+          acc0 = fmaf(dw[4 - k], w, acc0);
+          acc1 = fmaf(dw[5 - k], w, acc1);
         }
       }
       const int u = 4 * p0 + v0;
       float* dst = gx + (size_t)n * T + u;
-      if (u < T) dst[0] = acc0;
-      if (u + 1 < T) dst[1] = acc1;
+      if (v0 >= 0 && u < T) dst[0] = acc0;
+      if (v0 + 1 < kInNU && u + 1 < T) dst[1] = acc1;
     }
   }
 }
