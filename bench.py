@@ -89,27 +89,54 @@ def settle_heap():
     gc.freeze()
 
 
+STAMPS = [0.0] * 4096     # preallocated: per-call host clock reads of a traced region
+
+
+def call_trace(t0, stamps, n, dt, steps):
+    """Host-side return time of each call of a timed region (the calls are asynchronous: this is
+    when the host came back, the queue drains behind it): first / last call and the region's tail
+    (synchronize + barrier), in us — shows whether a short region is at steady state."""
+    d = [1e6 * (b - a) for a, b in zip([t0] + stamps[:n - 1], stamps[:n])]
+    return {"first_call_us": d[0], "last_call_us": d[-1], "median_call_us": float(np.median(d)),
+            "max_call_us": max(d), "drain_us": 1e6 * (t0 + dt - stamps[n - 1]) if n == steps else None,
+            "first_5_calls_us": d[:5]}
+
+
 def run_augment_steps(method, data, tgt, frames, wav, device, steps, warmup, barrier,
-                      host_labels=None):
+                      host_labels=None, trace=None):
     """``steps`` calls of the drop-in ``augment()`` through the reference's positional signature
     (``host_labels``: the keyword extension that spares the label read-back, for the split of the
     step time reported under extra.host_split)."""
     args, sc = Args(method), StepCounter()
     kw = {} if host_labels is None else {"host_labels": host_labels}
+    # Heap settling (tens of ms of host-only work) comes BEFORE the warm-up: nothing but the
+    # barrier sits between the last warm-up call and t0, so a 20-step region is steady state.
+    settle_heap()
     for _ in range(warmup):
         augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "", **kw)
         sc.add()
-    settle_heap()                                   # before the barrier: its duration differs per rank
     barrier()
     torch.cuda.synchronize()
+    stamps = STAMPS if trace is not None else None
     t0 = time.perf_counter()
-    for _ in range(steps):
-        out = augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "", **kw)
-        sc.add()
+    if stamps is None:
+        for _ in range(steps):
+            out = augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "", **kw)
+            sc.add()
+    else:                                           # same loop + one clock read per call (~40 ns)
+        n = 0
+        for _ in range(steps):
+            out = augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "", **kw)
+            sc.add()
+            if n < len(stamps):
+                stamps[n] = time.perf_counter()
+                n += 1
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     gc.unfreeze()
+    if trace is not None:
+        trace.update(call_trace(t0, stamps, min(steps, len(stamps)), dt, steps))
     return dt, out
 
 
@@ -295,22 +322,27 @@ def build_train_step(method, model_name, B, C, T, rate, device, total_steps, ran
 
 def run_train_steps(step, info, steps, warmup, barrier, tag):
     PROGRESS["leg"] = tag
+    settle_heap()                                   # before the warm-up (see run_augment_steps)
     for i in range(warmup):
         PROGRESS["step"] = i - warmup
         step()
-    settle_heap()                                   # before the barrier: its duration differs per rank
     barrier()
     torch.cuda.synchronize()
+    stamps, n = STAMPS, 0
     t0 = time.perf_counter()
     for i in range(steps):
         PROGRESS["step"] = i
         loss = step()
+        if n < len(stamps):
+            stamps[n] = time.perf_counter()
+            n += 1
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     gc.unfreeze()
     PROGRESS["leg"] = ""
-    return dict(info, steps_per_s=steps / dt, ms_per_step=1e3 * dt / steps, loss=float(loss))
+    return dict(info, steps_per_s=steps / dt, ms_per_step=1e3 * dt / steps, loss=float(loss),
+                call_trace=call_trace(t0, stamps, n, dt, steps))
 
 
 def train_steps_per_s(method, model_name, B, C, T, rate, device, steps, warmup, barrier, rank,
@@ -631,7 +663,9 @@ def main():
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumtime").print_stats(25)
     # the timed region carries nothing but the drop-in calls (no event recording inside it)
-    dt, _ = run_augment_steps(a.method, data, tgt, frames, wav, device, a.steps, a.warmup, barrier)
+    headline_trace = {}
+    dt, _ = run_augment_steps(a.method, data, tgt, frames, wav, device, a.steps, a.warmup, barrier,
+                              trace=headline_trace)
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -661,6 +695,7 @@ def main():
                    "batch_per_gpu": B, "channels": C, "sig_len": T, "method": a.method,
                    "parallelism": f"dp{world}"},
         "roofline": roof,
+        "call_trace": headline_trace,
     }
 
     # train step/s (second half of BASELINE.json's metric): 1D-CNN, bs 256 per GPU; N>1: one

@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 11
+#define PCGMIX_ABI_VERSION 12
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -572,6 +572,17 @@ int pcgmix_ctx_flush_payload(pcgmix_ctx* ctx, pcgmix_stream_t stream);
 int pcgmix_ctx_salopt_begin(pcgmix_ctx* ctx, const int64_t* target_ohe_dev, int num_classes,
                             float* seed_out, const int64_t* frames, int32_t* frames_dst_dev, int B,
                             int T, pcgmix_stream_t stream);
+/* begin for a caller that holds the class labels on the HOST (a training loop with the loader's
+ * CPU `target`, train_model.py:498-501): no read-back.  labels_host HOST int64 (B), values in
+ * [0, num_classes).  Up to 256 samples (T <= 32767, num_classes <= 256) ONE launch carries the
+ * labels, the boundaries and a pending pcgmix_ctx_set_payload of up to 320 bytes in its
+ * arguments and writes seed_out, frames_dst_dev and the payload's destination; larger batches
+ * stage [frames | labels] through a pinned slot (the payload then stays pending for
+ * pcgmix_ctx_flush_payload).  finish is called with the same labels_host.  Returns as begin.
+ * All step-context entry points return hipErrorStreamCaptureUnsupported on a capturing stream. */
+int pcgmix_ctx_salopt_begin_labels(pcgmix_ctx* ctx, const int64_t* labels_host, int num_classes,
+                                   float* seed_out, const int64_t* frames,
+                                   int32_t* frames_dst_dev, int B, int T, pcgmix_stream_t stream);
 int pcgmix_ctx_salopt_finish(pcgmix_ctx* ctx, const float* x, float* y, const float* sal,
                              const int32_t* frames_dev, const int64_t* labels_host, uint64_t step,
                              float lam, int mode, const double* knots, int n_knots, int64_t* mix_out,

@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -96,6 +96,8 @@ SIGNATURES = {
     "pcgmix_ctx_set_payload": (_c_int, [_ptr, _ptr, ctypes.c_size_t, _ptr]),
     "pcgmix_ctx_flush_payload": (_c_int, [_ptr, _ptr]),
     "pcgmix_ctx_salopt_begin": (_c_int, [_ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),
+    "pcgmix_ctx_salopt_begin_labels": (_c_int, [_ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _c_int, _c_int,
+                                                _ptr]),
     "pcgmix_ctx_salopt_finish": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_uint64, _c_float,
                                           _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_ctx_phase_times": (ctypes.c_longlong, [_ptr, _ptr]),

@@ -344,13 +344,17 @@ def splice_plain(recipe, data: torch.Tensor, labels, frames, step: int,
     return out, mix
 
 
-def _salopt_step(srec, g, data: torch.Tensor, ohe: torch.Tensor, labels, frames, step: int):
+def _salopt_step(srec, g, data: torch.Tensor, ohe: Optional[torch.Tensor], labels, frames, step: int,
+                 out: Optional[torch.Tensor] = None):
     """One fired saliency-guided step with same-label partners: two library calls around the
     captured saliency pass.  ``pcgmix_ctx_salopt_begin``: label arg-max kernel (labels to the
-    host, gradient seed to the graph) + boundaries to the device; replay; lambda and knots from
-    numpy's global stream (they do not depend on the labels) while the GPU works;
-    ``pcgmix_ctx_salopt_finish``: labels picked up, partners drawn, one H2D copy, displacement
-    search and fused splice(+warp).  Returns (out, mix_indices)."""
+    host, gradient seed to the graph) + boundaries to the device — or, when the caller holds the
+    labels on the host (``labels``; ``ohe`` may then be None), ``pcgmix_ctx_salopt_begin_labels``:
+    seed, boundaries and a pending step payload from the arguments of one launch, no read-back;
+    replay; lambda and knots from numpy's global stream (they do not depend on the labels) while
+    the GPU works; ``pcgmix_ctx_salopt_finish``: labels picked up, partners drawn, one H2D copy,
+    displacement search and fused splice(+warp) into ``out`` (a captured training step's static
+    input) or a new tensor.  Returns (out, mix_indices)."""
     mode, alpha, sigma, n_knots = srec
     B, C, T = data.shape
     idx = data.device.index
@@ -365,12 +369,21 @@ def _salopt_step(srec, g, data: torch.Tensor, ohe: torch.Tensor, labels, frames,
         if labels.shape[0] != B:
             raise ValueError("labels/frames do not match the batch size")
         lab_ptr = labels.ctypes.data
-    err = lib.pcgmix_ctx_salopt_begin(ctx, ohe.data_ptr(), ohe.shape[1], g.seed.data_ptr(), fr_ptr,
-                                      g.fr.data_ptr(), B, T, stream)
+    if out is not None and (out.shape != data.shape or out.dtype != data.dtype
+                            or not out.is_contiguous() or out.data_ptr() == data.data_ptr()):
+        raise ValueError("out must be a distinct contiguous tensor shaped like data")
+    if lab_ptr is not None:
+        name = "pcgmix_ctx_salopt_begin_labels"
+        err = lib.pcgmix_ctx_salopt_begin_labels(ctx, lab_ptr, g.seed.shape[1], g.seed.data_ptr(),
+                                                 fr_ptr, g.fr.data_ptr(), B, T, stream)
+    else:
+        name = "pcgmix_ctx_salopt_begin"
+        err = lib.pcgmix_ctx_salopt_begin(ctx, ohe.data_ptr(), ohe.shape[1], g.seed.data_ptr(), fr_ptr,
+                                          g.fr.data_ptr(), B, T, stream)
     if err:
         if err < 0:
-            raise ValueError(_SPLICE_ERRORS.get(err, f"pcgmix_ctx_salopt_begin error {err}"))
-        _lib.check(err, "pcgmix_ctx_salopt_begin")
+            raise ValueError(_SPLICE_ERRORS.get(err, f"{name} error {err}"))
+        _lib.check(err, name)
     if torch.cuda.current_device() == idx:
         sal = g.replay(data)
     else:
@@ -385,7 +398,8 @@ def _salopt_step(srec, g, data: torch.Tensor, ohe: torch.Tensor, labels, frames,
     if n_knots:
         knots = np.random.normal(loc=1.0, scale=sigma, size=(B, n_knots, C))
         knots_ptr = knots.ctypes.data
-    out = torch.empty_like(data)
+    if out is None:
+        out = torch.empty_like(data)
     mix = np.empty(B, dtype=np.int64)
     _lib.check(lib.pcgmix_ctx_salopt_finish(
         ctx, data.data_ptr(), out.data_ptr(), sal.data_ptr(), g.fr.data_ptr(), lab_ptr, step,
@@ -497,8 +511,9 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
         ohe_ok = ohe.dim() == 2 and ohe.is_cuda and ohe.dtype == torch.int64 and ohe.is_contiguous() \
             and ohe.shape[0] == B
         srec = hostprep.salopt_recipe(method)
-        if g is not None and ohe_ok and srec is not None:
-            out, mix = _salopt_step(srec, g, data, ohe, host_labels, frames, step)
+        if g is not None and srec is not None and (ohe_ok or host_labels is not None):
+            out, mix = _salopt_step(srec, g, data, ohe if host_labels is None else None, host_labels,
+                                    frames, step)
             return out, target_ohe, mix, None
         if g is not None and ohe_ok:
             lib = _lib.load()

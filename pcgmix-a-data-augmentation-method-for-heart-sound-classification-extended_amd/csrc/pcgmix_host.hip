@@ -14,6 +14,17 @@
 
 #include "pcgmix_kernels.h"
 
+namespace {
+// The step-context entry points stage through pinned slots they may have to (re)allocate, wait on
+// events, spin on host-mapped memory and carry per-step index data in kernel ARGUMENTS (frozen at
+// capture): none of that belongs in a stream capture.  They refuse a capturing stream up front,
+// before any of their first-call work (hipHostMalloc / hipMalloc / hipMemcpy) can invalidate it.
+bool stream_is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+}  // namespace
+
 extern "C" int pcgmix_abi_version(void) { return PCGMIX_ABI_VERSION; }
 
 extern "C" const char* pcgmix_error_string(int err) {
@@ -360,6 +371,7 @@ extern "C" int pcgmix_splice_same_label_ohe_f32(const float* x, float* y,
                                                 int B, int C, int T, pcgmix_stream_t stream) {
   if (!target_ohe_dev || !ohe_pinned || num_classes <= 0 || B <= 0) return hipErrorInvalidValue;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stream_is_capturing(s)) return hipErrorStreamCaptureUnsupported;   // synchronises below
   const size_t n = (size_t)B * num_classes;
   hipError_t e = hipMemcpyAsync(ohe_pinned, target_ohe_dev, n * sizeof(int64_t),
                                 hipMemcpyDeviceToHost, s);
@@ -465,6 +477,50 @@ __global__ __launch_bounds__(256) void label_frames_kernel(const int64_t* __rest
     const int w = fp.w[i >> 1];
     frames_out[i] = (i & 1) ? (w >> 16) : ((int)((unsigned)w << 16) >> 16);
   }
+}
+
+// The begin of a saliency-guided step whose class labels are already on the HOST (a training loop
+// that still holds the loader's CPU targets): no label read-back, so ONE launch delivers everything
+// the step's first half needs, all of it in the kernel ARGUMENTS — the labels (uint8) become the
+// float one-hot gradient seed of the saliency pass (saliency.py:52-61), the boundaries (int16)
+// become the int32 array post-processing, search and splice read, and a pending step payload of
+// up to kPackPayBytes (pcgmix_ctx_set_payload: targets, dropout key, optimiser scalars of a
+// captured training step) goes to its static device address.
+struct LabelPack {
+  int32_t w[pcgmix::kPackB / 4];
+};
+struct StepPayPack {
+  uint4 w[pcgmix::kPackPayBytes / 16];
+};
+__global__ __launch_bounds__(256) void seed_frames_kernel(const LabelPack lp, int K, int B,
+                                                          float* __restrict__ seed,
+                                                          const FramePack fp,
+                                                          int32_t* __restrict__ frames_out,
+                                                          const StepPayPack pay,
+                                                          uint4* __restrict__ pay_dst, int pay_n16) {
+  if ((int)threadIdx.x < pay_n16) pay_dst[threadIdx.x] = pay.w[threadIdx.x];
+  if (seed)
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+      const int lab = (lp.w[b >> 2] >> (8 * (b & 3))) & 0xff;
+      for (int c = 0; c < K; ++c) seed[(size_t)b * K + c] = c == lab ? 1.f : 0.f;
+    }
+  for (int i = threadIdx.x; i < B * 5; i += blockDim.x) {
+    const int w = fp.w[i >> 1];
+    frames_out[i] = (i & 1) ? (w >> 16) : ((int)((unsigned)w << 16) >> 16);
+  }
+}
+
+// The same from device memory, for batches beyond kPackB: [frames int32 B*5 | labels int32 B].
+__global__ __launch_bounds__(256) void seed_from_labels_kernel(const int32_t* __restrict__ blk, int K,
+                                                               int B, float* __restrict__ seed,
+                                                               int32_t* __restrict__ frames_out) {
+  const int i0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+  if (seed)
+    for (int b = i0; b < B; b += stride) {
+      const int lab = blk[B * 5 + b];
+      for (int c = 0; c < K; ++c) seed[(size_t)b * K + c] = c == lab ? 1.f : 0.f;
+    }
+  for (int i = i0; i < B * 5; i += stride) frames_out[i] = blk[i];
 }
 
 // Host-to-device copy as a kernel: n16 16-byte words from device-readable host memory (a pinned
@@ -712,9 +768,7 @@ struct DeviceGuard {      // make the context's device current for the call
 // flag word takes the returned token.
 // Capture check, label memory sized for B, next token: what precedes the launch of a label kernel.
 hipError_t labels_prepare(pcgmix_ctx* c, int B, hipStream_t s) {
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-    return hipErrorStreamCaptureUnsupported;     // a host wait cannot be captured
+  if (stream_is_capturing(s)) return hipErrorStreamCaptureUnsupported;   // a host wait cannot be captured
   if (c->lab_cap < (size_t)B) {
     if (c->lab) (void)hipHostFree(c->lab);
     c->lab = nullptr;
@@ -805,6 +859,7 @@ extern "C" int pcgmix_ctx_flush_payload(pcgmix_ctx* c, pcgmix_stream_t stream) {
   if (!c) return hipErrorInvalidValue;
   if (c->payload.empty()) return hipSuccess;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stream_is_capturing(s)) return hipErrorStreamCaptureUnsupported;
   int cur = 0;
   hipError_t e = hipGetDevice(&cur);
   if (e != hipSuccess) return (int)e;
@@ -839,6 +894,7 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
       (knots && n_knots < 2))
     return hipErrorInvalidValue;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stream_is_capturing(s)) return hipErrorStreamCaptureUnsupported;
   auto tp = std::chrono::steady_clock::now();
   auto lap = [&](int i) {
     const auto now = std::chrono::steady_clock::now();
@@ -979,6 +1035,7 @@ extern "C" int pcgmix_ctx_salopt_begin(pcgmix_ctx* c, const int64_t* target_ohe_
   if (!c || !frames || !frames_dst_dev || B <= 0 || T <= 0 || (target_ohe_dev && num_classes <= 0))
     return hipErrorInvalidValue;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stream_is_capturing(s)) return hipErrorStreamCaptureUnsupported;
   DeviceGuard guard(c->device);
   hipError_t e = guard.err;
   if (e != hipSuccess) return (int)e;
@@ -1023,6 +1080,80 @@ extern "C" int pcgmix_ctx_salopt_begin(pcgmix_ctx* c, const int64_t* target_ohe_
   return (int)slot_commit(c, my_slot, s);
 }
 
+// begin with the class labels on the HOST: no read-back, no flag.  Up to kPackB samples everything
+// rides in the arguments of ONE launch (seed_frames_kernel), a pending step payload of up to
+// kPackPayBytes included (it is then consumed); larger batches stage [frames | labels] through a
+// slot and leave the payload pending (pcgmix_ctx_flush_payload).
+extern "C" int pcgmix_ctx_salopt_begin_labels(pcgmix_ctx* c, const int64_t* labels_host,
+                                              int num_classes, float* seed_out,
+                                              const int64_t* frames, int32_t* frames_dst_dev, int B,
+                                              int T, pcgmix_stream_t stream) {
+  if (!c || !labels_host || !frames || !frames_dst_dev || B <= 0 || T <= 0 || num_classes <= 0)
+    return hipErrorInvalidValue;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stream_is_capturing(s)) return hipErrorStreamCaptureUnsupported;
+  DeviceGuard guard(c->device);
+  hipError_t e = guard.err;
+  if (e != hipSuccess) return (int)e;
+  for (int b = 0; b < B; ++b)
+    if (labels_host[b] < 0 || labels_host[b] >= num_classes) return hipErrorInvalidValue;
+  if (B <= pcgmix::kPackB && T <= 32767 && num_classes <= 256) {
+    FramePack fp;
+    LabelPack lp;
+    StepPayPack pay;
+    int16_t* p16 = reinterpret_cast<int16_t*>(fp.w);
+    uint8_t* p8 = reinterpret_cast<uint8_t*>(lp.w);
+    int bad16 = 0;
+    int64_t longest = 0;
+    for (int b = 0; b < B; ++b) {
+      const int64_t* r = frames + (size_t)b * 5;
+      if (r[0] < 0) bad16 = bad16 ? bad16 : -1;
+      for (int k = 0; k < 4; ++k) {
+        if (r[k + 1] < r[k]) bad16 = bad16 ? bad16 : -1;
+        if (r[k + 1] - r[k] > longest) longest = r[k + 1] - r[k];
+      }
+      if (r[4] > T) bad16 = bad16 ? bad16 : -2;
+      for (int k = 0; k < 5; ++k) p16[b * 5 + k] = (int16_t)r[k];
+      p8[b] = (uint8_t)labels_host[b];
+    }
+    if (bad16) return bad16;
+    int pay_n16 = 0;
+    void* pay_dst = nullptr;
+    if (!c->payload.empty() && c->payload.size() <= (size_t)pcgmix::kPackPayBytes) {
+      std::memcpy(pay.w, c->payload.data(), c->payload.size());
+      pay_n16 = (int)(c->payload.size() / 16);
+      pay_dst = c->payload_dst;
+    }
+    hipLaunchKernelGGL(seed_frames_kernel, dim3(1), dim3(256), 0, s, lp, num_classes, B, seed_out, fp,
+                       frames_dst_dev, pay, static_cast<uint4*>(pay_dst), pay_n16);
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    if (pay_n16) {
+      c->payload.clear();
+      c->payload_dst = nullptr;
+    }
+    c->sal_B = B;
+    c->sal_max_len = (int)(longest > T ? T : longest);
+    return hipSuccess;
+  }
+  const int my_slot = c->next;
+  if ((e = slot_reserve(c, my_slot, (size_t)B * 24)) != hipSuccess) return (int)e;
+  Slot& sl = c->slot[my_slot];
+  int32_t* st = reinterpret_cast<int32_t*>(sl.pinned);
+  int max_len = 0;
+  const int bad = pack_frames(frames, B, T, st, &max_len);
+  if (bad) return bad;
+  for (int b = 0; b < B; ++b) st[(size_t)B * 5 + b] = (int32_t)labels_host[b];
+  if ((e = upload_slot(sl, (size_t)B * 24, s)) != hipSuccess) return (int)e;
+  const int blocks = (B * 5 + 255) / 256 < 64 ? (B * 5 + 255) / 256 : 64;
+  hipLaunchKernelGGL(seed_from_labels_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                     reinterpret_cast<const int32_t*>(sl.dev), num_classes, B, seed_out,
+                     frames_dst_dev);
+  if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+  c->sal_B = B;
+  c->sal_max_len = max_len;
+  return (int)slot_commit(c, my_slot, s);
+}
+
 // finish: labels picked up (or handed over), same-label partners drawn, [mix | knots] sent in one
 // copy, displacement search and fused splice(+warp) enqueued (pcgmix_salopt_mix_warp_f32's pair
 // of kernels; the search workspace is the context's).  frames_dev = begin's frames_dst_dev.
@@ -1035,6 +1166,7 @@ extern "C" int pcgmix_ctx_salopt_finish(pcgmix_ctx* c, const float* x, float* y,
       (knots && n_knots < 2) || (mode != 0 && mode != 1) || (!labels_host && (size_t)B > c->lab_cap))
     return hipErrorInvalidValue;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stream_is_capturing(s)) return hipErrorStreamCaptureUnsupported;
   DeviceGuard guard(c->device);
   hipError_t e = guard.err;
   if (e != hipSuccess) return (int)e;

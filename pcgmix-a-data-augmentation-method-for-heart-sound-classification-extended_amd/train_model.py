@@ -571,7 +571,7 @@ class GraphedTrainStep:
         self._pay_key[1] = z >> 32
 
     def step(self, batch, epoch, step_counter, stats: Optional[dict] = None):
-        from . import hostprep, _lib
+        from . import hostprep, _lib, saliency as _saliency
         data, target, frames, wav, _sq, _idx = batch
         if self.es is not None and epoch > self.es:
             raise NotImplementedError("SELC phase is not captured; use train_step")
@@ -592,22 +592,39 @@ class GraphedTrainStep:
         if self.adam_in_graph:
             self.opt.next_hyper(self._pay_hyper)
         recipe = hostprep.plain_recipe(args.method, False)
+        srec = hostprep.salopt_recipe(args.method) if recipe is None else None
         lib, ctx = _lib.load(), augmentations.step_context(data.device.index)
         _lib.check(lib.pcgmix_ctx_set_payload(ctx, self._payload.ctypes.data, self._pay_bytes,
                                               self.aux.data_ptr()), "pcgmix_ctx_set_payload")
+        plan = hostprep.MixPlan(fired=False)
         if recipe is not None and B > 0:                # plain splice: one library call
             fired = augmentations.gate_passes(recipe, args.method, step, data.device.index)
-            plan = hostprep.MixPlan(fired=False)
             if fired:                                   # ... which carries the payload along
                 augmentations.splice_plain(recipe, data, labels_np, frames_np, step, out=self.x)
+        elif srec is not None and B > 0:
+            # Saliency-guided splice with same-label partners (BASELINE config 3; augmentations.py:
+            # 874-928): seed + boundaries + this step's payload in the arguments of one launch,
+            # the frozen saliency model's captured pass, then search + splice straight into the
+            # training graph's static input — the whole step stays on the stream, no host wait.
+            fired = hostprep.gate_fires(args.method, step)
+            if fired:
+                g = _saliency.step_graph(args, data, args.num_classes)
+                if g is None:
+                    raise RuntimeError("the captured saliency pass is unavailable (saliency.USE_GRAPHS "
+                                       "is off or the stream is capturing)")
+                with torch.cuda.device(self.device):
+                    augmentations._salopt_step(srec, g, data, None, labels_np, frames_np, step,
+                                               out=self.x)
         else:
-            plan = hostprep.make_plan(args.method, labels_np, frames_np, wav, step, B, C) \
-                if hostprep.select_method(args.method, False) else hostprep.MixPlan(fired=False)
-            if plan.salopt_mode is not None:
-                raise NotImplementedError("saliency-guided steps are not captured; use train_step")
+            if hostprep.select_method(args.method, False):
+                plan = hostprep.make_plan(args.method, labels_np, frames_np, wav, step, B, C)
             fired = plan.fired
             if fired:
-                augmentations.apply_plan(plan, data, frames_np, out=self.x)
+                sal = None
+                if plan.salopt_mode is not None:        # salopt with '(samePCG)' & co.: general path
+                    t_dev = F.one_hot(target, args.num_classes).to(self.device, non_blocking=True)
+                    sal = _saliency.get_saliency_maps(args, self.device, data, t_dev, frames_np)
+                augmentations.apply_plan(plan, data, frames_np, sal, out=self.x)
         if not fired:
             self.x.copy_(data, non_blocking=True)
         # any other step: the payload goes on its own (no-op when the splice took it)
@@ -767,8 +784,7 @@ def train_model(args, dataset, device, use_graph: bool = True, log=print):
     rank, world = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
     args.num_steps = args.num_epochs * (len(train_loader.dataset) // args.batch_size)   # :390
     criterion = SELCLoss(train_labels, args.num_classes, es=selc_turning_point(args), device=device)
-    graphable = use_graph and device.type == "cuda" and "(salopt" not in args.method \
-        and args.num_epochs <= criterion.es
+    graphable = use_graph and device.type == "cuda" and args.num_epochs <= criterion.es
     if not graphable:
         model = wrap_distributed(model, device)
     optimizer, scheduler = make_optimizer(args, model)

@@ -49,3 +49,78 @@ def eval_loader():
     x, labels, wav = eval_pool()
     return [(torch.from_numpy(x[i:i + 24]), torch.from_numpy(labels[i:i + 24]), None,
              tuple(wav[i:i + 24]), None, None) for i in (0, 24)]
+
+
+# ---- round 3: saliency-guided Potes trajectory, ResNet9 train-mode trajectories ----------------
+SALOPT_STEPS, SALOPT_B = 5, 8
+SALOPT_METHOD = "(saloptenv)durmixmagwarp(0.2,4)"
+RESNET_STEPS = 3
+RESNET1D_B, RESNET2D_B = 8, 4
+# OneCycleLR's total_steps (= args.num_steps, train_model.py:390, 410) for these short replays: the
+# first steps of a 40-step schedule (lr from max_lr/25 upwards) rather than a whole 3- or 5-step
+# cycle, whose very first update already runs at max_lr and sends the ResNet9 loss to ~500.
+SCHED_STEPS = 40
+
+
+def salopt_traj_args(experiments_dir):
+    """train_epoch's fields plus what utils.experiment_dir reads (utils.py:34-53): the saliency
+    model is the 'base' run's model.pth under ``experiments_dir`` (saliency.py:26-51)."""
+    a = traj_args()
+    a.__dict__.update(method=SALOPT_METHOD, batch_size=SALOPT_B, num_steps=SCHED_STEPS, num_epochs=50,
+                      n_fraction=1.0, train_balance=True, seed_data=1100001, valid=False,
+                      EXPERIMENTS=experiments_dir)
+    return a
+
+
+def salopt_traj_batches():
+    out = []
+    for i in range(SALOPT_STEPS):
+        x, frames, labels, wav = synthetic.make_batch(SALOPT_B, 4, 2500, sample_rate=1000, seed=300 + i)
+        out.append((torch.from_numpy(x), torch.from_numpy(labels), torch.from_numpy(frames), wav,
+                    torch.ones(SALOPT_B, dtype=torch.long), torch.arange(SALOPT_B) + SALOPT_B * i))
+    return out
+
+
+def resnet1d_args():
+    a = traj_args()
+    a.__dict__.update(model="resnet9", method="durmixmagwarp(0.2,4)", batch_size=RESNET1D_B,
+                      num_steps=SCHED_STEPS)
+    return a
+
+
+def resnet1d_batches():
+    out = []
+    for i in range(RESNET_STEPS):
+        x, frames, labels, wav = synthetic.make_batch(RESNET1D_B, 4, 2500, sample_rate=1000, seed=400 + i)
+        out.append((torch.from_numpy(x), torch.from_numpy(labels), torch.from_numpy(frames), wav,
+                    torch.ones(RESNET1D_B, dtype=torch.long), torch.arange(RESNET1D_B) + RESNET1D_B * i))
+    return out
+
+
+def resnet2d_args():
+    a = traj_args()
+    a.__dict__.update(model="resnet9", dataset="PhysioNet(spec128)", method="durratiomixup",
+                      batch_size=RESNET2D_B, num_steps=SCHED_STEPS, num_channels=1)
+    return a
+
+
+def resnet2d_batches():
+    """(4,1,128,128) images: noise inside the cycle's columns, zero (the mean level) after, with
+    boundaries in spectrogram columns as databuilder.ipynb cell 6:101 rounds them."""
+    out = []
+    for i in range(RESNET_STEPS):
+        _, frames, labels, wav = synthetic.make_batch(RESNET2D_B, 1, 5000, sample_rate=2000, seed=500 + i)
+        fs = synthetic.spec_frames(frames, 148, 5000)
+        x = np.random.RandomState(600 + i).standard_normal((RESNET2D_B, 1, 128, 128)).astype(np.float32)
+        x[np.broadcast_to(np.arange(128)[None, None, None, :] >= fs[:, 4][:, None, None, None], x.shape)] = 0
+        out.append((torch.from_numpy(x), torch.from_numpy(labels), torch.from_numpy(fs), wav,
+                    torch.ones(RESNET2D_B, dtype=torch.long), torch.arange(RESNET2D_B) + RESNET2D_B * i))
+    return out
+
+
+def tensor_digest(t, n=512):
+    """A compact image of a large tensor for a fixture: float64 sum, sum of squares, and ``n``
+    evenly strided elements (all of them when the tensor has at most ``n``)."""
+    a = np.asarray(t, dtype=np.float64).reshape(-1)
+    idx = np.unique(np.linspace(0, a.size - 1, min(n, a.size)).astype(np.int64))
+    return np.concatenate([[a.sum(), (a * a).sum()], a[idx]])
