@@ -313,6 +313,161 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
   mix_body<VEC, WARP, U>(x, y, lam, oml, knots, spline_op, n_knots, zero_rect, C, T, epb, b, m, sm, lds);
 }
 
+// ---- splice + warp, one lane = one quad of sample positions for ALL channels -------------------
+// The spline's break points are the same for every channel (linspace(0, T-1, n),
+// augmentations.py:676), so everything that depends on the sample position only — the state
+// classification and partner shift of the splice, the spline piece, s = t - brk, s^2, s^3 and the
+// int -> float64 conversion — is computed once per position and reused by the C channels of the
+// row group (mix_body computes it per (channel, position): 4 of its 13 float64 operations per
+// element, plus all of the integer work).  Same arithmetic per element, in the same order, each
+// operation rounded on its own: bit-identical output (tests/test_mix_gpu.py).
+// Block = kThreads * 4 * UT consecutive positions of one sample, all channels; LDS = the C * (n-1)
+// coefficient records of the sample, built while the first loads are in flight.
+template <int CG, int UT>
+__global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
+    const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ frames,
+    const int32_t* __restrict__ mix_idx, const int32_t* __restrict__ off, float lam, float oml,
+    const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots, int B, int C,
+    int T, const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst, int pay_n16,
+    const float2* __restrict__ disp_part, const PartnerPack pk) {
+  extern __shared__ __align__(16) double lds[];  // C * (n_knots - 1) records, then thresholds
+  if (pay_n16 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0)
+    for (int i = threadIdx.x; i < pay_n16; i += kThreads) pay_dst[i] = pay_src[i];
+  const int b = blockIdx.z * kBatchPerGridZ + blockIdx.y;
+  if (b >= B) return;  // block-uniform
+  int m = pk.n ? partner_get(pk, b) : mix_idx[b];
+  m = (m < 0 || m >= B) ? b : m;
+  const StateMap sm = make_state_map(frames, off, b, m, T, disp_part);
+  const size_t own_base = (size_t)b * C * T, par_base = (size_t)m * C * T;
+  const int rec_per_ch = (n_knots - 1) * kRec;
+  int* thr = reinterpret_cast<int*>(lds + (size_t)C * rec_per_ch);
+  const int tq0 = blockIdx.x * (kThreads * 4 * UT);
+
+  // per position quad: where the partner quad comes from and which elements blend (as mix_body)
+  int t0s[UT], masks[UT], src0s[UT];
+#pragma unroll
+  for (int q = 0; q < UT; ++q) {
+    const int t0 = tq0 + (q * kThreads + (int)threadIdx.x) * 4;
+    const bool valid = t0 < T;
+    const int tt = valid ? t0 : 0;
+    bool hit[4];
+    int d[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = blend_shift(sm, tt + e, hit[e]);
+    const int dsel = hit[0] ? d[0] : hit[1] ? d[1] : hit[2] ? d[2] : hit[3] ? d[3] : 0;
+    int src0 = tt + dsel;
+    src0 = src0 < 0 ? 0 : (src0 > T - 4 ? T - 4 : src0);
+    const bool clamped = src0 != tt + dsel;
+    int mask = valid ? 0x100 : 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (hit[e]) mask |= 1 << e;
+      if (hit[e] && (clamped || d[e] != dsel)) mask |= 16 << e;
+    }
+    t0s[q] = tt;
+    masks[q] = mask;
+    src0s[q] = src0;
+  }
+  float4_a own[UT][CG];
+  float4_u par[UT][CG];
+  auto issue_loads = [&](int c0) {
+#pragma unroll
+    for (int q = 0; q < UT; ++q)
+#pragma unroll
+      for (int cc = 0; cc < CG; ++cc) {
+        const size_t row = (size_t)(c0 + cc) * T;
+        own[q][cc] = *reinterpret_cast<const float4_a*>(x + own_base + row + t0s[q]);
+        float4_u pz = {0.f, 0.f, 0.f, 0.f};
+        if (masks[q] & 0xf) pz = *reinterpret_cast<const float4_u*>(x + par_base + row + src0s[q]);
+        par[q][cc] = pz;
+      }
+  };
+  issue_loads(0);
+  // coefficient records of all channels of this sample: coef = op * knots[b, :, c]
+  for (int i = threadIdx.x; i < n_knots; i += kThreads) thr[i] = (int)ceil(spline_op[i]);
+  for (int i = threadIdx.x; i < C * rec_per_ch; i += kThreads) {
+    const int c = i / rec_per_ch, r = i % rec_per_ch;
+    const int piece = r / kRec, j4 = r % kRec;
+    double acc = 0.0;
+    if (j4 < 4) {
+      const double* mrow = spline_op + n_knots + (size_t)(piece * 4 + j4) * n_knots;
+      for (int j = 0; j < n_knots; ++j)
+        acc = __dadd_rn(acc, __dmul_rn(mrow[j], knots[((size_t)b * n_knots + j) * C + c]));
+    } else if (j4 == 4) {
+      acc = spline_op[piece];
+    }
+    lds[i] = acc;
+  }
+  __syncthreads();
+  // per position: piece, s, s^2, s^3 (scipy's running power, each product rounded)
+  int pc[UT][4];
+  double s1[UT][4], s2[UT][4], s3[UT][4];
+#pragma unroll
+  for (int q = 0; q < UT; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int t = t0s[q] + e;
+      const int p = spline_piece(thr, n_knots, t);
+      const double brk = lds[p * kRec + 4];
+      const double s = __dsub_rn((double)t, brk);
+      const double z = __dmul_rn(s, s);
+      pc[q][e] = p;
+      s1[q][e] = s;
+      s2[q][e] = z;
+      s3[q][e] = __dmul_rn(z, s);
+    }
+  for (int c0 = 0; c0 < C; c0 += CG) {
+    if (c0) issue_loads(c0);
+#pragma unroll
+    for (int q = 0; q < UT; ++q) {
+      const int mask = masks[q];
+      if (!(mask & 0x100)) continue;
+      const int t0 = t0s[q];
+#pragma unroll
+      for (int cc = 0; cc < CG; ++cc) {
+        const int c = c0 + cc;
+        const float o[4] = {own[q][cc].x, own[q][cc].y, own[q][cc].z, own[q][cc].w};
+        const float pv[4] = {par[q][cc].x, par[q][cc].y, par[q][cc].z, par[q][cc].w};
+        const double* rec = lds + (size_t)c * rec_per_ch;
+        float bl[4], out[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = pv[e];
+          if (mask & (16 << e)) {  // rare: patch with the element's own shift
+            bool h;
+            const int de = blend_shift(sm, t0 + e, h);
+            v = x[par_base + (size_t)c * T + t0 + e + de];
+          }
+          bl[e] = (mask & (1 << e)) ? blend(o[e], v, lam, oml) : o[e];
+        }
+        if (pc[q][0] == pc[q][3]) {  // the usual case: pieces are hundreds of samples long
+          const double* r = rec + pc[q][0] * kRec;
+          const double k0 = r[0], k1 = r[1], k2 = r[2], k3 = r[3];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            double w = __dadd_rn(k3, __dmul_rn(k2, s1[q][e]));
+            w = __dadd_rn(w, __dmul_rn(k1, s2[q][e]));
+            w = __dadd_rn(w, __dmul_rn(k0, s3[q][e]));
+            out[e] = __double2float_rn(__dmul_rn((double)bl[e], w));
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const double* r = rec + pc[q][e] * kRec;
+            double w = __dadd_rn(r[3], __dmul_rn(r[2], s1[q][e]));
+            w = __dadd_rn(w, __dmul_rn(r[1], s2[q][e]));
+            w = __dadd_rn(w, __dmul_rn(r[0], s3[q][e]));
+            out[e] = __double2float_rn(__dmul_rn((double)bl[e], w));
+          }
+        }
+        float4_a v4;
+        v4.x = out[0]; v4.y = out[1]; v4.z = out[2]; v4.w = out[3];
+        *reinterpret_cast<float4_a*>(y + own_base + (size_t)c * T + t0) = v4;
+      }
+    }
+  }
+}
+
 // The same kernel with the whole index block — boundaries and partners of up to kPackB samples
 // as int16 — in its ARGUMENTS (3 KB of the 4 KB kernarg segment): block-uniform data that the
 // blocks read with scalar loads, and no host-to-device copy in front of the launch.  For the
@@ -499,6 +654,31 @@ int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, con
     else if (U == 2) PCGMIX_LAUNCH(4, W, 2);              \
     else PCGMIX_LAUNCH(4, W, 1);                          \
   } while (0)
+  static const bool tq_ok = getenv("PCGMIX_NO_WARP_TQ") == nullptr;     // tuning / A-B runs
+  if (vec4 && warp && !zero_rect && tq_ok && C <= 64) {
+    // one lane = one position quad for all channels (mix_warp_tq_kernel)
+    // two quads per lane only where the registers allow it (CG = 4, UT = 2 needs 256 VGPRs)
+    int UT = (C % 4 != 0 && T >= 4096 && (long long)B * plane >= (64LL << 20)) ? 2 : 1;
+    if (const char* env = getenv("PCGMIX_WARP_TQ_UT")) UT = atoi(env) == 2 ? 2 : 1;     // tuning runs
+    const size_t lds_tq = sizeof(double) * (size_t)C * (n_knots - 1) * kRec + sizeof(int) * (size_t)n_knots;
+    if (lds_tq <= 64 * 1024) {
+      dim3 grid_tq((unsigned)((T + kThreads * 4 * UT - 1) / (kThreads * 4 * UT)), gy, gz);
+#define PCGMIX_LAUNCH_TQ(CGV, UTV)                                                                  \
+  hipLaunchKernelGGL((mix_warp_tq_kernel<CGV, UTV>), grid_tq, block, lds_tq, s, x, y, frames,        \
+                     mix_idx, off, lam, oml, knots, spline_op, n_knots, B, C, T, pay_src, pay_dst,  \
+                     pay_n16, disp_part, pk)
+      int CG = C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 1);      // channels whose loads a lane keeps in flight
+      if (const char* env = getenv("PCGMIX_WARP_TQ_CG")) {  // tuning runs
+        const int v = atoi(env);
+        if ((v == 1 || v == 2 || v == 4) && C % v == 0) CG = v;
+      }
+      if (CG == 4) { if (UT == 2) PCGMIX_LAUNCH_TQ(4, 2); else PCGMIX_LAUNCH_TQ(4, 1); }
+      else if (CG == 2) { if (UT == 2) PCGMIX_LAUNCH_TQ(2, 2); else PCGMIX_LAUNCH_TQ(2, 1); }
+      else { if (UT == 2) PCGMIX_LAUNCH_TQ(1, 2); else PCGMIX_LAUNCH_TQ(1, 1); }
+#undef PCGMIX_LAUNCH_TQ
+      return (int)hipGetLastError();
+    }
+  }
   if (vec4) {
     if (warp) PCGMIX_LAUNCH_U(true); else PCGMIX_LAUNCH_U(false);
   } else {

@@ -57,7 +57,9 @@ class PotesStackFunction(torch.autograd.Function):
         stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         need_x = ctx.needs_input_grad[0]
         m2 = s1 = None
-        if PotesStackFunction.use_masks and N > 0 and any(ctx.needs_input_grad):
+        # rnd without any gradient (frozen conv stack, head-only fine-tuning in train mode): the
+        # mask-saving forward still runs, for the dropout bytes it fills on the side
+        if PotesStackFunction.use_masks and N > 0 and (any(ctx.needs_input_grad) or rnd is not None):
             m2 = torch.empty(lib.pcgmix_potes_mask_bytes(N, T, 2), dtype=torch.uint8, device=x.device)
             if need_x:
                 s1 = torch.empty(lib.pcgmix_potes_mask_bytes(N, T, 1), dtype=torch.uint8,
@@ -71,7 +73,7 @@ class PotesStackFunction(torch.autograd.Function):
                 "pcgmix_potes_stack_fwd_save_f32")
         elif rnd is not None:
             raise RuntimeError("PotesStackFunction: dropout bytes are filled by the mask-saving "
-                               "forward (needs use_masks and a gradient)")
+                               "forward (needs use_masks)")
         else:
             _lib.check(lib.pcgmix_potes_stack_fwd_f32(x.data_ptr(), w1c.data_ptr(), b1c.data_ptr(),
                                                       w2c.data_ptr(), b2c.data_ptr(), h2.data_ptr(),
@@ -342,6 +344,14 @@ class PotesHeadLossFunction(torch.autograd.Function):
         ws, loss = ctx.deferred
         if gloss is None:                       # nothing upstream of the loss
             return (None,) * 11
+        # dW1 is accumulated (two row halves, atomicAdd) into the buffer the FORWARD zeroed and is
+        # returned as the gradient: a second backward over the same graph would add onto the first
+        # result — which may already be p.grad — without an error.  Refuse it.
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("PotesHeadLossFunction: backward ran twice over one forward "
+                               "(retain_graph / a second autograd.grad): its dW1 buffer is zeroed by "
+                               "the forward and consumed by the first backward; run the forward again")
+        ctx.consumed = True
         thr1, bits1, s1 = ctx.drop
         B, K = x.shape
         C = ctx.C
