@@ -368,21 +368,26 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
     masks[q] = mask;
     src0s[q] = src0;
   }
-  float4_a own[UT][CG];
-  float4_u par[UT][CG];
-  auto issue_loads = [&](int c0) {
+  // Two register sets: the loads of channel group g+1 are issued before group g is evaluated, so a
+  // wave keeps requests in flight through its ~200-instruction float64 section (without this the
+  // kernel alternates between waiting for memory and computing: measured 750 us against 708 us
+  // with smaller groups at the saturating batch, 511 us for the plain splice).
+  float4_a own[UT][CG], own_n[UT][CG];
+  float4_u par[UT][CG], par_n[UT][CG];
+  auto issue_loads = [&](int c0, float4_a (&o)[UT][CG], float4_u (&p)[UT][CG]) {
 #pragma unroll
     for (int q = 0; q < UT; ++q)
 #pragma unroll
       for (int cc = 0; cc < CG; ++cc) {
         const size_t row = (size_t)(c0 + cc) * T;
-        own[q][cc] = *reinterpret_cast<const float4_a*>(x + own_base + row + t0s[q]);
+        o[q][cc] = *reinterpret_cast<const float4_a*>(x + own_base + row + t0s[q]);
         float4_u pz = {0.f, 0.f, 0.f, 0.f};
         if (masks[q] & 0xf) pz = *reinterpret_cast<const float4_u*>(x + par_base + row + src0s[q]);
-        par[q][cc] = pz;
+        p[q][cc] = pz;
       }
   };
-  issue_loads(0);
+  issue_loads(0, own, par);
+  if (CG < C) issue_loads(CG, own_n, par_n);
   // coefficient records of all channels of this sample: coef = op * knots[b, :, c]
   for (int i = threadIdx.x; i < n_knots; i += kThreads) thr[i] = (int)ceil(spline_op[i]);
   for (int i = threadIdx.x; i < C * rec_per_ch; i += kThreads) {
@@ -417,7 +422,16 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
       s3[q][e] = __dmul_rn(z, s);
     }
   for (int c0 = 0; c0 < C; c0 += CG) {
-    if (c0) issue_loads(c0);
+    if (c0) {                        // rotate: the prefetched group becomes current, fetch the next
+#pragma unroll
+      for (int q = 0; q < UT; ++q)
+#pragma unroll
+        for (int cc = 0; cc < CG; ++cc) {
+          own[q][cc] = own_n[q][cc];
+          par[q][cc] = par_n[q][cc];
+        }
+      if (c0 + CG < C) issue_loads(c0 + CG, own_n, par_n);
+    }
 #pragma unroll
     for (int q = 0; q < UT; ++q) {
       const int mask = masks[q];
@@ -667,7 +681,9 @@ int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, con
   hipLaunchKernelGGL((mix_warp_tq_kernel<CGV, UTV>), grid_tq, block, lds_tq, s, x, y, frames,        \
                      mix_idx, off, lam, oml, knots, spline_op, n_knots, B, C, T, pay_src, pay_dst,  \
                      pay_n16, disp_part, pk)
-      int CG = C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 1);      // channels whose loads a lane keeps in flight
+      // channels per register set (two sets are in flight): 2 measured best at C = 4 — 12.3 us
+      // against 15.5 us for 4 at (256,4,5000), 708 against 751 us at the saturating batch
+      int CG = C % 2 == 0 ? 2 : 1;
       if (const char* env = getenv("PCGMIX_WARP_TQ_CG")) {  // tuning runs
         const int v = atoi(env);
         if ((v == 1 || v == 2 || v == 4) && C % v == 0) CG = v;

@@ -371,6 +371,28 @@ def shard_batch(batch, rank: int, world: int):
     return tuple(b[sl] for b in batch)
 
 
+class _SeedView:
+    __slots__ = ("count",)
+
+    def __init__(self, count: int):
+        self.count = count
+
+
+def augmentation_counter(args, step_counter):
+    """What ``augment()`` is given as its step counter.  The reference derives every random choice
+    of a step from ``step_counter.count`` (train_model.py:507, augmentations.py:869-903), so under
+    data parallelism every rank draws the same lambda, the same warp knots and the same
+    permutation pattern.  ``args.rank_seed = True`` — NOT the reference's behaviour,
+    off by default — gives rank r of w the seed ``count * w + r`` instead: distinct
+    streams per rank that never collide across steps.  One process: unchanged."""
+    if not getattr(args, "rank_seed", False):
+        return step_counter
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return step_counter
+    return _SeedView(int(step_counter.count) * dist.get_world_size() + dist.get_rank())
+
+
 def reseed_device_rng(args, device) -> None:
     """train_model.py:565: the reference calls ``torch.cuda.manual_seed_all(args.seed_fix)`` before
     every ``optimizer.step()``.  Its visible effect on a GPU is on the NEXT forward pass: the
@@ -380,6 +402,10 @@ def reseed_device_rng(args, device) -> None:
     (:217); loops that do not set it keep torch's running stream."""
     seed = getattr(args, "seed_fix", None)
     if seed is not None and device.type == "cuda":
+        if getattr(args, "rank_seed", False):           # non-reference: per-rank dropout masks
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                seed = int(seed) + dist.get_rank()
         torch.cuda.manual_seed(int(seed))
 
 
@@ -408,8 +434,8 @@ def train_step(args, model, batch, device, optimizer, scheduler, criterion, epoc
     data = data.to(device, non_blocking=True)
     target_ohe = F.one_hot(target, args.num_classes).to(device, non_blocking=True)
     aug = augmentations2d if args.dataset in SPECTROGRAM_DATASETS else augmentations
-    data, target_ohe, _, _ = aug.augment(args, data, target_ohe, frames, wav, step_counter,
-                                         model, device, None,
+    data, target_ohe, _, _ = aug.augment(args, data, target_ohe, frames, wav,
+                                         augmentation_counter(args, step_counter), model, device, None,
                                          host_labels=target.numpy() if not target.is_cuda else None)
     fused = fused_loss_model(model, criterion, data, target_ohe, epoch) \
         if getattr(args, "depth", 0) == 0 else None
@@ -449,13 +475,15 @@ class GraphedTrainStep:
     captured once in a hipGraph (torch.cuda.CUDAGraph) and replayed: at bs=256 the eager Potes
     step issues ~40 launches and is host-bound (~1 ms wall for ~0.45 ms of GPU work).
 
-    Stays eager, around the replay: the augmentation (its index upload and the lambda kernel
-    argument change every step; it writes straight into the graph's static input), the optimiser
-    (OneCycleLR moves lr AND beta1 every step — host scalars that a captured Adam would freeze)
-    and the scheduler.  Under torch.distributed pass the UNWRAPPED model: gradients are packed
-    into one flat buffer inside the graph and averaged by one eager all-reduce after the replay
-    (``FlatGradSync``) — DDP's hooks cannot be captured.  Needs static shapes (the loaders use
-    drop_last=True)."""
+    Stays eager, around the replay: the augmentation (its index data and lambda are kernel
+    arguments that change every step; it writes straight into the graph's static input — plain
+    splices, and the saliency-guided ones around the frozen model's own captured pass) and the
+    scheduler.  The ClipAdam update is the graph's last node: OneCycleLR moves lr AND beta1 every
+    step, so the captured launch reads its eight scalars from device memory (they travel with the
+    step's payload).  Under torch.distributed pass the UNWRAPPED model: gradients are packed into
+    one flat buffer inside the graph, averaged by one eager all-reduce after the replay
+    (``FlatGradSync``) — DDP's hooks cannot be captured — and the update is a SECOND small graph
+    replayed behind the collective.  Needs static shapes (the loaders use drop_last=True)."""
 
     def __init__(self, args, model, optimizer, scheduler, criterion, device, batch_size, channels,
                  sig_len, sync: Optional[FlatGradSync] = None):
@@ -513,8 +541,9 @@ class GraphedTrainStep:
         # The optimiser update is the graph's last node when nothing has to happen between
         # backward and update (no gradient all-reduce) and the optimiser can read its scalars
         # from ``aux`` (ClipAdam).
-        self.adam_in_graph = sync is None and isinstance(optimizer, ClipAdam) \
-            and optimizer.can_capture() and device.type == "cuda"
+        self.adam_in_graph = isinstance(optimizer, ClipAdam) and optimizer.can_capture() \
+            and device.type == "cuda"
+        self.graph_update = None        # with a sync: the update as a second graph behind the all-reduce
         # The warm-up passes run the network on the all-zero placeholder batch: they must leave no
         # trace.  Weights are not updated (no optimiser step); BatchNorm running statistics and
         # num_batches_tracked, and the device RNG stream the dropout masks come from, are put
@@ -523,15 +552,42 @@ class GraphedTrainStep:
         rng = torch.cuda.get_rng_state(device)
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):                   # warm-up off the capture (no weight update)
-            for _ in range(3):
-                self.opt.zero_grad(set_to_none=True)
-                self._fwd_bwd()
-            if sync is not None:
-                sync.attach()
-            if self.adam_in_graph:
-                self.opt.prepare_capture([p for p in self.params if p.grad is not None])
+        import warnings
+        warn_always = torch.is_warn_always_enabled()
+        torch.set_warn_always(True)                     # the stream-mismatch warning is a warn-once
+        try:
+            with warnings.catch_warnings(record=True) as caught, torch.cuda.stream(side):
+                warnings.simplefilter("always")         # warm-up off the capture (no weight update)
+                for _ in range(3):
+                    self.opt.zero_grad(set_to_none=True)
+                    self._fwd_bwd()
+                if sync is not None:
+                    sync.attach()
+                if self.adam_in_graph:
+                    self.opt.prepare_capture([p for p in self.params if p.grad is not None])
+        finally:
+            torch.set_warn_always(warn_always)
         torch.cuda.current_stream(device).wait_stream(side)
+        stale = [w for w in caught if "AccumulateGrad node's stream does not match" in str(w.message)]
+        for w in caught:
+            if w not in stale:
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        if stale:
+            # An autograd graph built in an earlier pass over these parameters is still alive (a loss
+            # or output tensor kept by the caller): its AccumulateGrad nodes belong to the stream of
+            # that pass.  Backward under capture would then make THAT stream wait on an event of the
+            # capturing stream; when it is the legacy default stream, hipStreamEndCapture walks a
+            # null stream object and the process dies with SIGSEGV inside libamdhip64
+            # (hip::Stream::EndCapture; reproduced with torch ops alone:
+            # profiles/probes/capture_defer_probe.py 'puretorch').  Refuse here,
+            # before any capture has begun.
+            self.opt.zero_grad(set_to_none=True)
+            raise RuntimeError(
+                "GraphedTrainStep: an autograd graph from an earlier forward pass over this model's "
+                "parameters is still alive (e.g. a non-detached loss/output tensor is still "
+                "referenced).  Its AccumulateGrad nodes are bound to that pass's stream and would pull "
+                "it into the capture (on ROCm: a crash in hipStreamEndCapture).  Drop those tensors "
+                "(or .detach() them) before building the captured step.")
         with torch.no_grad():
             for b, saved in buffers:
                 b.copy_(saved)
@@ -546,7 +602,17 @@ class GraphedTrainStep:
         # thread_local: HIP calls of other threads (RCCL's watchdog) must not abort the capture
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss, self.out = self._fwd_bwd()
-            if self.adam_in_graph:
+            if self.adam_in_graph and sync is None:
+                self.opt.capture_update(self.aux[4:12])
+        if self.adam_in_graph and sync is not None:
+            # N > 1: [forward + backward + pack] | one eager all-reduce | [clip + Adam].  The update
+            # reads the averaged gradients through views of the flat buffer and its eight scalars
+            # from ``aux`` — an N-rank step issues exactly the launches of the one-rank step plus
+            # the collective, and no Python optimiser code runs between them.
+            for p, v in zip(sync.params, sync.views):
+                p.grad = v
+            self.graph_update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_update, capture_error_mode="thread_local"):
                 self.opt.capture_update(self.aux[4:12])
 
     def _fwd_bwd(self):
@@ -579,7 +645,7 @@ class GraphedTrainStep:
         data = data.to(self.device, non_blocking=True)
         frames_np = augmentations._as_numpy_frames(frames)
         B, C, T = data.shape
-        step = int(step_counter.count)
+        step = int(augmentation_counter(args, step_counter).count)
         # host image of the static block: one-hot float targets, dropout key, Adam scalars
         labels_np = target.numpy() if not target.is_cuda else target.cpu().numpy()
         if self.labels_mode:
@@ -635,7 +701,10 @@ class GraphedTrainStep:
             self.t.copy_(augmentations.blend_targets(t_ohe, plan))
         self.graph.replay()
         reseed_device_rng(self.args, self.device)
-        if not self.adam_in_graph:
+        if self.graph_update is not None:
+            self.sync.reduce_and_bind()
+            self.graph_update.replay()
+        elif not self.adam_in_graph:
             if self.sync is not None:
                 self.sync.reduce_and_bind()
                 if self.args.grad_clip and not isinstance(self.opt, ClipAdam):

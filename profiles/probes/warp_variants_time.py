@@ -23,7 +23,7 @@ for m, b, c, t in (("durmixmagwarp(0.2,4)", 256, 4, 5000), ("durmixmagwarp(0.2,4
     ms = bench.kernel_back_to_back_ms(m, b, c, t, 2000, dev, iters=50 if b > 1000 else 200)
     print(f"  {m:22s} ({b},{c},{t}) {ms * 1e3:9.2f} us", flush=True)
 '''
-for tag, env in (("old", {"PCGMIX_NO_WARP_TQ": "1"}), ("tq", {}), ("tq cg2", {"PCGMIX_WARP_TQ_CG": "2"}),
+for tag, env in (("old", {"PCGMIX_NO_WARP_TQ": "1"}), ("tq cg4", {"PCGMIX_WARP_TQ_CG": "4"}), ("tq cg2", {"PCGMIX_WARP_TQ_CG": "2"}),
                  ("tq cg1", {"PCGMIX_WARP_TQ_CG": "1"}), ("tq cg2 ut2", {"PCGMIX_WARP_TQ_CG": "2", "PCGMIX_WARP_TQ_UT": "2"})):
     print(f"--- {tag} {env}", flush=True)
     r = subprocess.run([sys.executable, "-c", CODE, ROOT], env=dict(os.environ, **env), capture_output=True,

@@ -60,6 +60,13 @@ RESNET1D_B, RESNET2D_B = 8, 4
 # first steps of a 40-step schedule (lr from max_lr/25 upwards) rather than a whole 3- or 5-step
 # cycle, whose very first update already runs at max_lr and sends the ResNet9 loss to ~500.
 SCHED_STEPS = 40
+# ResNet9 on 8 (4) noise items is a chaotic system at the reference's lr_max = 0.01: Adam's first
+# update moves each of the 2.3 M (6.6 M) weights by +-lr and the loss from 0.9 to 12-25, so last-bit
+# differences between two correct fp32 convolution implementations (oneDNN on the CPU, MIOpen on
+# the GPU) grow to 4e-3 of the loss within three steps — measured, round 3.  The goldens therefore
+# run the reference's code at lr_max = 1e-4 (first lr 4e-6): same code path (batch statistics,
+# running-stat updates, backward, clip, Adam, OneCycleLR), a trajectory that can be held to 1e-4.
+RESNET_LR_MAX = 1e-4
 
 
 def salopt_traj_args(experiments_dir):
@@ -84,7 +91,7 @@ def salopt_traj_batches():
 def resnet1d_args():
     a = traj_args()
     a.__dict__.update(model="resnet9", method="durmixmagwarp(0.2,4)", batch_size=RESNET1D_B,
-                      num_steps=SCHED_STEPS)
+                      num_steps=SCHED_STEPS, lr_max=RESNET_LR_MAX)
     return a
 
 
@@ -100,7 +107,7 @@ def resnet1d_batches():
 def resnet2d_args():
     a = traj_args()
     a.__dict__.update(model="resnet9", dataset="PhysioNet(spec128)", method="durratiomixup",
-                      batch_size=RESNET2D_B, num_steps=SCHED_STEPS, num_channels=1)
+                      batch_size=RESNET2D_B, num_steps=SCHED_STEPS, num_channels=1, lr_max=RESNET_LR_MAX)
     return a
 
 

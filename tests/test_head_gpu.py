@@ -315,3 +315,78 @@ def test_head_loss_takes_hard_targets_as_uint8_labels(device):
     with pytest.raises(ValueError):
         models.PotesHeadLossFunction.apply(feat, w1, b1, w2, b2, labels[:-1].to(torch.uint8), 0.0, 0.0,
                                            True, None)
+
+
+def test_head_loss_finalize_deferred_under_capture(device):
+    """The deferred head+loss captured DIRECTLY with torch.cuda.graph (what CNN_potes.loss_and_logits
+    does while a training step is being captured) and replayed: loss, logits and every gradient
+    bit-identical to the eager two-launch form.
+
+    Round 2's version of this test died with SIGSEGV in CUDAGraph.capture_end.  Cause (round 3,
+    profiles/probes/capture_defer_probe.py + profiles/r3_capture_defer_probe_run*.txt): it kept the
+    eager pass's ``loss0`` — and with it that pass's autograd graph, whose AccumulateGrad nodes
+    belong to the legacy default stream — alive while the same leaves went through backward under
+    capture.  The autograd engine then makes the default stream wait on an event recorded in the
+    capturing stream, HIP registers the NULL stream as a parallel capture stream, and
+    hip::Stream::EndCapture dereferences it (fault address 0x308).  Not `defer`, not the capture
+    mode, not a missing warm-up: a torch-ops-only program crashes the same way.  So: keep only
+    detached copies of the eager results and let the eager graph die before capturing."""
+    from pcgmix_amd import models
+    torch.manual_seed(8)
+    B, K, C = 100, 19968, 2                                  # 25 row blocks: uneven segments
+    w1 = (torch.randn(20, K, device=device) * 0.01).requires_grad_(True)
+    b1 = torch.randn(20, device=device).requires_grad_(True)
+    w2 = torch.randn(C, 20, device=device).requires_grad_(True)
+    b2 = torch.randn(C, device=device).requires_grad_(True)
+    feat = torch.randn(B, K, device=device).requires_grad_(True)
+    t = F.one_hot(torch.randint(0, C, (B,), device=device), C).float()
+    gs = torch.tensor(0.5, device=device)
+    params = (feat, w1, b1, w2, b2)
+
+    def forward(defer):
+        return models.PotesHeadLossFunction.apply(feat, w1, b1, w2, b2, t, 0.0, 0.0, True, None, defer)
+
+    def eager_reference():
+        loss, logits = forward(False)
+        grads = torch.autograd.grad(loss, params, gs)
+        return loss.detach().clone(), logits.detach().clone(), [g.detach().clone() for g in grads]
+
+    loss0, logits0, grads0 = eager_reference()               # the eager graph is gone on return
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):                            # warm-up of the deferred form
+        l, _ = forward(True)
+        torch.autograd.grad(l, params, gs)
+        del l
+    torch.cuda.current_stream(device).wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        loss1, logits1 = forward(True)
+        loss1.detach().fill_(-1.0)                           # the forward has not written it ...
+        grads1 = torch.autograd.grad(loss1, params, gs)
+    loss1.detach().fill_(-2.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(loss1.detach(), loss0)                # ... the backward's feature pass does
+    assert torch.equal(logits1, logits0)
+    for a, b in zip(grads1, grads0):
+        assert torch.equal(a, b)
+
+
+def test_head_loss_backward_twice_is_refused(device):
+    """dW1 accumulates into a buffer the forward zeroed: a second backward over the same forward
+    would silently double it.  It raises instead."""
+    from pcgmix_amd import models
+    torch.manual_seed(2)
+    B, K, C = 8, 400, 2
+    w1 = torch.randn(20, K, device=device, requires_grad=True)
+    w2 = torch.randn(C, 20, device=device, requires_grad=True)
+    feat = torch.randn(B, K, device=device, requires_grad=True)
+    t = F.one_hot(torch.randint(0, C, (B,), device=device), C).float()
+    loss, _ = models.PotesHeadLossFunction.apply(feat, w1, None, w2, None, t, 0.0, 0.0, True, None)
+    g1 = torch.autograd.grad(loss, (w1,), retain_graph=True)[0].clone()
+    with pytest.raises(RuntimeError, match="backward ran twice"):
+        torch.autograd.grad(loss, (w1,))
+    loss2, _ = models.PotesHeadLossFunction.apply(feat, w1, None, w2, None, t, 0.0, 0.0, True, None)
+    assert torch.equal(torch.autograd.grad(loss2, (w1,))[0], g1)

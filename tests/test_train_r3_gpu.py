@@ -200,7 +200,7 @@ def test_salopt_train_step_on_reference_saliency_is_strict(mode, device, tmp_pat
 def _digest_check(tag, name, got, want, atol, frac_loose=0.0, loose=0.0):
     d = np.abs(TC.tensor_digest(got)[2:] - want[2:])
     n_bad = int((d > atol).sum())
-    assert n_bad <= frac_loose * d.size and (d.max() <= loose if n_bad else True), \
+    assert n_bad <= max(1.0 if frac_loose else 0.0, frac_loose * d.size) and (d.max() <= loose if n_bad else True), \
         (tag, name, float(d.max()), n_bad, d.size)
     return float(d.max())
 
@@ -212,11 +212,15 @@ def test_resnet9_train_mode_reproduces_reference(tag, device):
     3 steps of its own ``train_epoch`` (tests/golden/make_golden_train_r3.py), replayed through
     ``train_step`` on the HIP path: NHWC MIOpen convolutions and the hand-written BatchNorm /
     ReLU / pool kernels (``pcgmix_bnrp.hip``: batch statistics, running-stat updates, backward),
-    ClipAdam.  Losses 1e-4 relative, BN buffers 1e-4, parameters 1e-3 on the recorded digest.
+    ClipAdam.  Losses 1e-4 relative, BN buffers 1e-4, parameters on the recorded digest.
 
-    Adam's first updates are sign-like (m/sqrt(v) = +-1), so an element whose gradient is at
-    rounding-noise level can legitimately move the other way (|delta| <= 2 lr per step): up to
-    0.5 % of a tensor's sampled elements may exceed 1e-3 and none 4e-3 (lr <= 1.2e-3 here)."""
+    The goldens run at lr_max = 1e-4 (train_cases.RESNET_LR_MAX: at the reference's 0.01 three
+    steps of this network amplify last-bit convolution differences to 4e-3 of the loss), so the
+    three updates move every weight by sum(lr) = 2.2e-5 in all — the parameter tolerance is set
+    against THAT, not against the weights: 99.5 % of a tensor's sampled elements within 2e-6.
+    Adam's first updates are sign-like (m/sqrt(v) = +-1): an element whose gradient is at
+    rounding-noise level may legitimately move the other way (2 lr per step), hence the 0.5 %
+    that may differ by up to 5e-5."""
     g = np.load(os.path.join(GOLDEN, "train_resnet_ref.npz"))
     if tag == "r1d":
         args, batches = TC.resnet1d_args(), TC.resnet1d_batches()
@@ -255,7 +259,7 @@ def test_resnet9_train_mode_reproduces_reference(tag, device):
             assert d <= 1e-4, (name, d)
         elif k.startswith(f"{tag}_par."):
             name = k[len(tag) + 5:]
-            worst_p = max(worst_p, _digest_check(tag, name, state[name], g[k], 1e-3, 0.005, 4e-3))
+            worst_p = max(worst_p, _digest_check(tag, name, state[name], g[k], 2e-6, 0.005, 5e-5))
     print(f"[{tag}] loss rel err {rel.max():.2e}, buffers {worst_b:.2e}, params {worst_p:.2e}")
 
 
@@ -305,3 +309,28 @@ def test_cfg4_chain_logmel_splice_train_step(device):
         assert float((d > 1e-4).double().mean()) <= 0.005 and float(d.max()) <= 1e-3, (k, float(d.max()))
     for (k, v), (_, w) in zip(net.named_buffers(), ref.named_buffers()):
         assert torch.allclose(v.cpu().double(), w.double(), rtol=1e-4, atol=1e-5), k
+
+
+def test_graphed_step_refuses_a_stale_autograd_graph(device):
+    """An autograd graph of an earlier eager pass that is still referenced keeps AccumulateGrad
+    nodes bound to the legacy default stream; backward under capture would pull that stream into
+    the capture and hipStreamEndCapture crashes the process.  GraphedTrainStep sees
+    the stream mismatch in its warm-up — outside any capture — and raises instead; once the
+    stale graph is dropped it builds and steps."""
+    B, C, T = 16, 4, 2500
+    args = TC.traj_args()
+    args.batch_size = B
+    net = _potes(args, device)
+    opt, sched = tm.make_optimizer(args, net)
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=1000, seed=3)
+    crit = tm.SELCLoss(labels, 2, es=args.num_epochs + 1, device=device)
+    data = torch.from_numpy(x).to(device)
+    stale = net(data, depth=0, pass_part="second").square().sum()       # eager, default stream
+    stale.backward()
+    opt.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError, match="autograd graph from an earlier"):
+        tm.GraphedTrainStep(args, net, opt, sched, crit, device, B, C, T)
+    del stale
+    g = tm.GraphedTrainStep(args, net, opt, sched, crit, device, B, C, T)
+    batch = (data, torch.from_numpy(labels), torch.from_numpy(frames), wav, None, torch.arange(B))
+    assert np.isfinite(float(g.step(batch, 1, tm.step_counter_class())))
