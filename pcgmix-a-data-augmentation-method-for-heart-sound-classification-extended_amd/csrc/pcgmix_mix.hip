@@ -368,38 +368,41 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
     masks[q] = mask;
     src0s[q] = src0;
   }
-  // Two register sets: the loads of channel group g+1 are issued before group g is evaluated, so a
-  // wave keeps requests in flight through its ~200-instruction float64 section (without this the
-  // kernel alternates between waiting for memory and computing: measured 750 us against 708 us
-  // with smaller groups at the saturating batch, 511 us for the plain splice).
-  float4_a own[UT][CG], own_n[UT][CG];
-  float4_u par[UT][CG], par_n[UT][CG];
-  auto issue_loads = [&](int c0, float4_a (&o)[UT][CG], float4_u (&p)[UT][CG]) {
+  float4_a own[UT][CG];
+  float4_u par[UT][CG];
+  auto issue_loads = [&](int c0) {
 #pragma unroll
     for (int q = 0; q < UT; ++q)
 #pragma unroll
       for (int cc = 0; cc < CG; ++cc) {
         const size_t row = (size_t)(c0 + cc) * T;
-        o[q][cc] = *reinterpret_cast<const float4_a*>(x + own_base + row + t0s[q]);
+        own[q][cc] = *reinterpret_cast<const float4_a*>(x + own_base + row + t0s[q]);
         float4_u pz = {0.f, 0.f, 0.f, 0.f};
         if (masks[q] & 0xf) pz = *reinterpret_cast<const float4_u*>(x + par_base + row + src0s[q]);
-        p[q][cc] = pz;
+        par[q][cc] = pz;
       }
   };
-  issue_loads(0, own, par);
-  if (CG < C) issue_loads(CG, own_n, par_n);
-  // coefficient records of all channels of this sample: coef = op * knots[b, :, c]
-  for (int i = threadIdx.x; i < n_knots; i += kThreads) thr[i] = (int)ceil(spline_op[i]);
+  issue_loads(0);
+  // coefficient records of all channels of this sample: coef = op * knots[b, :, c].  The operator
+  // and the sample's knots are staged in LDS first — ONE round trip to memory; the dot products
+  // with their operands in global memory were n_knots dependent round trips on every block's
+  // critical path (each iteration: two loads, s_waitcnt vmcnt(0), one multiply-add).
+  const int n_op = n_knots + 4 * (n_knots - 1) * n_knots;
+  double* opl = reinterpret_cast<double*>(thr + ((n_knots + 1) & ~1));
+  double* knl = opl + n_op;
+  for (int i = threadIdx.x; i < n_op + n_knots * C; i += kThreads)
+    opl[i] = i < n_op ? spline_op[i] : knots[(size_t)b * n_knots * C + (i - n_op)];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_knots; i += kThreads) thr[i] = (int)ceil(opl[i]);
   for (int i = threadIdx.x; i < C * rec_per_ch; i += kThreads) {
     const int c = i / rec_per_ch, r = i % rec_per_ch;
     const int piece = r / kRec, j4 = r % kRec;
     double acc = 0.0;
     if (j4 < 4) {
-      const double* mrow = spline_op + n_knots + (size_t)(piece * 4 + j4) * n_knots;
-      for (int j = 0; j < n_knots; ++j)
-        acc = __dadd_rn(acc, __dmul_rn(mrow[j], knots[((size_t)b * n_knots + j) * C + c]));
+      const double* mrow = opl + n_knots + (size_t)(piece * 4 + j4) * n_knots;
+      for (int j = 0; j < n_knots; ++j) acc = __dadd_rn(acc, __dmul_rn(mrow[j], knl[j * C + c]));
     } else if (j4 == 4) {
-      acc = spline_op[piece];
+      acc = opl[piece];
     }
     lds[i] = acc;
   }
@@ -422,16 +425,7 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
       s3[q][e] = __dmul_rn(z, s);
     }
   for (int c0 = 0; c0 < C; c0 += CG) {
-    if (c0) {                        // rotate: the prefetched group becomes current, fetch the next
-#pragma unroll
-      for (int q = 0; q < UT; ++q)
-#pragma unroll
-        for (int cc = 0; cc < CG; ++cc) {
-          own[q][cc] = own_n[q][cc];
-          par[q][cc] = par_n[q][cc];
-        }
-      if (c0 + CG < C) issue_loads(c0 + CG, own_n, par_n);
-    }
+    if (c0) issue_loads(c0);
 #pragma unroll
     for (int q = 0; q < UT; ++q) {
       const int mask = masks[q];
@@ -674,7 +668,10 @@ int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, con
     // two quads per lane only where the registers allow it (CG = 4, UT = 2 needs 256 VGPRs)
     int UT = (C % 4 != 0 && T >= 4096 && (long long)B * plane >= (64LL << 20)) ? 2 : 1;
     if (const char* env = getenv("PCGMIX_WARP_TQ_UT")) UT = atoi(env) == 2 ? 2 : 1;     // tuning runs
-    const size_t lds_tq = sizeof(double) * (size_t)C * (n_knots - 1) * kRec + sizeof(int) * (size_t)n_knots;
+    // records | thresholds (padded to 8 bytes) | staged operator | staged knots of the sample
+    const size_t lds_tq = sizeof(double) * ((size_t)C * (n_knots - 1) * kRec + (size_t)n_knots +
+                                            4 * (size_t)(n_knots - 1) * n_knots + (size_t)n_knots * C) +
+                          sizeof(int) * (size_t)((n_knots + 1) & ~1);
     if (lds_tq <= 64 * 1024) {
       dim3 grid_tq((unsigned)((T + kThreads * 4 * UT - 1) / (kThreads * 4 * UT)), gy, gz);
 #define PCGMIX_LAUNCH_TQ(CGV, UTV)                                                                  \

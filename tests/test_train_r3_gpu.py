@@ -259,6 +259,15 @@ def test_resnet9_train_mode_reproduces_reference(tag, device):
             assert d <= 1e-4, (name, d)
         elif k.startswith(f"{tag}_par."):
             name = k[len(tag) + 5:]
+            if name.endswith(".0.bias"):
+                # A convolution bias in front of a BatchNorm has an exactly zero gradient (the
+                # normalisation cancels it); this build folds it into the BatchNorm and gives it that
+                # zero, the reference's autograd returns rounding noise of the size of
+                # the weight-decay term 1e-4 * b, which Adam's normalisation turns into steps of
+                # +-lr.  The bias has no effect on the network function; it may differ by the
+                # whole distance three steps can cover, 2 * sum(lr) = 4.4e-5.
+                _digest_check(tag, name, state[name], g[k], 4.6e-5)
+                continue
             worst_p = max(worst_p, _digest_check(tag, name, state[name], g[k], 2e-6, 0.005, 5e-5))
     print(f"[{tag}] loss rel err {rel.max():.2e}, buffers {worst_b:.2e}, params {worst_p:.2e}")
 
