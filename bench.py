@@ -176,10 +176,10 @@ def mix_warp_kernel_name(B, C, T, warp):
     """Name of the instantiation pcgmix_mix_warp_f32 launches (index block in device memory)."""
     import ctypes
     from pcgmix_amd import _lib
-    vec, unroll = ctypes.c_int(), ctypes.c_int()
-    _lib.check(_lib.load().pcgmix_mix_variant(B, C, T, int(bool(warp)), 1, ctypes.byref(vec),
-                                              ctypes.byref(unroll)), "pcgmix_mix_variant")
-    return f"pcgmix::mix_warp_kernel<{vec.value}, {'true' if warp else 'false'}, {unroll.value}>"
+    buf = ctypes.create_string_buffer(96)
+    _lib.check(_lib.load().pcgmix_mix_kernel_name(B, C, T, int(bool(warp)), 1, buf, 96),
+               "pcgmix_mix_kernel_name")
+    return buf.value.decode()
 
 
 def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200, per_launch=False, info=None):
@@ -436,6 +436,18 @@ def secondary_kernel_times(device, B=256, iters=50):
     fr = torch.from_numpy(frames.astype(np.int32)).to(device)
     x1 = data[:, 0, :].contiguous()
     out["logmel_256x5000"] = entry(timeit(lambda: frontend.logmel(x1, frames)), B * (4 * T + 4 * 128 * 128))
+    # The log-mel kernel is bound by its float64 STFT GEMM, not by memory: folded real transform,
+    # two products (re, im) of M = 72 bins (padded), K = n_fft/2 = 68, N = 160 frames per item
+    #  -> 2 * 2*72*68*160 = 3.13 MFLOP per cycle on v_mfma_f64_16x16x4_f64.
+    lm_flop = B * 2 * (2.0 * 72 * 68 * 160)
+    lm = out["logmel_256x5000"]
+    lm["roofline"] = {"bound": "mfma_f64", "achieved": lm_flop / lm["us"] / 1e6, "unit": "TFLOP/s",
+                      "peak": 78.6, "frac": lm_flop / lm["us"] / 1e6 / 78.6,
+                      "measured_issue_rate_peak": 32.0,
+                      "frac_of_measured_rate": lm_flop / lm["us"] / 1e6 / 32.0,
+                      "flop_per_launch": lm_flop,
+                      "note": "peak = data-sheet FP64 matrix rate; the instruction's measured issue rate on "
+                              "this part is 32 TFLOP/s (profiles/probes/mfma_f64_rate.hip)"}
     grad = torch.randn_like(data)
     out["saliency_post_256x4x5000"] = entry(timeit(lambda: saliency.saliency_post(grad, fr.data_ptr())),
                                             B * (4 * C * T + 4 * T))
@@ -476,6 +488,26 @@ def cfg3_salopt(device, steps=100, warmup=10, B=256, C=4, T=5000, reps=3):
     return {"method": method, "shape": [B, C, T], "samples_per_s": B * steps / dt,
             "ms_per_step": 1e3 * dt / steps, "ms_per_step_repeats": [1e3 * d / steps for d in dts],
             "steps": steps, "saliency_model": "CNN_potes (frozen copy)"}
+
+
+def cfg3_train(device, steps, warmup, barrier, rank, B=256, C=4, T=5000):
+    """BASELINE.json configs[2] as a TRAINING step: (saloptenv)durmixmagwarp(0.2,4) + the 1D-CNN,
+    captured (GraphedTrainStep: seed/boundaries/payload kernel -> the frozen saliency model's
+    captured pass -> search + splice into the graph's static input -> replay) and eager.  The
+    saliency model is a frozen random-init CNN_potes (reference: the 'base' run's model.pth)."""
+    from pcgmix_amd import models, saliency
+    method = "(saloptenv)durmixmagwarp(0.2,4)"
+    torch.manual_seed(5)
+    saliency.set_saliency_model(models.CNN_potes_TS(4, 2, "PhysioNet", sig_len=T).to(device))
+    try:
+        tr = train_steps_per_s(method, "Potes", B, C, T, 2000, device, steps, warmup, barrier, rank,
+                               tag="train_cfg3")
+        eager = train_steps_per_s(method, "Potes", B, C, T, 2000, device, min(steps, 200), warmup,
+                                  barrier, rank, use_graph=False, tag="train_cfg3_eager")
+        tr["eager_steps_per_s"] = eager["steps_per_s"]
+    finally:
+        saliency.set_saliency_model(None)
+    return tr
 
 
 def cfg4_spectrogram(device, steps=12, warmup=4, B=256, T=5000):
@@ -840,6 +872,8 @@ def main():
             leg("secondary_kernels", lambda: secondary_kernel_times(device))
             leg("cfg3_salopt", lambda: cfg3_salopt(device))
             if not a.no_train:
+                leg("cfg3_train", lambda: cfg3_train(device, max(20, a.steps), max(5, a.warmup), barrier,
+                                                     rank))
                 leg("cfg4_spectrogram", lambda: cfg4_spectrogram(device))
                 leg("train_resnet9_1d_magwarp", lambda: train_steps_per_s(
                     "durmixmagwarp(0.2,4)", "resnet9", 256, 4, 5000, rate, device, 20, 5, barrier,

@@ -611,6 +611,9 @@ long long pcgmix_ctx_phase_times(pcgmix_ctx* ctx, double* out8);
  * vec = 4 (16-byte lanes; needs T % 4 == 0 and 16-byte aligned x, y) or 1, unroll = quads per
  * lane (1, 2, 4).  For reporting: the kernel's name is mix_warp_kernel<vec, warp, unroll>. */
 int pcgmix_mix_variant(int B, int C, int T, int warp, int aligned16, int* vec, int* unroll);
+/* Name of the kernel instantiation pcgmix_mix_warp_f32 launches for this problem, as rocprofv3
+ * lists it (e.g. "pcgmix::mix_warp_tq_kernel<2, 1>"), written NUL-terminated into buf. */
+int pcgmix_mix_kernel_name(int B, int C, int T, int warp, int aligned16, char* buf, int buf_len);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm (training mode) + ReLU + MaxPool of a ResNet9 block, channels innermost.  [device]

@@ -14,6 +14,7 @@
 // fp64 and stores 16 bytes.  HBM-bound: 12 algorithmic bytes per element.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -555,6 +556,29 @@ extern "C" int pcgmix_mix_variant(int B, int C, int T, int warp, int aligned16, 
   return hipSuccess;
 }
 
+// Name of the kernel instantiation pcgmix_mix_warp_f32 launches for this problem (what rocprofv3
+// lists), so that a benchmark can match its own timing with the profiler's rows.
+extern "C" int pcgmix_mix_kernel_name(int B, int C, int T, int warp, int aligned16, char* buf,
+                                      int buf_len) {
+  if (B < 0 || C <= 0 || T <= 0 || !buf || buf_len <= 0) return hipErrorInvalidValue;
+  const bool vec4 = (T % 4 == 0) && aligned16;
+  const long long plane = (long long)C * T;
+  if (vec4 && warp && getenv("PCGMIX_NO_WARP_TQ") == nullptr && C <= 64) {
+    int UT = (C % 4 != 0 && T >= 4096 && (long long)B * plane >= (64LL << 20)) ? 2 : 1;
+    if (const char* env = getenv("PCGMIX_WARP_TQ_UT")) UT = atoi(env) == 2 ? 2 : 1;
+    int CG = (C % 2 == 0 && (long long)B * plane < (64LL << 20)) ? 2 : 1;
+    if (const char* env = getenv("PCGMIX_WARP_TQ_CG")) {
+      const int v = atoi(env);
+      if ((v == 1 || v == 2 || v == 4) && C % v == 0) CG = v;
+    }
+    snprintf(buf, (size_t)buf_len, "pcgmix::mix_warp_tq_kernel<%d, %d>", CG, UT);
+    return hipSuccess;
+  }
+  snprintf(buf, (size_t)buf_len, "pcgmix::mix_warp_kernel<%d, %s, %d>", vec4 ? 4 : 1,
+           warp ? "true" : "false", vec4 ? pcgmix::choose_unroll(B, plane, warp != 0) : 1);
+  return hipSuccess;
+}
+
 extern "C" int pcgmix_mix_warp_f32(const float* x, float* y, const int32_t* frames,
                                    const int32_t* mix_idx, const int32_t* off, float lam,
                                    const double* knots, const double* spline_op, int n_knots,
@@ -678,9 +702,10 @@ int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, con
   hipLaunchKernelGGL((mix_warp_tq_kernel<CGV, UTV>), grid_tq, block, lds_tq, s, x, y, frames,        \
                      mix_idx, off, lam, oml, knots, spline_op, n_knots, B, C, T, pay_src, pay_dst,  \
                      pay_n16, disp_part, pk)
-      // channels per register set (two sets are in flight): 2 measured best at C = 4 — 12.3 us
-      // against 15.5 us for 4 at (256,4,5000), 708 against 751 us at the saturating batch
-      int CG = C % 2 == 0 ? 2 : 1;
+      // channels whose loads a lane keeps in flight.  Measured at C = 4 (MI355X, back to back):
+      // (256,4,5000) 14.2 / 11.9 / 12.1 us for 4 / 2 / 1, saturating 16384x4x5000 672 / 596 / 573 us
+      // (fewer registers, more waves: 144 / 94 / 76 VGPRs)
+      int CG = (C % 2 == 0 && (long long)B * plane < (64LL << 20)) ? 2 : 1;
       if (const char* env = getenv("PCGMIX_WARP_TQ_CG")) {  // tuning runs
         const int v = atoi(env);
         if ((v == 1 || v == 2 || v == 4) && C % v == 0) CG = v;
