@@ -32,7 +32,7 @@ hipError_t launch_skinny_partial(const float* h, const float* W, float* partial,
 // disp_part != nullptr: the per-state offsets are not read from `off` but reduced by every block
 // from the displacement search's per-block results (kDispSplit float2 {value, displacement bits}
 // per (sample, state); pcgmix_saliency.hip) — the search's own finalize launch is then not needed.
-constexpr int kDispSplit = 16;
+constexpr int kDispSplit = 4;
 int launch_mix_warp(const float* x, float* y, const int32_t* frames, const int32_t* mix_idx,
                     const int32_t* off, float lam, const double* knots, const double* spline_op,
                     int n_knots, const int32_t* zero_rect, int B, int C, int T, hipStream_t s,

@@ -174,7 +174,27 @@ __device__ __forceinline__ float pw_leaf(F elem, int start, int n) {
   float r[8];
   elem.get8(start, r);
   int i = 8;
-  for (; i < n - (n % 8); i += 8) {
+  const int nn = n - (n % 8);
+  // Four 8-element groups per round, every load of the round issued before its first add: the
+  // adds of one accumulator stay in numpy's order (r[j] += a[i+j], then a[i+8+j], ...), but a lane
+  // now waits for LDS once per 32 elements instead of once per 8 — the launch is as long as its
+  // longest lane's chain of such waits.
+  for (; i + 24 < nn; i += 32) {
+    float v0[8], v1[8], v2[8], v3[8];
+    elem.get8(start + i, v0);
+    elem.get8(start + i + 8, v1);
+    elem.get8(start + i + 16, v2);
+    elem.get8(start + i + 24, v3);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], v0[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], v1[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], v2[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], v3[j]);
+  }
+  for (; i < nn; i += 8) {
     float v[8];
     elem.get8(start + i, v);
 #pragma unroll
@@ -394,170 +414,6 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   }
 }
 
-// ---- the same search with the lanes of a wave spread over the LEAVES of numpy's split tree --------
-// salopt_disp_kernel gives every candidate displacement one lane, and that lane walks the whole
-// pairwise tree of its three sums alone: the launch lasts as long as the heaviest (sample, state)
-// pair's longest chain — ~175 dependent 8-element groups at LDS latency, 27 us for that pair alone
-// on an otherwise idle chip — while its total arithmetic is 8.5 us of VALU issue.
-// Here one sum belongs to 16 lanes.  numpy's tree over n <= kLeafMaxN elements has depth <= 4
-// (every split halves: n2 = n/2 - (n/2) % 8; brute-forced: the deepest leaf stays <= 128 elements
-// up to n = 1928), so a leaf is a 4-bit path, MSB first: each lane descends ITS path (four
-// integer steps, no stack, no enumeration of other leaves), sums its leaf exactly as numpy does
-// (pw_leaf: 8 strided accumulators, fixed combine, sequential tail) and the 16 leaf sums are
-// combined up the tree by four shuffle rounds — level k adds the right sibling to the left one
-// where that node was split (a + b is commutative in IEEE arithmetic, so which lane adds is
-// immaterial; the SHAPE of the tree is what numpy's result depends on, and it is kept).
-// A block takes a contiguous chunk of candidates and does all their middle sums, then all head
-// sums, then all tail sums (a wave's four 16-lane groups always work on the same kind of sum: no
-// divergence), parks the results in LDS and forms J(d) = (head + mid) + tail per candidate.
-// kDispSplit blocks per pair, each on its own CU: the heaviest pair's LDS traffic (every
-// candidate re-reads both segments: 8 MB) is spread over 16 LDS pipes instead of 4.
-constexpr int kLeafLog = 4;
-constexpr int kLeafLanes = 1 << kLeafLog;
-constexpr int kLeafMaxN = 1928;
-constexpr int kLeafMinChunk = 32;     // candidates per block at least: light pairs use few blocks
-constexpr int kLeafMaxChunk = 128;    // ceil((kLeafMaxN + 1) / kDispSplit) rounded up to 16
-
-__device__ __forceinline__ void leaf_of(int n, int path, int& start, int& len, int& depth) {
-  start = 0;
-  len = n;
-  depth = 0;
-#pragma unroll
-  for (int lvl = 0; lvl < kLeafLog; ++lvl) {
-    if (len > 128) {
-      const int n2 = pw_split(len);
-      if ((path >> (kLeafLog - 1 - lvl)) & 1) { start += n2; len -= n2; } else { len = n2; }
-      depth = lvl + 1;
-    }
-  }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kDispThreads) void salopt_disp_leaf_kernel(
-    const float* __restrict__ sal, const int32_t* __restrict__ frames,
-    const int32_t* __restrict__ mix_idx, float lam, float oml, float2* __restrict__ part, int B,
-    int T, int max_len, const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst,
-    int pay_n16, const PartnerPack pk) {
-  extern __shared__ __align__(16) float smem[];
-  if (pay_n16 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 3 && blockIdx.z == gridDim.z - 1)
-    for (int i = threadIdx.x; i < pay_n16; i += kDispThreads) pay_dst[i] = pay_src[i];
-  __shared__ float res[3 * kLeafMaxChunk];
-  __shared__ float best_v[kDispThreads / 64];
-  __shared__ int best_d[kDispThreads / 64];
-  const int z = blockIdx.z;
-  const int b = (int)((blockIdx.x + (unsigned)z * (gridDim.x / kDispSplit + 3)) % gridDim.x);
-  const int k = (0x2013 >> (4 * blockIdx.y)) & 3;   // blockIdx.y 0,1,2,3 -> state 3,1,0,2
-  float2* out = part + ((size_t)b * 4 + k) * kDispSplit + z;
-  int m = pk.n ? partner_get(pk, b) : mix_idx[b];
-  m = (m < 0 || m >= B) ? b : m;
-  int a1 = frames[b * 5 + k], e1 = frames[b * 5 + k + 1];
-  int a2 = frames[m * 5 + k], e2 = frames[m * 5 + k + 1];
-  a1 = a1 < 0 ? 0 : (a1 > T ? T : a1);
-  e1 = e1 < a1 ? a1 : (e1 > T ? T : e1);
-  a2 = a2 < 0 ? 0 : (a2 > T ? T : a2);
-  e2 = e2 < a2 ? a2 : (e2 > T ? T : e2);
-  e1 = e1 - a1 > max_len ? a1 + max_len : e1;
-  e2 = e2 - a2 > max_len ? a2 + max_len : e2;
-  const int n1 = e1 - a1, n2 = e2 - a2;
-  const bool own_longer = n1 > n2;
-  const int nL = own_longer ? n1 : n2, nS = own_longer ? n2 : n1;
-  const int gap = nL - nS, ncand = gap + 1;
-  // contiguous chunk of candidates per block, a multiple of 16
-  int chunk = (ncand + kDispSplit - 1) / kDispSplit;
-  chunk = chunk < kLeafMinChunk ? kLeafMinChunk : chunk;
-  chunk = (chunk + 15) & ~15;
-  const int d_lo = z * chunk;
-  if (n1 == n2 || d_lo >= ncand) {  // no search (:226-229) / no candidate for this block
-    if (threadIdx.x == 0) *out = float2{-INFINITY, __int_as_float(0x7fffffff)};
-    return;
-  }
-  const int cn = ncand - d_lo < chunk ? ncand - d_lo : chunk;   // candidates of this block
-  const float* gl = sal + (size_t)(own_longer ? b : m) * T + (own_longer ? a1 : a2);
-  const float* gs = sal + (size_t)(own_longer ? m : b) * T + (own_longer ? a2 : a1);
-  float* lng = smem;
-  float* sht = smem + nL;
-  {
-    constexpr int kMaxPer = 8;
-    for (int base = 0; base < nL + nS; base += kMaxPer * kDispThreads) {
-      float v[kMaxPer];
-#pragma unroll
-      for (int u = 0; u < kMaxPer; ++u) {
-        const int i = base + u * kDispThreads + threadIdx.x;
-        v[u] = i < nL ? gl[i] : (i < nL + nS ? gs[i - nL] : 0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < kMaxPer; ++u) {
-        const int i = base + u * kDispThreads + threadIdx.x;
-        if (i < nL + nS) smem[i] = v[u];
-      }
-    }
-  }
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int grp = lane >> kLeafLog, path = lane & (kLeafLanes - 1);
-  const int nsum = own_longer ? 3 : 1;              // kinds of sums: 0 middle, 1 head, 2 tail
-  const int units = chunk * nsum;                   // unit u = kind * chunk + candidate (chunk % 4 == 0)
-  for (int u0 = wave * 4; u0 < units; u0 += (kDispThreads / 64) * 4) {
-    const int kind = __builtin_amdgcn_readfirstlane(u0 / chunk);   // the same for the wave's 4 groups
-    const int ci = u0 - kind * chunk + grp;
-    const int d = d_lo + ci;
-    const bool valid = ci < cn;
-    int n = kind == 0 ? nS : (kind == 1 ? d : gap - d);
-    n = valid ? n : 0;
-    int start, len, depth;
-    leaf_of(n, path, start, len, depth);
-    const bool mine = (path & ((1 << (kLeafLog - depth)) - 1)) == 0 && len > 0;
-    float v = 0.f;
-    if (kind == 0) {
-      if (mine) v = pw_leaf(SeqMid<MODE>{lng + d, sht, lam, oml, own_longer}, start, len);
-    } else {
-      if (mine) v = pw_leaf(SeqPlain{kind == 1 ? lng : lng + d + nS}, start, len);
-    }
-#pragma unroll
-    for (int lvl = kLeafLog - 1; lvl >= 0; --lvl) {   // children at depth lvl+1 -> their parent
-      const float o = __shfl_down(v, 1 << (kLeafLog - 1 - lvl), kLeafLanes);
-      if (depth > lvl) v = __fadd_rn(v, o);
-    }
-    if (path == 0 && valid) res[kind * kLeafMaxChunk + ci] = v;
-  }
-  __syncthreads();
-
-  float bv = -INFINITY;
-  int bd = 0x7fffffff;
-  for (int ci = threadIdx.x; ci < cn; ci += kDispThreads) {
-    float cur = res[ci];
-    if (own_longer)   // np.sum(s1[:d]) + np.sum(mid) + np.sum(s1[d+n2:])   (:76-78, :111-113)
-      cur = __fadd_rn(__fadd_rn(res[kLeafMaxChunk + ci], cur), res[2 * kLeafMaxChunk + ci]);
-    if (cur > bv) {
-      bv = cur;
-      bd = d_lo + ci;
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(bv, o, 64);
-    const int od = __shfl_xor(bd, o, 64);
-    if (ov > bv || (ov == bv && od < bd)) {
-      bv = ov;
-      bd = od;
-    }
-  }
-  if (lane == 0) {
-    best_v[wave] = bv;
-    best_d[wave] = bd;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < kDispThreads / 64; ++i)
-      if (best_v[i] > bv || (best_v[i] == bv && best_d[i] < bd)) {
-        bv = best_v[i];
-        bd = best_d[i];
-      }
-    *out = float2{bv, __int_as_float(bd)};
-  }
-}
-
 __global__ void salopt_finalize_kernel(const float2* __restrict__ part, int32_t* __restrict__ disp,
                                        int n /* B * 4 */) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -684,30 +540,12 @@ int pcgmix::launch_salopt_search(const float* sal, const int32_t* frames, const 
   const float oml = 1.0f - lam;
   dim3 grid((unsigned)B, 4, kDispSplit), block(kDispThreads);
   float2* part = static_cast<float2*>(workspace);
-  // Heart states of up to kLeafMaxN samples (every PhysioNet cycle at 1-2 kHz): the leaf-parallel
-  // kernel; longer ones keep one lane per candidate.  PCGMIX_DISP_LANE_PER_CANDIDATE=1: A/B runs.
-  static const bool leaf_ok = getenv("PCGMIX_DISP_LANE_PER_CANDIDATE") == nullptr;
-  static unsigned long long lds_ok2 = 0, lds_ok3 = 0;
-  if (leaf_ok && max_len <= kLeafMaxN) {
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(salopt_disp_leaf_kernel<0>),
-                                       &lds_ok2, 150 * 1024))
-      return (int)e;
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(salopt_disp_leaf_kernel<1>),
-                                       &lds_ok3, 150 * 1024))
-      return (int)e;
-    if (mode == 0)
-      hipLaunchKernelGGL(salopt_disp_leaf_kernel<0>, grid, block, lds, s, sal, frames, mix_idx, lam,
-                         oml, part, B, T, max_len, pay_src, pay_dst, pay_n16, pk);
-    else
-      hipLaunchKernelGGL(salopt_disp_leaf_kernel<1>, grid, block, lds, s, sal, frames, mix_idx, lam,
-                         oml, part, B, T, max_len, pay_src, pay_dst, pay_n16, pk);
-  } else if (mode == 0) {
+  if (mode == 0)
     hipLaunchKernelGGL(salopt_disp_kernel<0>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
                        part, B, T, max_len, pay_src, pay_dst, pay_n16, pk);
-  } else {
+  else
     hipLaunchKernelGGL(salopt_disp_kernel<1>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
                        part, B, T, max_len, pay_src, pay_dst, pay_n16, pk);
-  }
   if (disp)
     hipLaunchKernelGGL(salopt_finalize_kernel, dim3((unsigned)((B * 4 + 255) / 256)), dim3(256), 0, s,
                        part, disp, B * 4);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Displacement search: one lane per candidate (salopt_disp_kernel) against the leaf-parallel
-kernel (salopt_disp_leaf_kernel), us per launch at BASELINE config 3's shape, plus the whole
-saliency-guided augment() step.  The library reads its switch once per process: child per variant.
+"""Displacement search (salopt_disp_kernel), us per launch at BASELINE config 3's shapes, plus the
+whole saliency-guided augment() step.  (Commit b1c49cb carried a second, leaf-parallel kernel
+behind PCGMIX_DISP_LANE_PER_CANDIDATE; this script compared the two:
+profiles/r3_disp_leaf_parallel_negative.txt.)
     python profiles/probes/disp_variants_time.py
 """
 import os
@@ -38,7 +39,7 @@ for B, C, T, rate in ((256, 4, 5000, 2000), (256, 4, 2500, 1000), (32, 4, 2500, 
 r = bench.cfg3_salopt(dev, steps=200, warmup=20, reps=3)
 print(f"  cfg3 augment() step: {r['ms_per_step'] * 1e3:.1f} us  {r['ms_per_step_repeats']}", flush=True)
 '''
-for tag, env in (("lane per candidate", {"PCGMIX_DISP_LANE_PER_CANDIDATE": "1"}), ("leaf-parallel", {})):
+for tag, env in (("lane per candidate", {}),):
     print(f"--- {tag} {env}", flush=True)
     r = subprocess.run([sys.executable, "-c", CODE, ROOT], env=dict(os.environ, **env), capture_output=True,
                        text=True, timeout=900)
