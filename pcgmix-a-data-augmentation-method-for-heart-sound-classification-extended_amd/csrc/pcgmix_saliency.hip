@@ -162,6 +162,7 @@ __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
 // 16-byte LDS vector whose address is only 4-byte aligned (a lane's window starts at an
 // arbitrary sample): gfx950 serves it with one ds_read_b128.
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f4al __attribute__((ext_vector_type(4), aligned(16)));
 
 // `elem.get(i)` yields element i, `elem.get8(i, v)` the eight elements i .. i+7.
 template <class F>
@@ -206,18 +207,30 @@ __device__ __forceinline__ float pw_leaf(F elem, int start, int n) {
   return res;
 }
 
+// AL: p is 16-byte aligned -> two ds_read_b128.  Otherwise (4-byte aligned window) the compiler
+// emits four ds_read2_b32 — an unaligned b128 is split by the hardware and slower still.  The
+// displacement search keeps the longer segment in four copies, copy c shifted by c samples, so
+// that a window starting at ANY sample d is read 16-byte aligned from copy d & 3 (see
+// salopt_disp_kernel); only segments too long for four copies in LDS take the unaligned form.
+template <bool AL>
 __device__ __forceinline__ void lds_get8(const float* p, float (&v)[8]) {
-  const f4u a = *reinterpret_cast<const f4u*>(p), b = *reinterpret_cast<const f4u*>(p + 4);
-  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  if (AL) {
+    const f4al a = *reinterpret_cast<const f4al*>(p), b = *reinterpret_cast<const f4al*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+    const f4u a = *reinterpret_cast<const f4u*>(p), b = *reinterpret_cast<const f4u*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
 }
 
 // Accessors of the three summed sequences.
+template <bool AL>
 struct SeqPlain {               // a[i]
   const float* a;
   __device__ __forceinline__ float get(int i) const { return a[i]; }
-  __device__ __forceinline__ void get8(int i, float (&v)[8]) const { lds_get8(a + i, v); }
+  __device__ __forceinline__ void get8(int i, float (&v)[8]) const { lds_get8<AL>(a + i, v); }
 };
-template <int MODE>
+template <int MODE, bool AL>
 struct SeqMid {                 // op(l[i], s[i]); own_longer decides which one is the OWN saliency
   const float* l;
   const float* s;
@@ -238,8 +251,8 @@ struct SeqMid {                 // op(l[i], s[i]); own_longer decides which one 
   __device__ __forceinline__ float get(int i) const { return op(l[i], s[i]); }
   __device__ __forceinline__ void get8(int i, float (&v)[8]) const {
     float a[8], b[8];
-    lds_get8(l + i, a);
-    lds_get8(s + i, b);
+    lds_get8<AL>(l + i, a);
+    lds_get8<true>(s + i, b);          // the shorter segment starts 16-byte aligned
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = op(a[j], b[j]);
   }
@@ -307,7 +320,12 @@ __device__ __forceinline__ float pw_sum(F elem, int n) {
 // LDS: lng[nL] (the longer state's saliency), sht[nS] (the shorter one's).
 // (kDispSplit = 4 blocks per pair: pcgmix_kernels.h — the splice kernel can read `part` itself.)
 
-template <int MODE>  // 0: envelope (max), 1: lambda-weighted sum
+__host__ __device__ inline int disp_copy_stride(int max_len) {   // floats; = 16 (mod 64), >= max_len
+  return ((max_len + 63) & ~63) + 16;
+}
+
+// COPIES: four shifted copies of the longer segment (aligned 16-byte LDS reads); false: one copy.
+template <int MODE, bool COPIES>  // MODE 0: envelope (max), 1: lambda-weighted sum
 __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
     const float* __restrict__ sal, const int32_t* __restrict__ frames,
     const int32_t* __restrict__ mix_idx, float lam, float oml, float2* __restrict__ part, int B,
@@ -353,8 +371,13 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   }
   const float* gl = sal + (size_t)(own_longer ? b : m) * T + (own_longer ? a1 : a2);
   const float* gs = sal + (size_t)(own_longer ? m : b) * T + (own_longer ? a2 : a1);
-  float* lng = smem;
-  float* sht = smem + nL;
+  // LDS: sht[nS] (16-byte aligned), then four copies of the longer segment, copy c holding
+  // lng[c ..] at its start: a window lng[d .. d+7] is copy (d & 3) at offset d - (d & 3), a
+  // multiple of 4 floats.  Copies are `cs` floats apart with cs = 16 (mod 64): the 16 lanes of a
+  // ds_read_b128 pass (4 consecutive offsets x 4 copies) then cover all 64 banks exactly once.
+  const int cs = COPIES ? disp_copy_stride(max_len) : 0;
+  float* sht = smem;
+  float* lng = smem + ((max_len + 3) & ~3);          // copy 0 == the segment itself
   {  // both segments staged with all of a lane's loads in flight together (a loop with runtime
      // bounds compiles to load, wait, store, next load: up to eight serialised L2 round trips)
     constexpr int kMaxPer = 8;                       // covers states up to 2048 samples per pass
@@ -368,7 +391,16 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
 #pragma unroll
       for (int u = 0; u < kMaxPer; ++u) {
         const int i = base + u * kDispThreads + threadIdx.x;
-        if (i < nL + nS) smem[i] = v[u];             // sht = smem + nL: one contiguous image
+        if (i < nL) {
+          lng[i] = v[u];
+          if (COPIES) {
+#pragma unroll
+            for (int c = 1; c < 4; ++c)
+              if (i >= c) lng[c * cs + i - c] = v[u];
+          }
+        } else if (i < nL + nS) {
+          sht[i - nL] = v[u];
+        }
       }
     }
   }
@@ -377,11 +409,14 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   float bv = -INFINITY;
   int bd = 0x7fffffff;
   for (int d = z * kDispThreads + threadIdx.x; d <= nL - nS; d += kDispSplit * kDispThreads) {
-    const SeqMid<MODE> mid{lng + d, sht, lam, oml, own_longer};
+    const SeqMid<MODE, COPIES> mid{COPIES ? lng + (d & 3) * cs + (d & ~3) : lng + d, sht, lam, oml,
+                                   own_longer};
     float cur = pw_sum(mid, nS);
     if (own_longer) {  // np.sum(s1[:d]) + np.sum(mid) + np.sum(s1[d+n2:])   (:76-78, :111-113)
-      const float head = pw_sum(SeqPlain{lng}, d);
-      const float tail = pw_sum(SeqPlain{lng + d + nS}, nL - nS - d);
+      const int t0 = d + nS;
+      const float head = pw_sum(SeqPlain<true>{lng}, d);
+      const float tail = pw_sum(SeqPlain<COPIES>{COPIES ? lng + (t0 & 3) * cs + (t0 & ~3) : lng + t0},
+                                nL - nS - d);
       cur = __fadd_rn(__fadd_rn(head, cur), tail);
     }
     if (cur > bv) {  // ascending d per lane: strict '>' keeps the first maximum
@@ -528,24 +563,27 @@ int pcgmix::launch_salopt_search(const float* sal, const int32_t* frames, const 
   if (reinterpret_cast<uintptr_t>(workspace) & 7) return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
   if (max_len <= 0 || max_len > T) max_len = T;
-  const size_t lds = sizeof(float) * (size_t)2 * (size_t)((max_len + 3) & ~3);
+  const size_t seg = (size_t)((max_len + 3) & ~3);
+  size_t lds = sizeof(float) * (seg + 4 * (size_t)disp_copy_stride(max_len));
+  const bool copies = lds <= 96 * 1024;              // longer segments: one copy, unaligned windows
+  if (!copies) lds = sizeof(float) * 2 * seg;
   if (lds > 150 * 1024) return hipErrorInvalidValue;
-  static unsigned long long lds_ok0 = 0, lds_ok1 = 0;
-  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(salopt_disp_kernel<0>), &lds_ok0,
-                                     150 * 1024))
-    return (int)e;
-  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(salopt_disp_kernel<1>), &lds_ok1,
-                                     150 * 1024))
-    return (int)e;
+  static unsigned long long lds_ok[4] = {0, 0, 0, 0};
+  const void* kerns[4] = {reinterpret_cast<const void*>(salopt_disp_kernel<0, false>),
+                          reinterpret_cast<const void*>(salopt_disp_kernel<0, true>),
+                          reinterpret_cast<const void*>(salopt_disp_kernel<1, false>),
+                          reinterpret_cast<const void*>(salopt_disp_kernel<1, true>)};
+  for (int i = 0; i < 4; ++i)
+    if (hipError_t e = allow_large_lds(kerns[i], &lds_ok[i], 150 * 1024)) return (int)e;
   const float oml = 1.0f - lam;
   dim3 grid((unsigned)B, 4, kDispSplit), block(kDispThreads);
   float2* part = static_cast<float2*>(workspace);
-  if (mode == 0)
-    hipLaunchKernelGGL(salopt_disp_kernel<0>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
-                       part, B, T, max_len, pay_src, pay_dst, pay_n16, pk);
-  else
-    hipLaunchKernelGGL(salopt_disp_kernel<1>, grid, block, lds, s, sal, frames, mix_idx, lam, oml,
-                       part, B, T, max_len, pay_src, pay_dst, pay_n16, pk);
+#define PCGMIX_DISP(M, CP)                                                                        \
+  hipLaunchKernelGGL((salopt_disp_kernel<M, CP>), grid, block, lds, s, sal, frames, mix_idx, lam, \
+                     oml, part, B, T, max_len, pay_src, pay_dst, pay_n16, pk)
+  if (mode == 0) { if (copies) PCGMIX_DISP(0, true); else PCGMIX_DISP(0, false); }
+  else { if (copies) PCGMIX_DISP(1, true); else PCGMIX_DISP(1, false); }
+#undef PCGMIX_DISP
   if (disp)
     hipLaunchKernelGGL(salopt_finalize_kernel, dim3((unsigned)((B * 4 + 255) / 256)), dim3(256), 0, s,
                        part, disp, B * 4);
