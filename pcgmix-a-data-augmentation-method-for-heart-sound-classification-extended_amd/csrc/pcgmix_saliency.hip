@@ -258,52 +258,59 @@ struct SeqMid {                 // op(l[i], s[i]); own_longer decides which one 
   }
 };
 
-// The split tree is walked without a memory stack: a node is (depth, path bits) and its range is
-// recomputed from the root (<= kPwDepth steps, negligible next to a 128-element leaf); the left
-// sums waiting for their right sibling live in a register array accessed by compare-select, so
-// nothing goes to scratch.  kPwDepth = 8 covers n <= 128 * 2^8 = 32768 (T is capped at 19000).
-constexpr int kPwDepth = 8;
+// The split tree is walked leaf by leaf, in order, without a memory stack.  A leaf is a PATH from
+// the root — DEPTH bits, MSB first, 0 = left child — and its range follows from the path by DEPTH
+// unrolled split steps (a node splits while it holds more than 128 elements, so subtrees end at
+// different depths; the unused low bits of a path are zero).  After a leaf's sum the walk climbs:
+// while the node is a right child its parked left sibling is added in front of it (acc[level],
+// statically indexed registers); the first time it is a left child it is parked and the walk
+// moves to the leftmost leaf of the right sibling — which is simply path + (1 << (DEPTH - depth)):
+// the carry runs through the right-child bits just consumed.  ~40 instructions per leaf at
+// DEPTH = 4; the first version recomputed every node's range from the root on the way down AND up
+// with compare-select register arrays, ~150 instructions per node visit, and those walks — not the
+// leaf sums — were most of a candidate's chain.
+// DEPTH = 4 covers n <= 1928 (brute-forced: the deepest leaf stays <= 128 elements), 8 covers
+// 128 * 2^8 = 32768 (T is capped at 19000); a node that is still larger at depth DEPTH is summed
+// as one leaf by pw_leaf, exactly as before.
+constexpr int kPwShallowN = 1928;
 
 __device__ __forceinline__ int pw_split(int n) {
   int n2 = n / 2;
   return n2 - (n2 % 8);
 }
 
-template <class F>
+template <int DEPTH, class F>
 __device__ __forceinline__ float pw_sum(F elem, int n) {
   if (n <= 128) return pw_leaf(elem, 0, n);
-  float left[kPwDepth];
+  float acc[DEPTH];
 #pragma unroll
-  for (int l = 0; l < kPwDepth; ++l) left[l] = 0.f;
-  int depth = 0;
-  unsigned path = 0;  // bit l: at depth l+1 we are in the RIGHT child
+  for (int l = 0; l < DEPTH; ++l) acc[l] = 0.f;
+  unsigned path = 0;
   for (;;) {
-    int start = 0, cn = n;  // range of node (depth, path)
-    for (int l = 0; l < depth; ++l) {
-      const int n2 = pw_split(cn);
-      if (path & (1u << l)) { start += n2; cn -= n2; } else { cn = n2; }
-    }
-    if (cn > 128 && depth < kPwDepth) {  // descend left
-      path &= ~(1u << depth);
-      ++depth;
-      continue;
-    }
-    float v = pw_leaf(elem, start, cn);
-    for (;;) {  // climb
-      if (depth == 0) return v;
-      const int lvl = depth - 1;
-      if (!(path & (1u << lvl))) {  // left child done: park it, go to the right sibling
+    int start = 0, len = n, depth = 0;
 #pragma unroll
-        for (int l = 0; l < kPwDepth; ++l) left[l] = (l == lvl) ? v : left[l];
-        path |= 1u << lvl;
-        break;
+    for (int lvl = 0; lvl < DEPTH; ++lvl) {
+      if (len > 128) {
+        const int n2 = pw_split(len);
+        if ((path >> (DEPTH - 1 - lvl)) & 1u) { start += n2; len -= n2; } else { len = n2; }
+        depth = lvl + 1;
       }
-      float lv = 0.f;  // right child done: combine with the parked left sum
-#pragma unroll
-      for (int l = 0; l < kPwDepth; ++l) lv = (l == lvl) ? left[l] : lv;
-      v = __fadd_rn(lv, v);
-      depth = lvl;
     }
+    float v = pw_leaf(elem, start, len);
+    bool parked = false;
+#pragma unroll
+    for (int l = DEPTH; l >= 1; --l) {
+      if (l <= depth && !parked) {
+        if ((path >> (DEPTH - l)) & 1u) {
+          v = __fadd_rn(acc[l - 1], v);       // right child: left sibling + this
+        } else {
+          acc[l - 1] = v;                     // left child: wait for the right sibling
+          parked = true;
+        }
+      }
+    }
+    if (!parked) return v;                    // climbed through the root
+    path += 1u << (DEPTH - depth);
   }
 }
 
@@ -325,7 +332,8 @@ __host__ __device__ inline int disp_copy_stride(int max_len) {   // floats; = 16
 }
 
 // COPIES: four shifted copies of the longer segment (aligned 16-byte LDS reads); false: one copy.
-template <int MODE, bool COPIES>  // MODE 0: envelope (max), 1: lambda-weighted sum
+// DEPTH: levels of numpy's split tree the walk provides for (4 when max_len <= kPwShallowN, else 8).
+template <int MODE, bool COPIES, int DEPTH>  // MODE 0: envelope (max), 1: lambda-weighted sum
 __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
     const float* __restrict__ sal, const int32_t* __restrict__ frames,
     const int32_t* __restrict__ mix_idx, float lam, float oml, float2* __restrict__ part, int B,
@@ -411,11 +419,11 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   for (int d = z * kDispThreads + threadIdx.x; d <= nL - nS; d += kDispSplit * kDispThreads) {
     const SeqMid<MODE, COPIES> mid{COPIES ? lng + (d & 3) * cs + (d & ~3) : lng + d, sht, lam, oml,
                                    own_longer};
-    float cur = pw_sum(mid, nS);
+    float cur = pw_sum<DEPTH>(mid, nS);
     if (own_longer) {  // np.sum(s1[:d]) + np.sum(mid) + np.sum(s1[d+n2:])   (:76-78, :111-113)
       const int t0 = d + nS;
-      const float head = pw_sum(SeqPlain<true>{lng}, d);
-      const float tail = pw_sum(SeqPlain<COPIES>{COPIES ? lng + (t0 & 3) * cs + (t0 & ~3) : lng + t0},
+      const float head = pw_sum<DEPTH>(SeqPlain<true>{lng}, d);
+      const float tail = pw_sum<DEPTH>(SeqPlain<COPIES>{COPIES ? lng + (t0 & 3) * cs + (t0 & ~3) : lng + t0},
                                 nL - nS - d);
       cur = __fadd_rn(__fadd_rn(head, cur), tail);
     }
@@ -568,21 +576,28 @@ int pcgmix::launch_salopt_search(const float* sal, const int32_t* frames, const 
   const bool copies = lds <= 96 * 1024;              // longer segments: one copy, unaligned windows
   if (!copies) lds = sizeof(float) * 2 * seg;
   if (lds > 150 * 1024) return hipErrorInvalidValue;
-  static unsigned long long lds_ok[4] = {0, 0, 0, 0};
-  const void* kerns[4] = {reinterpret_cast<const void*>(salopt_disp_kernel<0, false>),
-                          reinterpret_cast<const void*>(salopt_disp_kernel<0, true>),
-                          reinterpret_cast<const void*>(salopt_disp_kernel<1, false>),
-                          reinterpret_cast<const void*>(salopt_disp_kernel<1, true>)};
-  for (int i = 0; i < 4; ++i)
+  static unsigned long long lds_ok[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const void* kerns[8] = {reinterpret_cast<const void*>(salopt_disp_kernel<0, false, 4>),
+                          reinterpret_cast<const void*>(salopt_disp_kernel<0, true, 4>),
+                          reinterpret_cast<const void*>(salopt_disp_kernel<1, false, 4>),
+                          reinterpret_cast<const void*>(salopt_disp_kernel<1, true, 4>),
+                          reinterpret_cast<const void*>(salopt_disp_kernel<0, false, 8>),
+                          reinterpret_cast<const void*>(salopt_disp_kernel<0, true, 8>),
+                          reinterpret_cast<const void*>(salopt_disp_kernel<1, false, 8>),
+                          reinterpret_cast<const void*>(salopt_disp_kernel<1, true, 8>)};
+  for (int i = 0; i < 8; ++i)
     if (hipError_t e = allow_large_lds(kerns[i], &lds_ok[i], 150 * 1024)) return (int)e;
   const float oml = 1.0f - lam;
   dim3 grid((unsigned)B, 4, kDispSplit), block(kDispThreads);
   float2* part = static_cast<float2*>(workspace);
-#define PCGMIX_DISP(M, CP)                                                                        \
-  hipLaunchKernelGGL((salopt_disp_kernel<M, CP>), grid, block, lds, s, sal, frames, mix_idx, lam, \
+  const bool shallow = max_len <= kPwShallowN;
+#define PCGMIX_DISP(M, CP, DP)                                                                       \
+  hipLaunchKernelGGL((salopt_disp_kernel<M, CP, DP>), grid, block, lds, s, sal, frames, mix_idx, lam, \
                      oml, part, B, T, max_len, pay_src, pay_dst, pay_n16, pk)
-  if (mode == 0) { if (copies) PCGMIX_DISP(0, true); else PCGMIX_DISP(0, false); }
-  else { if (copies) PCGMIX_DISP(1, true); else PCGMIX_DISP(1, false); }
+#define PCGMIX_DISP_D(M, CP) do { if (shallow) PCGMIX_DISP(M, CP, 4); else PCGMIX_DISP(M, CP, 8); } while (0)
+  if (mode == 0) { if (copies) PCGMIX_DISP_D(0, true); else PCGMIX_DISP_D(0, false); }
+  else { if (copies) PCGMIX_DISP_D(1, true); else PCGMIX_DISP_D(1, false); }
+#undef PCGMIX_DISP_D
 #undef PCGMIX_DISP
   if (disp)
     hipLaunchKernelGGL(salopt_finalize_kernel, dim3((unsigned)((B * 4 + 255) / 256)), dim3(256), 0, s,
