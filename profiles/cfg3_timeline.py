@@ -11,7 +11,7 @@ import sys
 
 csv.field_size_limit(1 << 30)
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-mix = [i for i, r in enumerate(rows) if "mix_warp_kernel" in r["Kernel_Name"]]
+mix = [i for i, r in enumerate(rows) if "mix_warp_" in r["Kernel_Name"]]
 steps = [(a, b) for a, b in zip(mix, mix[1:])
          if any("salopt_disp" in r["Kernel_Name"] for r in rows[a + 1:b + 1])]
 walls = [int(rows[b]["End_Timestamp"]) - int(rows[a]["End_Timestamp"]) for a, b in steps]
@@ -20,7 +20,7 @@ steps, walls = [steps[i] for i in keep], [walls[i] for i in keep]
 med = statistics.median(walls)
 a, b = min(zip(steps, walls), key=lambda sw: abs(sw[1] - med))[0]
 t0 = int(rows[a]["End_Timestamp"])
-out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "r2_cfg3_step_timeline.txt")
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("PCGMIX_ROUND", "r3") + "_cfg3_step_timeline.txt")
 with open(out, "w") as f:
     f.write(f"# one saliency-guided step ((saloptenv)durmixmagwarp(0.2,4), Potes saliency model, bs 256) under "
             f"rocprofv3 --kernel-trace: {med / 1e3:.1f} us from splice end to splice end (median of {len(steps)} steps)\n")

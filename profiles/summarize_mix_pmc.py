@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Fold the rocprofv3 passes of profiles/run_mix_pmc.sh (gpurun_out/pmc/<mode>_<B>/{trace,fetch,write})
-into profiles/r2_mix_roofline.json: per workload the kernel's mean duration (kernel trace), raw
+into profiles/r<round>_mix_roofline.json (round = 3rd argument, default 3): per workload the kernel's mean duration (kernel trace), raw
 FETCH_SIZE / WRITE_SIZE per launch (KB as rocprofv3 reports them), the gfx950 correction the guide
 prescribes (FETCH_SIZE x 2 for wide coalesced reads, WRITE_SIZE as is), the exact bytes of the
 batch, and every fraction of the 8 TB/s roofline one can form from them.
 
-    python profiles/summarize_mix_pmc.py [gpurun_out/pmc] [git head]
+    python profiles/summarize_mix_pmc.py [gpurun_out/pmc] [git head] [round]
 """
 import csv
 import glob
@@ -17,6 +17,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 head = sys.argv[2] if len(sys.argv) > 2 else "?"
+ROUND = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+OUT = os.path.join(HERE, f"r{ROUND}_mix_roofline.json")
 csv.field_size_limit(1 << 30)
 PEAK = 8000.0
 
@@ -38,10 +40,10 @@ def summ(v):
 # Workloads collected earlier stay in the file (a later run may re-profile a subset only).
 prev = {}
 try:
-    prev = json.load(open(os.path.join(HERE, "r2_mix_roofline.json"))).get("workloads", {})
+    prev = json.load(open(OUT)).get("workloads", {})
 except (OSError, ValueError):
     pass
-result = {"round": 2, "collected_at": head, "peak_GBs": PEAK,
+result = {"round": ROUND, "collected_at": head, "peak_GBs": PEAK,
           "how": "profiles/run_mix_pmc.sh: per workload `rocprofv3 --kernel-trace --stats`, "
                  "`rocprofv3 --pmc FETCH_SIZE`, `rocprofv3 --pmc WRITE_SIZE` (separate passes) around "
                  "profiles/mix_pmc_probe.py (the splice kernel alone, 20 or 200 launches back to back)",
@@ -93,8 +95,8 @@ for info_path in sorted(glob.glob(os.path.join(src, "mixprobe_*.json"))):
           f"{w['frac_on_12CT_model']:.3f}")
 for k, v in prev.items():
     if k not in result["workloads"]:
-        v.setdefault("collected_at", "9a5355a")
+        v.setdefault("collected_at", "?")
         result["workloads"][k] = v
 for k, v in result["workloads"].items():
     v.setdefault("collected_at", head)
-json.dump(result, open(os.path.join(HERE, "r2_mix_roofline.json"), "w"), indent=1)
+json.dump(result, open(OUT, "w"), indent=1)

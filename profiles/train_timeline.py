@@ -28,7 +28,7 @@ med = statistics.median(walls)
 a, b = min(((a, b) for (a, b), w in zip(steps, walls)), key=lambda ab: abs(
     int(rows[ab[1]]["Start_Timestamp"]) - int(rows[ab[0]]["Start_Timestamp"]) - med))
 t0 = int(rows[a]["End_Timestamp"])
-out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "r2_train_step_timeline.txt")
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("PCGMIX_ROUND", "r3") + "_train_step_timeline.txt")
 with open(out, "w") as f:
     f.write(f"# one captured train step (Potes 1D-CNN, bs 256, durratiomixup) under rocprofv3 --kernel-trace: "
             f"{med / 1e3:.1f} us from optimiser launch to optimiser launch (median of {len(steps)} steps)\n")

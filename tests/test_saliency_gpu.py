@@ -80,7 +80,7 @@ def _check_against_reference_golden(g, sal_gpu, disp_gpu, y_gpu, mix):
 
     The frozen model's backward runs through the HIP kernels, so its input gradient differs from
     the CPU reference's in the last bits and the saliency maps by eps = max|sal_gpu - sal_ref|
-    (<= 1e-4 asserted by the caller).  The displacement is an arg-max of a float32 objective
+    (<= 1e-5 asserted below).  The displacement is an arg-max of a float32 objective
     J(d): it may differ from the recorded one ONLY at a near-tie.  For every state whose
     displacement differs this asserts, on the REFERENCE's saliency maps,
         0 <= J_ref(d_ref) - J_ref(d_gpu) <= 2 * (n1 + n2) * eps + float32 rounding slack
@@ -90,7 +90,7 @@ def _check_against_reference_golden(g, sal_gpu, disp_gpu, y_gpu, mix):
     method, frames = g["method"], g["frames"]
     assert np.array_equal(mix, g["mix"])
     eps = float(np.abs(sal_gpu - g["sal"]).max())
-    assert eps <= 1e-4
+    assert eps <= 1e-5          # measured <= 2e-6; the near-tie bound below scales with it
     ref = O.augment(method, g["x"], g["labels"], frames, g["wav"], g["step"], saliency_maps=sal_gpu)
     # (i) the GPU chain == the oracle fed the same saliency: indices bit-exact, waveform 1e-4
     assert np.array_equal(ref["mix"], mix)
@@ -106,8 +106,10 @@ def _check_against_reference_golden(g, sal_gpu, disp_gpu, y_gpu, mix):
         j_ref = float(O.displacement_objective(s1, s2, lam_np, int(g["disp"][i, k]), method))
         j_gpu = float(O.displacement_objective(s1, s2, lam_np, int(disp_gpu[i, k]), method))
         bound = 2.0 * (len(s1) + len(s2)) * eps + 1e-5 * max(1.0, abs(j_ref))
-        print(f"[salopt] sample {i} state {k}: d_gpu={disp_gpu[i, k]} d_ref={g['disp'][i, k]} "
-              f"J_ref(d_ref)-J_ref(d_gpu)={j_ref - j_gpu:.3e} bound={bound:.3e} eps={eps:.2e}")
+        import warnings
+        warnings.warn(f"[salopt] proven near-tie: sample {i} state {k}: d_gpu={disp_gpu[i, k]} "
+                      f"d_ref={g['disp'][i, k]} J_ref(d_ref)-J_ref(d_gpu)={j_ref - j_gpu:.3e} "
+                      f"bound={bound:.3e} eps={eps:.2e}")     # reaches the log under -q too
         assert -1e-5 * max(1.0, abs(j_ref)) <= j_ref - j_gpu <= bound, (i, k, j_ref, j_gpu, bound)
     same = np.ones(len(frames), dtype=bool)
     same[differing[:, 0]] = False

@@ -196,6 +196,39 @@ def test_ddp_two_ranks_equals_single_process(tmp_path, flat):
         assert torch.allclose(v, ddp_state[k], atol=2e-6), k
 
 
+def _seed_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = tm.step_counter_class()
+    seen = []
+    for _ in range(3):
+        a, b = make_args(), make_args()
+        b.rank_seed = True
+        seen.append((tm.augmentation_counter(a, sc).count, tm.augmentation_counter(b, sc).count))
+        sc.add()
+    assert tm.augmentation_counter(make_args(), sc) is sc          # default: the counter itself
+    torch.save(seen, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_seed_flag_two_ranks(tmp_path):
+    """Default (the reference's behaviour): every rank hands augment() the same step count.  With
+    ``args.rank_seed`` (non-reference) rank r of w gets count*w + r: distinct on
+    every rank and never colliding across steps.  One process: the flag changes nothing."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "seeds")
+    mp.spawn(_seed_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert [s[0] for s in r0] == [s[0] for s in r1] == [0, 1, 2]
+    assert [s[1] for s in r0] == [0, 2, 4] and [s[1] for s in r1] == [1, 3, 5]
+    sc = tm.step_counter_class()
+    a = make_args()
+    a.rank_seed = True
+    assert tm.augmentation_counter(a, sc) is sc                    # no process group
+
+
 def _driver_worker(rank, world, port, out_dir):
     import torch.distributed as dist
     from conftest import learnable_dataset
