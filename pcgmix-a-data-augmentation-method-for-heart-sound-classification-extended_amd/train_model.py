@@ -821,8 +821,10 @@ def train_model(args, dataset, device, use_graph: bool = True, log=print):
     base can load it (saliency.py:50).  Plots, the pickle of the performance dict and the model
     zoo are out of scope.  Returns the performance dict.
 
-    ``dataset`` is the dictionary ``dataloader_physionet.file2dict`` returns; it is selected by
-    ``physionet_dataloader`` and kept resident on ``device``.  The step runs as a captured
+    ``dataset`` is the dictionary ``dataloader_physionet.file2dict`` returns (time series:
+    ``args.dataset = 'PhysioNet'``; log-mel images, one per cycle: ``'PhysioNet(spec128)'``,
+    train_model.py:228-233 -> ``dataloader_physionet2d``); it is selected by ``physionet_dataloader``
+    and kept resident on ``device``.  The step runs as a captured
     hipGraph (``use_graph``); under torch.distributed each rank trains on its shard of every batch
     and gradients are averaged by one all-reduce per step (``FlatGradSync`` around the graph, DDP
     for the eager step)."""
@@ -833,8 +835,9 @@ def train_model(args, dataset, device, use_graph: bool = True, log=print):
     from . import dataloader_physionet as dlp
     from . import saliency as _sal
 
-    if args.dataset != "PhysioNet":
-        raise NotImplementedError("train_model drives the PhysioNet time-series path")
+    spectro = args.dataset == "PhysioNet(spec128)"
+    if args.dataset != "PhysioNet" and not spectro:
+        raise NotImplementedError("train_model drives the PhysioNet time-series and spectrogram paths")
     seed_fix = 4                                                   # :217
     args.seed_fix = seed_fix
     torch.manual_seed(seed_fix)
@@ -843,7 +846,11 @@ def train_model(args, dataset, device, use_graph: bool = True, log=print):
     args.device = device
     if not hasattr(args, "classical_space"):
         args.classical_space = False
-    loaders = dlp.physionet_dataloader(args, dataset)
+    if spectro:                                                    # :228-233
+        from . import dataloader_physionet2d as dlp2
+        loaders = dlp2.physionet_dataloader(args, dataset)
+    else:
+        loaders = dlp.physionet_dataloader(args, dataset)
     train_loader, train_labels = loaders.run("train", seed_fix)
     test_loader = loaders.run("valid" if args.valid else "test", None)
     args.sig_len = int(train_loader.data.shape[-1])
@@ -853,7 +860,8 @@ def train_model(args, dataset, device, use_graph: bool = True, log=print):
     rank, world = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
     args.num_steps = args.num_epochs * (len(train_loader.dataset) // args.batch_size)   # :390
     criterion = SELCLoss(train_labels, args.num_classes, es=selc_turning_point(args), device=device)
-    graphable = use_graph and device.type == "cuda" and args.num_epochs <= criterion.es
+    # (the spectrogram step is 80 ms of MIOpen convolutions: nothing for a graph to win, it stays eager)
+    graphable = use_graph and device.type == "cuda" and args.num_epochs <= criterion.es and not spectro
     if not graphable:
         model = wrap_distributed(model, device)
     optimizer, scheduler = make_optimizer(args, model)

@@ -93,3 +93,39 @@ def test_dataloader_run_interface():
     assert data.shape[1:] == (4, 48) and data.dtype == torch.float32 and frames.dtype == torch.int64
     test = dl.physionet_dataloader(a, ds).run("test", None)
     assert sum(len(b[1]) for b in test) == len(test.dataset)
+
+
+# ---- spectrogram datasets (dataloader_physionet2d.py) -------------------------------------------
+from make_golden_loader2d import CONFIGS2D, synthetic_dataset2d  # noqa: E402  (data generator only)
+
+
+@pytest.mark.parametrize("i", range(len(CONFIGS2D)))
+def test_selection2d_matches_reference(i):
+    from pcgmix_amd import dataloader_physionet2d as dl2
+    g = np.load(os.path.join(GOLDEN, "loader2d_selection.npz"))
+    cfg = CONFIGS2D[i]
+    d = dl2.physionet_dataset(dataset=synthetic_dataset2d(), dataset_name="PhysioNet(spec128)",
+                              seed_data=cfg["seed_data"], num_classes=2, n_fraction=cfg["n_fraction"],
+                              mode="train", seed=cfg["seed"], method="base", valid=cfg["valid"])
+    k = f"cfg{i}"
+    assert np.array_equal(d.train_wav, g[k + "_train_wav"])
+    assert np.array_equal(d.train_label, g[k + "_train_label"])
+    assert np.allclose(d.train_data.reshape(len(d.train_data), -1).sum(1), g[k + "_train_data_sum"])
+    if cfg["valid"]:
+        assert np.array_equal(d.test_wav, g[k + "_valid_wav"])
+        assert np.array_equal(d.test_label, g[k + "_valid_label"])
+
+
+def test_dataloader2d_run_interface():
+    from pcgmix_amd import dataloader_physionet2d as dl2
+    g = np.load(os.path.join(GOLDEN, "loader2d_selection.npz"))
+    ds = synthetic_dataset2d()
+    a = argparse.Namespace(dataset="PhysioNet(spec128)", seed_data=1100001, n_fraction=1.0, batch_size=8,
+                           num_classes=2, num_channels=1, seed=4, method="durratiomixup", valid=False)
+    loader, labels = dl2.physionet_dataloader(a, ds).run("train", 4)
+    assert len(labels) == len(loader.dataset) and len(loader) == len(labels) // 8
+    data, target, frames, wav, qual, idx = next(iter(loader))
+    assert data.shape == (8, 1, 6, 6) and data.dtype == torch.float32        # channel dim added (:104)
+    test = dl2.physionet_dataloader(a, ds).run("test", None)
+    assert [w for b in test for w in b[3]] == g["test_wav"].tolist()
+    assert list(next(iter(test))[0].shape[1:]) == g["test_item3_shape"].tolist()

@@ -344,3 +344,40 @@ def test_graphed_step_refuses_a_stale_autograd_graph(device):
     g = tm.GraphedTrainStep(args, net, opt, sched, crit, device, B, C, T)
     batch = (data, torch.from_numpy(labels), torch.from_numpy(frames), wav, None, torch.arange(B))
     assert np.isfinite(float(g.step(batch, 1, tm.step_counter_class())))
+
+
+def test_train_model_driver_on_spectrograms(device, tmp_path):
+    """BASELINE config 4 through the run driver: a dataset dictionary of log-mel images (computed
+    here by ``frontend.logmel`` from separable synthetic cycles, laid out as the reference's
+    spectrogram container: dataloader_physionet2d.py) -> ``train_model(args.dataset =
+    'PhysioNet(spec128)')`` -> 2D durratiomixup + ResNet9-2D -> evaluation -> model.pth."""
+    rs = np.random.RandomState(0)
+    ds = {}
+    for split, n_rec in (("train", 16), ("test", 8)):
+        d = {"data": [], "label": [], "frames": [], "wav": [], "sig_qual": []}
+        for r in range(n_rec):
+            wav, label = f"{'abcdef'[r % 6]}{r:04d}", (r // 2) % 2
+            fr = synthetic.make_frames(3, 2.0, rs)
+            x = rs.standard_normal((3, 5000)).astype(np.float32)
+            if label:       # a spectral tilt (the per-cycle dB reference cancels a plain gain)
+                x = np.cumsum(x, axis=1).astype(np.float32)
+                x -= x.mean(axis=1, keepdims=True)
+            for j in range(3):
+                x[j, fr[j, 4]:] = 0
+            spec, fspec = frontend.logmel(torch.from_numpy(x).to(device), fr)
+            for j in range(3):
+                d["data"].append(spec[j, 0].cpu().numpy())
+                d["label"].append(label); d["frames"].append(fspec[j]); d["wav"].append(wav)
+                d["sig_qual"].append(1)
+        ds[split] = d
+    args = argparse.Namespace(dataset="PhysioNet(spec128)", model="resnet9", method="durratiomixup+0.7",
+                              num_epochs=3, batch_size=16, op="adam", use_sched=True, lr_max=0.002,
+                              weight_decay=1e-4, grad_clip=0.1, seed=4, seed_data=1100001, n_fraction=1.0,
+                              train_balance=True, num_classes=2, sample_rate=2000, num_channels=1,
+                              valid=False, depth=0, EXPERIMENTS=str(tmp_path))
+    perf = tm.train_model(args, ds, device, log=None)
+    assert perf["steps"][-1] == args.num_steps == 3 * (48 // 16)
+    assert all(np.isfinite(v) for v in perf["train_loss"])
+    assert perf["train_loss"][-1] < perf["train_loss"][0]
+    import glob
+    assert len(glob.glob(str(tmp_path / "*" / "model.pth"))) == 1
