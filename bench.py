@@ -112,8 +112,13 @@ def run_augment_steps(method, data, tgt, frames, wav, device, steps, warmup, bar
     # Heap settling (tens of ms of host-only work) comes BEFORE the warm-up: nothing but the
     # barrier sits between the last warm-up call and t0, so a 20-step region is steady state.
     settle_heap()
+    out = None
     for _ in range(warmup):
-        augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "", **kw)
+        # bound to `out` exactly as in the timed loop: while the previous output is still alive the
+        # next call needs a SECOND 20 MB block from torch's caching allocator — with the result
+        # discarded here, that hipMalloc (~40 us) landed on the second timed call (round 3: calls
+        # of 40 / 63 / 25 / 24 us at the head of every region; profiles/r3_region_start_probe.txt)
+        out = augmentations.augment(args, data, tgt, frames, wav, sc, None, device, "", **kw)
         sc.add()
     barrier()
     torch.cuda.synchronize()

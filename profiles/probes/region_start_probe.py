@@ -39,6 +39,10 @@ def main():
     ap.add_argument("--idle-ms", type=float, default=0.0, help="host sleep before each region")
     ap.add_argument("--regions", type=int, default=8)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warm", type=int, default=50, help="warm-up calls before the first region")
+    ap.add_argument("--freeze", action="store_true", help="gc.collect() + gc.freeze() before the warm-up (bench.settle_heap)")
+    ap.add_argument("--gc", choices=["on", "off", "collect0"], default="on",
+                    help="inside the regions: collector on, disabled, or a gen-0 collection before each region")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     x, frames, labels, wav = synthetic.make_batch(256, 4, 5000, sample_rate=2000, seed=0)
@@ -48,9 +52,15 @@ def main():
     kw = {"host_labels": labels} if a.host_labels else {}
     args, sc = A(), SC()
     lib = _lib.load()
-    for _ in range(50):
+    import gc
+    if a.freeze:
+        gc.collect()
+        gc.freeze()
+    for _ in range(a.warm):
         augmentations.augment(args, data, tgt, fr, wav, sc, None, dev, "", **kw)
         sc.count += 1
+    if a.gc == "off":
+        gc.disable()
     torch.cuda.synchronize()
     ctx = augmentations.step_context(0)
     ph = (ctypes.c_double * 8)()
@@ -59,6 +69,8 @@ def main():
     for r in range(a.regions):
         if a.idle_ms:
             time.sleep(a.idle_ms * 1e-3)
+        if a.gc == "collect0":
+            gc.collect(0)
         torch.cuda.synchronize()
         lib.pcgmix_ctx_phase_times(ctx, ph)
         st = [time.perf_counter()]
@@ -73,7 +85,8 @@ def main():
         end = time.perf_counter()
         d = np.diff(st) * 1e6
         rows.append(list(d) + [(end - st[-1]) * 1e6, (end - st[0]) * 1e6 / a.steps])
-    print(f"host_labels={a.host_labels} idle_ms={a.idle_ms}: per-call host us (last two columns: drain, "
+    print(f"host_labels={a.host_labels} idle_ms={a.idle_ms} warm={a.warm} freeze={a.freeze} gc={a.gc} "
+          f"gc.get_count()={gc.get_count()}: per-call host us (last two columns: drain, "
           f"region mean per step)")
     for r in rows:
         print(" ".join(f"{v:6.1f}" for v in r))
