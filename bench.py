@@ -91,6 +91,32 @@ def settle_heap():
 
 STAMPS = [0.0] * 4096     # preallocated: per-call host clock reads of a traced region
 
+_SPIN = {}
+
+
+def settle_clocks(device, ms=40.0):
+    """Bring the GPU to its loaded power state before a leg's warm-up steps: ~40 ms of neutral
+    work (a float32 GEMM and a streaming pass over 256 MB, nothing of the package), then a
+    synchronize.  Why: a leg starts after tens of ms of host-only work (graph capture, heap
+    settling) with the GPU at idle clocks, and the clocks climb for the first milliseconds of
+    load — in a rocprofv3 trace of `--steps 20 --warmup 5` the same kernel of the train step
+    shortened monotonically from 78.3 to 74.9 us over the 25 steps of the leg, the step from 172
+    to 164.5 us (round 3, gpurun_out/prof_r3_bench).  A 4 ms region measured the ramp, not the
+    step.  This is not part of the W warm-up steps and not of the K timed ones; the JSON line
+    records it (`config.pre_settle`)."""
+    st = _SPIN.get(device)
+    if st is None:
+        st = _SPIN[device] = (torch.randn(4096, 4096, device=device), torch.empty(4096, 4096, device=device),
+                              torch.zeros(64 << 20, device=device))
+    a, c, big = st
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(4):
+            torch.mm(a, a, out=c)
+            big.add_(1.0)
+        torch.cuda.synchronize(device)
+
 
 def call_trace(t0, stamps, n, dt, steps):
     """Host-side return time of each call of a timed region (the calls are asynchronous: this is
@@ -112,6 +138,7 @@ def run_augment_steps(method, data, tgt, frames, wav, device, steps, warmup, bar
     # Heap settling (tens of ms of host-only work) comes BEFORE the warm-up: nothing but the
     # barrier sits between the last warm-up call and t0, so a 20-step region is steady state.
     settle_heap()
+    settle_clocks(device)
     out = None
     for _ in range(warmup):
         # bound to `out` exactly as in the timed loop: while the previous output is still alive the
@@ -328,6 +355,7 @@ def build_train_step(method, model_name, B, C, T, rate, device, total_steps, ran
 def run_train_steps(step, info, steps, warmup, barrier, tag):
     PROGRESS["leg"] = tag
     settle_heap()                                   # before the warm-up (see run_augment_steps)
+    settle_clocks(torch.device("cuda", torch.cuda.current_device()))
     for i in range(warmup):
         PROGRESS["step"] = i - warmup
         step()
@@ -730,7 +758,9 @@ def main():
         "config": {"workload": f"{a.method} augment() on synthetic 2.5 s @ 2 kHz PCG cycles, "
                                f"({B},{C},{T}) float32 per GPU (BASELINE.json configs[1])",
                    "batch_per_gpu": B, "channels": C, "sig_len": T, "method": a.method,
-                   "parallelism": f"dp{world}"},
+                   "parallelism": f"dp{world}",
+                   "pre_settle": "heap collected + frozen, then 40 ms of neutral GPU work (GEMM + streaming "
+                                 "add) before the W warm-up steps of every leg: see bench.settle_clocks"},
         "roofline": roof,
         "call_trace": headline_trace,
     }
