@@ -138,8 +138,7 @@ def run_augment_steps(method, data, tgt, frames, wav, device, steps, warmup, bar
     # Heap settling (tens of ms of host-only work) comes BEFORE the warm-up: nothing but the
     # barrier sits between the last warm-up call and t0, so a 20-step region is steady state.
     settle_heap()
-    settle_clocks(device)
-    out = None
+    out = None      # (no settle_clocks here: measured, it does not change this host-bound leg)
     for _ in range(warmup):
         # bound to `out` exactly as in the timed loop: while the previous output is still alive the
         # next call needs a SECOND 20 MB block from torch's caching allocator — with the result
@@ -759,8 +758,9 @@ def main():
                                f"({B},{C},{T}) float32 per GPU (BASELINE.json configs[1])",
                    "batch_per_gpu": B, "channels": C, "sig_len": T, "method": a.method,
                    "parallelism": f"dp{world}",
-                   "pre_settle": "heap collected + frozen, then 40 ms of neutral GPU work (GEMM + streaming "
-                                 "add) before the W warm-up steps of every leg: see bench.settle_clocks"},
+                   "pre_settle": "heap collected + frozen before the W warm-up steps of every leg; train legs: plus 40 ms "
+                                 "of neutral GPU work (GEMM + streaming add) to reach loaded clocks first, see "
+                                 "bench.settle_clocks"},
         "roofline": roof,
         "call_trace": headline_trace,
     }
