@@ -96,6 +96,43 @@ __device__ __forceinline__ void lds_load8(const float* p, float (&v)[8]) {  // p
 // s1g (forward kernel only, may be nullptr): global plane (8, own_hi bytes) of this row that
 // receives the same pool/ReLU selectors, four per byte (own_lo unused) — what the mask-based
 // backward kernels read instead of recomputing this layer.
+// c[m] = bias + sum_k w[k] * xw[m + k], m < 8, as float2 pairs (see potes_fwd_kernel): the ONE
+// place where the first layer's arithmetic order is written down — forward and every backward
+// recompute it through this function, so they agree on which ReLUs are alive and which element
+// wins each max-pool.
+__device__ __forceinline__ void conv1_window(const float (&xw)[12], const float (&w)[kK], float bias,
+                                             float (&c)[8]) {
+  f2 ce[4], co_[3];
+  float o0 = 0.f, o7 = 0.f;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) ce[m] = f2{bias, bias};
+#pragma unroll
+  for (int m = 0; m < 3; ++m) co_[m] = f2{0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < kK; k += 2) {
+    const f2 wk = {w[k], w[k]};
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      ce[m] = __builtin_elementwise_fma(wk, f2{xw[2 * m + k], xw[2 * m + k + 1]}, ce[m]);
+  }
+#pragma unroll
+  for (int k = 1; k < kK; k += 2) {
+    const f2 wk = {w[k], w[k]};
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+      co_[m] = __builtin_elementwise_fma(wk, f2{xw[2 * m + 1 + k], xw[2 * m + 2 + k]}, co_[m]);
+    o0 = fmaf(w[k], xw[k], o0);
+    o7 = fmaf(w[k], xw[7 + k], o7);
+  }
+  c[0] = ce[0].x + o0;
+  c[7] = ce[3].y + o7;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    c[2 * m + 1] = ce[m].y + co_[m].x;
+    c[2 * m + 2] = ce[m + 1].x + co_[m].y;
+  }
+}
+
 template <bool SWZ>
 __device__ __forceinline__ void layer1_t(const PotesWeights& W, const float* xs, float* a1s,
                                          uint8_t* sel, int qlo, int nq, int P1, int xplane,
@@ -119,37 +156,8 @@ __device__ __forceinline__ void layer1_t(const PotesWeights& W, const float* xs,
 #pragma unroll
     for (int k = 0; k < kK; ++k) w[k] = W.w1[ci * kK + k];
     const float bias = W.b1[ci];
-    // c[m] = bias + sum_k w[k] * xw[m + k], m < 8, as float2 pairs (see potes_fwd_kernel)
-    f2 ce[4], co_[3];
-    float o0 = 0.f, o7 = 0.f;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) ce[m] = f2{bias, bias};
-#pragma unroll
-    for (int m = 0; m < 3; ++m) co_[m] = f2{0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < kK; k += 2) {
-      const f2 wk = {w[k], w[k]};
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        ce[m] = __builtin_elementwise_fma(wk, f2{xw[2 * m + k], xw[2 * m + k + 1]}, ce[m]);
-    }
-#pragma unroll
-    for (int k = 1; k < kK; k += 2) {
-      const f2 wk = {w[k], w[k]};
-#pragma unroll
-      for (int m = 0; m < 3; ++m)
-        co_[m] = __builtin_elementwise_fma(wk, f2{xw[2 * m + 1 + k], xw[2 * m + 2 + k]}, co_[m]);
-      o0 = fmaf(w[k], xw[k], o0);
-      o7 = fmaf(w[k], xw[7 + k], o7);
-    }
     float c[8];
-    c[0] = ce[0].x + o0;
-    c[7] = ce[3].y + o7;
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      c[2 * m + 1] = ce[m].y + co_[m].x;
-      c[2 * m + 2] = ce[m + 1].x + co_[m].y;
-    }
+    conv1_window(xw, w, bias, c);
     f4 out;
     uint32_t sels = 0;
 #pragma unroll
@@ -632,6 +640,223 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
       const int co = f / (kC1 * kK), rest = f - co * (kC1 * kK);
       v = red[co * kNAcc + rest];
     } else {                              // gb2[co]
+      v = red[(e - kNW1 - kC1 - kNW2) * kNAcc + 40];
+    }
+    partial[(size_t)blockIdx.x * kNGrad + e] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------- backward, fused
+// potes_bwd_kernel<true> with the first-layer recompute moved onto the lane that consumes it
+// (VERDICT r2 item 6 / DESIGN §7.1).  In that kernel a work item of layer 1 is (channel, group of
+// 4 pooled positions) spread over the block in two rounds, its ReLU/pool selectors go to LDS
+// (sel1), a barrier, and then lane l of wave w — which owns a1 positions 4l..4l+3 of channels
+// 2w, 2w+1 for dgrad / gw1 — reads them back together with a second copy of the same x window.
+// Here that lane computes layer-1 group l+1 (a1 positions r = 4l-1 .. 4l+2 relative to the tile's
+// first owned position) of its two channels itself, from ONE 12-float x window that it keeps for
+// gw1; the selectors never leave registers, a1 goes to LDS (one 16-byte store per channel) only
+// for the gw2 phase of the other waves, the dz2 window shrinks from 12 to 8 floats and is 16-byte
+// aligned, and dgrad + gw1 no longer wait for the barrier behind layer 1.  Positions shifted by
+// one (r = 4l-1+u): the groups then cover exactly what gw2 reads (a1 index 4 .. 259), position
+// r = -1 is computed for that halo and owned by the previous tile.  Same arithmetic per value as
+// potes_bwd_kernel<true> (conv1_window; the accumulations per lane differ only in which lane
+// holds which position), same partial layout.
+__global__ __launch_bounds__(kPotThreads) void potes_bwd_fused_kernel(
+    const float* __restrict__ x, const float* __restrict__ gh2, const uint8_t* __restrict__ m2,
+    const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+    const float* __restrict__ b2, float* __restrict__ partial /* gridDim.x * 212 */, int N, int T) {
+  __shared__ PotesWeights W;
+  __shared__ __align__(16) float xs[kBwdNX + 4];
+  __shared__ __align__(16) float a1s[kC1 * kBwdNQ];
+  __shared__ __align__(16) float dz2s[kC2 * (kBwdNJ + 12)];
+  __shared__ float red[4 * kNAcc];
+  constexpr int kDz2Row = kBwdNJ + 12;
+  const PotesDims d = potes_dims(T);
+  const int tiles = potes_bwd_tiles(d);
+  const unsigned work = (unsigned)N * (unsigned)tiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  load_weights(&W, w1, b1, w2, b2);
+  for (int i = threadIdx.x; i < kC2 * kDz2Row; i += kPotThreads) dz2s[i] = 0.f;
+
+  float acc2[kC1][kK], acc1[2][kK], accb1[2] = {0.f, 0.f}, accb2 = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < kC1; ++ci)
+#pragma unroll
+    for (int k = 0; k < kK; ++k) acc2[ci][k] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int k = 0; k < kK; ++k) acc1[c][k] = 0.f;
+
+  constexpr int kXPer = (kBwdNX + 4 + kPotThreads - 1) / kPotThreads;   // 3
+  float xr[kXPer], gr[2];
+  uint32_t mr[2] = {0u, 0u};
+  const int m2s = (d.P2 + 3) / 4;
+  auto prefetch = [&](unsigned it) {
+    const int n = (int)(it / (unsigned)tiles), p0 = (int)(it - (unsigned)n * (unsigned)tiles) * kBwdTP;
+    const int xlo = 2 * (2 * p0 - 5) - 1;
+    const float* xrow = x + (size_t)n * T;
+#pragma unroll
+    for (int j = 0; j < kXPer; ++j) {
+      const int u = threadIdx.x + j * kPotThreads, g = xlo + u;
+      xr[j] = (u < kBwdNX + 4 && g >= 0 && g < T) ? xrow[g] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pe = p0 - 2 + 2 * lane + u;
+      gr[u] = (pe >= 0 && pe < d.P2) ? gh2[((size_t)n * kC2 + wave) * d.P2 + pe] : 0.f;
+      mr[u] = (pe >= 0 && pe < d.P2)
+                  ? (m2[((size_t)n * kC2 + wave) * m2s + (pe >> 2)] >> (2 * (pe & 3))) & 3u
+                  : 0u;
+    }
+  };
+  if (blockIdx.x < work) prefetch(blockIdx.x);
+  __syncthreads();                                   // weights in LDS before the first item reads them
+
+  // this lane's two first-layer channels: weights in registers for the whole kernel
+  const int ci0 = __builtin_amdgcn_readfirstlane(2 * wave);
+  float wl[2][kK], bl[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int k = 0; k < kK; ++k) wl[c][k] = W.w1[(ci0 + c) * kK + k];
+    bl[c] = W.b1[ci0 + c];
+  }
+  const int R0 = 4 * lane;                           // positions r = R0 - 1 + u, u < 4
+
+  for (unsigned item = blockIdx.x; item < work; item += gridDim.x) {
+    const int n = (int)(item / (unsigned)tiles), p0 = (int)(item - (unsigned)n * (unsigned)tiles) * kBwdTP;
+    (void)n;
+    __syncthreads();  // previous item's LDS fully consumed
+#pragma unroll
+    for (int j = 0; j < kXPer; ++j) {
+      const int u = threadIdx.x + j * kPotThreads;
+      if (u < kBwdNX + 4) xs[u] = xr[j];
+    }
+    {
+      f4 dz;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        dz[2 * u] = mr[u] == 1u ? gr[u] : 0.f;
+        dz[2 * u + 1] = mr[u] == 2u ? gr[u] : 0.f;
+      }
+      *reinterpret_cast<f4*>(dz2s + wave * kDz2Row + 4 * lane) = dz;
+    }
+    if (item + gridDim.x < work) prefetch(item + gridDim.x);
+    __syncthreads();
+    {  // layer 1 (group lane+1 of channels 2w, 2w+1) -> a1 to LDS, selectors in registers;
+       // back through conv2 to these positions; routed by the selectors straight into gw1 / gb1
+      float xw[12];
+      lds_load12(xs + 2 * R0 + 8, xw);
+      uint32_t sel[2] = {0u, 0u};                      // 2 bits per position u
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float cv[8];
+        conv1_window(xw, wl[c], bl[c], cv);
+        f4 out;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = 2 * p0 + R0 - 1 + u;
+          const float ra = fmaxf(cv[2 * u], 0.f), rb = fmaxf(cv[2 * u + 1], 0.f);
+          float a = 0.f;
+          uint32_t sc = 0;
+          if (q >= 0 && q < d.P1) {
+            if (rb > ra) { a = rb; sc = 2; } else { a = ra; sc = ra > 0.f ? 1 : 0; }
+          }
+          out[u] = a;
+          // owned by this tile (gradient accumulated here) only for 0 <= r < kBwdNS
+          const int r = R0 - 1 + u;
+          if (r >= 0 && r < kBwdNS) sel[c] |= sc << (2 * u);
+        }
+        *reinterpret_cast<f4*>(a1s + (ci0 + c) * kBwdNQ + R0 + 4) = out;
+      }
+      float da1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 1
+      for (int co = 0; co < kC2; ++co) {
+        float dw[8];
+        lds_load8(dz2s + co * kDz2Row + R0, dw);       // dz2 index r + 5 - k = R0 + u + 4 - k
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float w[kK];
+#pragma unroll
+          for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci0 + c) * kK + k];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < kK; ++k) da1[c][u] = fmaf(dw[u + 4 - k], w[k], da1[c][u]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float dd[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t sc = (sel[c] >> (2 * u)) & 3u;
+          dd[2 * u] = sc == 1u ? da1[c][u] : 0.f;
+          dd[2 * u + 1] = sc == 2u ? da1[c][u] : 0.f;
+        }
+        accb1[c] += ((dd[0] + dd[1]) + (dd[2] + dd[3])) + ((dd[4] + dd[5]) + (dd[6] + dd[7]));
+#pragma unroll
+        for (int k = 0; k < kK; ++k)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc1[c][k] = fmaf(dd[u], xw[u + k], acc1[c][k]);
+      }
+    }
+    __syncthreads();                                   // a1s complete
+    {  // gw2 / gb2: wave = co, lane -> owned s0 = 4*lane .. +3 (s < 250)
+      const int co = wave, s0 = 4 * lane;
+      const f4 dv = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + s0 + 4);
+      float dd[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u >= kBwdNS) dd[u] = 0.f;
+      accb2 += (dd[0] + dd[1]) + (dd[2] + dd[3]);
+      if (s0 < kBwdNS) {
+#pragma unroll
+        for (int ci = 0; ci < kC1; ++ci) {
+          float aw[8];
+          lds_load8(a1s + ci * kBwdNQ + s0 + 4, aw);
+#pragma unroll
+          for (int k = 0; k < kK; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc2[ci][k] = fmaf(dd[u], aw[u + k], acc2[ci][k]);
+        }
+      }
+    }
+  }
+
+  float flat[kNAcc];
+#pragma unroll
+  for (int ci = 0; ci < kC1; ++ci)
+#pragma unroll
+    for (int k = 0; k < kK; ++k) flat[ci * kK + k] = acc2[ci][k];
+  flat[40] = accb2;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+#pragma unroll
+    for (int k = 0; k < kK; ++k) flat[41 + c * kK + k] = acc1[c][k];
+    flat[51 + c] = accb1[c];
+  }
+#pragma unroll
+  for (int e = 0; e < kNAcc; ++e) flat[e] = wave_sum_lane63(flat[e]);
+  __syncthreads();
+  if (lane == 63)
+#pragma unroll
+    for (int e = 0; e < kNAcc; ++e) red[wave * kNAcc + e] = flat[e];
+  __syncthreads();
+  for (int e = threadIdx.x; e < kNGrad; e += kPotThreads) {
+    float v;
+    if (e < kNW1) {
+      const int ci = e / kK, k = e - ci * kK;
+      v = red[(ci >> 1) * kNAcc + 41 + (ci & 1) * kK + k];
+    } else if (e < kNW1 + kC1) {
+      const int ci = e - kNW1;
+      v = red[(ci >> 1) * kNAcc + 51 + (ci & 1)];
+    } else if (e < kNW1 + kC1 + kNW2) {
+      const int f = e - kNW1 - kC1;
+      const int co = f / (kC1 * kK), rest = f - co * (kC1 * kK);
+      v = red[co * kNAcc + rest];
+    } else {
       v = red[(e - kNW1 - kC1 - kNW2) * kNAcc + 40];
     }
     partial[(size_t)blockIdx.x * kNGrad + e] = v;
@@ -1317,8 +1542,13 @@ extern "C" int pcgmix_potes_stack_bwd_mask_f32(const float* x, const float* grad
     return hipErrorInvalidValue;
   const int G = pcgmix_potes_bwd_blocks(N, T);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(potes_bwd_kernel<true>, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2,
-                     m2, w1, b1, w2, b2, partial, N, T);
+  static const bool fused = getenv("PCGMIX_POTES_BWD_UNFUSED") == nullptr;     // A/B runs
+  if (fused)
+    hipLaunchKernelGGL(potes_bwd_fused_kernel, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2,
+                       m2, w1, b1, w2, b2, partial, N, T);
+  else
+    hipLaunchKernelGGL(potes_bwd_kernel<true>, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2,
+                       m2, w1, b1, w2, b2, partial, N, T);
   hipLaunchKernelGGL(potes_reduce_kernel, dim3(kNGrad), dim3(kPotThreads), 0, s, partial, grads, G);
   return (int)hipGetLastError();
 }
