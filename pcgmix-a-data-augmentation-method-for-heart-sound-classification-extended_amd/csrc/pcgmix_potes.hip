@@ -647,32 +647,27 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------- backward, fused
-// potes_bwd_kernel<true> with everything between the staging barrier and the end of the item done
-// by ONE lane per (channel pair, four a1 positions) (VERDICT r2 item 6 / DESIGN §7.1).
-// In potes_bwd_kernel a work item of layer 1 is (channel, group of 4 pooled positions) spread over
-// the block in two rounds, its outputs and ReLU/pool selectors go to LDS (a1s, sel1), a barrier,
-// then lane l of wave w — which owns a1 positions of channels 2w, 2w+1 for dgrad / gw1 — reads the
-// selectors back together with a second copy of the same x window, and a third phase (wave = co)
-// reads a1 of all eight channels and dz2 again for gw2.
-// Here lane l of wave w computes layer-1 group l+1 (a1 positions r = 4l-1 .. 4l+2 relative to the
-// tile's first owned position; index qq = 4l+4+u in the old a1s) of channels 2w, 2w+1 from ONE
-// 12-float x window, keeps a1 and the selectors in registers, and for each co loads ONE 8-float dz2
-// window (16-byte aligned: dz2 index qq - k = 4l + u + 4 - k) that serves BOTH
-//   dgrad   da1[c][u]     += dz2[qq - k] * w2[co][2w+c][k]
-//   gw2     acc2[co][c][k] += dz2[qq - k] * a1[c][u]        (dz2 counted only where this tile owns it)
-// — gw2 is a sum over (conv2 output, tap) pairs, and enumerating them by the a1 position they read
-// instead of by the output makes the operand the lane already holds.  Then pool/ReLU routing from
-// the register selectors straight into gw1 / gb1 with the x window still in registers.  No a1s, no
-// sel1, no third phase, two block barriers per item instead of three, 11 ds_read_b128 per lane and
-// item instead of ~31.  Same multiply-adds (480 per lane and item), same values (conv1_window is
-// the forward's arithmetic; sums are accumulated in another order: checked against torch like the
-// other backward kernels, tests/test_potes_gpu.py), same partial layout for potes_reduce_kernel.
-__global__ __launch_bounds__(kPotThreads, 3) void potes_bwd_fused_kernel(
+// potes_bwd_kernel<true> with the first-layer recompute moved onto the lane that consumes it
+// (VERDICT r2 item 6 / DESIGN §7.1).  In that kernel a work item of layer 1 is (channel, group of
+// 4 pooled positions) spread over the block in two rounds, its ReLU/pool selectors go to LDS
+// (sel1), a barrier, and then lane l of wave w — which owns a1 positions 4l..4l+3 of channels
+// 2w, 2w+1 for dgrad / gw1 — reads them back together with a second copy of the same x window.
+// Here that lane computes layer-1 group l+1 (a1 positions r = 4l-1 .. 4l+2 relative to the tile's
+// first owned position) of its two channels itself, from ONE 12-float x window that it keeps for
+// gw1; the selectors never leave registers, a1 goes to LDS (one 16-byte store per channel) only
+// for the gw2 phase of the other waves, the dz2 window shrinks from 12 to 8 floats and is 16-byte
+// aligned, and dgrad + gw1 no longer wait for the barrier behind layer 1.  Positions shifted by
+// one (r = 4l-1+u): the groups then cover exactly what gw2 reads (a1 index 4 .. 259), position
+// r = -1 is computed for that halo and owned by the previous tile.  Same arithmetic per value as
+// potes_bwd_kernel<true> (conv1_window; the accumulations per lane differ only in which lane
+// holds which position), same partial layout.
+__global__ __launch_bounds__(kPotThreads) void potes_bwd_fused_kernel(
     const float* __restrict__ x, const float* __restrict__ gh2, const uint8_t* __restrict__ m2,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
     const float* __restrict__ b2, float* __restrict__ partial /* gridDim.x * 212 */, int N, int T) {
   __shared__ PotesWeights W;
   __shared__ __align__(16) float xs[kBwdNX + 4];
+  __shared__ __align__(16) float a1s[kC1 * kBwdNQ];
   __shared__ __align__(16) float dz2s[kC2 * (kBwdNJ + 12)];
   __shared__ float red[4 * kNAcc];
   constexpr int kDz2Row = kBwdNJ + 12;
@@ -683,16 +678,11 @@ __global__ __launch_bounds__(kPotThreads, 3) void potes_bwd_fused_kernel(
   load_weights(&W, w1, b1, w2, b2);
   for (int i = threadIdx.x; i < kC2 * kDz2Row; i += kPotThreads) dz2s[i] = 0.f;
 
-  // Private accumulators (wave w: input channels 2w, 2w+1 of both layers):
-  //   acc2[co][c][k] = gw2[co][2w+c][k] (40), acc1[c][k] = gw1[2w+c][k] (10), accb1[c] = gb1[2w+c],
-  //   accb2 = gb2[w] (accumulated where dz2 is staged: wave = co there)
-  float acc2[kC2][2][kK], acc1[2][kK], accb1[2] = {0.f, 0.f}, accb2 = 0.f;
+  float acc2[kC1][kK], acc1[2][kK], accb1[2] = {0.f, 0.f}, accb2 = 0.f;
 #pragma unroll
-  for (int co = 0; co < kC2; ++co)
+  for (int ci = 0; ci < kC1; ++ci)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int k = 0; k < kK; ++k) acc2[co][c][k] = 0.f;
+    for (int k = 0; k < kK; ++k) acc2[ci][k] = 0.f;
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -721,22 +711,18 @@ __global__ __launch_bounds__(kPotThreads, 3) void potes_bwd_fused_kernel(
     }
   };
   if (blockIdx.x < work) prefetch(blockIdx.x);
-  __syncthreads();                                   // weights in LDS before anyone reads them
+  __syncthreads();                                   // weights in LDS before the first item reads them
 
+  // this lane's two first-layer channels: weights in registers for the whole kernel
   const int ci0 = __builtin_amdgcn_readfirstlane(2 * wave);
-  float wl[2][kK], bl[2];                            // this wave's two first-layer channels (uniform)
+  float wl[2][kK], bl[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
 #pragma unroll
-    for (int k = 0; k < kK; ++k) wl[c][k] = w1[(ci0 + c) * kK + k];
-    bl[c] = b1[ci0 + c];
+    for (int k = 0; k < kK; ++k) wl[c][k] = W.w1[(ci0 + c) * kK + k];
+    bl[c] = W.b1[ci0 + c];
   }
-  const int R0 = 4 * lane;                           // a1 positions r = R0 - 1 + u, u < 4
-  // dz2 index jj = R0 + i of this lane's window is OWNED by the tile (counts for gw2 / gb2) iff
-  // 4 <= jj < 4 + kBwdNS; the halo on either side belongs to the neighbouring tiles
-  float own[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) own[i] = (R0 + i >= 4 && R0 + i < 4 + kBwdNS) ? 1.f : 0.f;
+  const int R0 = 4 * lane;                           // positions r = R0 - 1 + u, u < 4
 
   for (unsigned item = blockIdx.x; item < work; item += gridDim.x) {
     const int n = (int)(item / (unsigned)tiles), p0 = (int)(item - (unsigned)n * (unsigned)tiles) * kBwdTP;
@@ -747,7 +733,7 @@ __global__ __launch_bounds__(kPotThreads, 3) void potes_bwd_fused_kernel(
       const int u = threadIdx.x + j * kPotThreads;
       if (u < kBwdNX + 4) xs[u] = xr[j];
     }
-    {  // dz2 on the extended range straight from the saved routing (wave = co); gb2 on the way
+    {
       f4 dz;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -755,80 +741,95 @@ __global__ __launch_bounds__(kPotThreads, 3) void potes_bwd_fused_kernel(
         dz[2 * u + 1] = mr[u] == 2u ? gr[u] : 0.f;
       }
       *reinterpret_cast<f4*>(dz2s + wave * kDz2Row + 4 * lane) = dz;
-      // jj = 4*lane + i: the first four entries of `own` describe exactly these positions
-      accb2 += (dz[0] * own[0] + dz[1] * own[1]) + (dz[2] * own[2] + dz[3] * own[3]);
     }
     if (item + gridDim.x < work) prefetch(item + gridDim.x);
     __syncthreads();
-    float xw[12];
-    lds_load12(xs + 2 * R0 + 8, xw);
-    float a1v[2][4];
-    uint32_t sel[2] = {0u, 0u};                        // 2 bits per position u, 0 where not owned
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      float cv[8];
-      conv1_window(xw, wl[c], bl[c], cv);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int q = 2 * p0 + R0 - 1 + u;
-        const float ra = fmaxf(cv[2 * u], 0.f), rb = fmaxf(cv[2 * u + 1], 0.f);
-        float a = 0.f;
-        uint32_t sc = 0;
-        if (q >= 0 && q < d.P1) {
-          if (rb > ra) { a = rb; sc = 2; } else { a = ra; sc = ra > 0.f ? 1 : 0; }
-        }
-        a1v[c][u] = a;
-        const int r = R0 - 1 + u;                      // gradient of this position accumulated here
-        if (r >= 0 && r < kBwdNS) sel[c] |= sc << (2 * u);
-      }
-    }
-    float da1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int co = 0; co < kC2; ++co) {                 // unrolled: acc2 is indexed statically
-      float dw[8], dwo[8];
-      lds_load8(dz2s + co * kDz2Row + R0, dw);         // dz2 index qq - k = R0 + u + 4 - k
-#pragma unroll
-      for (int i = 0; i < 8; ++i) dwo[i] = dw[i] * own[i];
+    {  // layer 1 (group lane+1 of channels 2w, 2w+1) -> a1 to LDS, selectors in registers;
+       // back through conv2 to these positions; routed by the selectors straight into gw1 / gb1
+      float xw[12];
+      lds_load12(xs + 2 * R0 + 8, xw);
+      uint32_t sel[2] = {0u, 0u};                      // 2 bits per position u
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        float w[kK];
+        float cv[8];
+        conv1_window(xw, wl[c], bl[c], cv);
+        f4 out;
 #pragma unroll
-        for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci0 + c) * kK + k];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int k = 0; k < kK; ++k) {
-            da1[c][u] = fmaf(dw[u + 4 - k], w[k], da1[c][u]);
-            acc2[co][c][k] = fmaf(dwo[u + 4 - k], a1v[c][u], acc2[co][c][k]);
+        for (int u = 0; u < 4; ++u) {
+          const int q = 2 * p0 + R0 - 1 + u;
+          const float ra = fmaxf(cv[2 * u], 0.f), rb = fmaxf(cv[2 * u + 1], 0.f);
+          float a = 0.f;
+          uint32_t sc = 0;
+          if (q >= 0 && q < d.P1) {
+            if (rb > ra) { a = rb; sc = 2; } else { a = ra; sc = ra > 0.f ? 1 : 0; }
           }
+          out[u] = a;
+          // owned by this tile (gradient accumulated here) only for 0 <= r < kBwdNS
+          const int r = R0 - 1 + u;
+          if (r >= 0 && r < kBwdNS) sel[c] |= sc << (2 * u);
+        }
+        *reinterpret_cast<f4*>(a1s + (ci0 + c) * kBwdNQ + R0 + 4) = out;
+      }
+      float da1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 1
+      for (int co = 0; co < kC2; ++co) {
+        float dw[8];
+        lds_load8(dz2s + co * kDz2Row + R0, dw);       // dz2 index r + 5 - k = R0 + u + 4 - k
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float w[kK];
+#pragma unroll
+          for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci0 + c) * kK + k];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < kK; ++k) da1[c][u] = fmaf(dw[u + 4 - k], w[k], da1[c][u]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float dd[8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t sc = (sel[c] >> (2 * u)) & 3u;
+          dd[2 * u] = sc == 1u ? da1[c][u] : 0.f;
+          dd[2 * u + 1] = sc == 2u ? da1[c][u] : 0.f;
+        }
+        accb1[c] += ((dd[0] + dd[1]) + (dd[2] + dd[3])) + ((dd[4] + dd[5]) + (dd[6] + dd[7]));
+#pragma unroll
+        for (int k = 0; k < kK; ++k)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc1[c][k] = fmaf(dd[u], xw[u + k], acc1[c][k]);
       }
     }
+    __syncthreads();                                   // a1s complete
+    {  // gw2 / gb2: wave = co, lane -> owned s0 = 4*lane .. +3 (s < 250)
+      const int co = wave, s0 = 4 * lane;
+      const f4 dv = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + s0 + 4);
+      float dd[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      float dd[8];
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u >= kBwdNS) dd[u] = 0.f;
+      accb2 += (dd[0] + dd[1]) + (dd[2] + dd[3]);
+      if (s0 < kBwdNS) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t sc = (sel[c] >> (2 * u)) & 3u;
-        dd[2 * u] = sc == 1u ? da1[c][u] : 0.f;
-        dd[2 * u + 1] = sc == 2u ? da1[c][u] : 0.f;
+        for (int ci = 0; ci < kC1; ++ci) {
+          float aw[8];
+          lds_load8(a1s + ci * kBwdNQ + s0 + 4, aw);
+#pragma unroll
+          for (int k = 0; k < kK; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc2[ci][k] = fmaf(dd[u], aw[u + k], acc2[ci][k]);
+        }
       }
-      accb1[c] += ((dd[0] + dd[1]) + (dd[2] + dd[3])) + ((dd[4] + dd[5]) + (dd[6] + dd[7]));
-#pragma unroll
-      for (int k = 0; k < kK; ++k)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc1[c][k] = fmaf(dd[u], xw[u + k], acc1[c][k]);
     }
   }
 
-  // ---- one cross-lane reduction per kernel, then one partial vector per block ----------------
-  // flat: [0..39] acc2[co][c][k] at co*10 + c*5 + k | 40 accb2 | 41..50 acc1[c][k] | 51, 52 accb1[c]
   float flat[kNAcc];
 #pragma unroll
-  for (int co = 0; co < kC2; ++co)
+  for (int ci = 0; ci < kC1; ++ci)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int k = 0; k < kK; ++k) flat[co * 10 + c * kK + k] = acc2[co][c][k];
+    for (int k = 0; k < kK; ++k) flat[ci * kK + k] = acc2[ci][k];
   flat[40] = accb2;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
@@ -845,18 +846,17 @@ __global__ __launch_bounds__(kPotThreads, 3) void potes_bwd_fused_kernel(
   __syncthreads();
   for (int e = threadIdx.x; e < kNGrad; e += kPotThreads) {
     float v;
-    if (e < kNW1) {                       // gw1[ci][k]
+    if (e < kNW1) {
       const int ci = e / kK, k = e - ci * kK;
       v = red[(ci >> 1) * kNAcc + 41 + (ci & 1) * kK + k];
-    } else if (e < kNW1 + kC1) {          // gb1[ci]
+    } else if (e < kNW1 + kC1) {
       const int ci = e - kNW1;
       v = red[(ci >> 1) * kNAcc + 51 + (ci & 1)];
-    } else if (e < kNW1 + kC1 + kNW2) {   // gw2[co][ci][k]: wave ci/2 holds it at co*10 + (ci&1)*5 + k
+    } else if (e < kNW1 + kC1 + kNW2) {
       const int f = e - kNW1 - kC1;
       const int co = f / (kC1 * kK), rest = f - co * (kC1 * kK);
-      const int ci = rest / kK, k = rest - ci * kK;
-      v = red[(ci >> 1) * kNAcc + co * 10 + (ci & 1) * kK + k];
-    } else {                              // gb2[co]
+      v = red[co * kNAcc + rest];
+    } else {
       v = red[(e - kNW1 - kC1 - kNW2) * kNAcc + 40];
     }
     partial[(size_t)blockIdx.x * kNGrad + e] = v;
