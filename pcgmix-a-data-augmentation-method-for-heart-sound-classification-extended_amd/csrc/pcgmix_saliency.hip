@@ -258,6 +258,24 @@ struct SeqMid {                 // op(l[i], s[i]); own_longer decides which one 
   }
 };
 
+// Middle sum of the lambda-weighted objective with both segments scaled ONCE at staging
+// (lng * lam or (1-lam), sht * the other): the reference forms lam*s1 + (1-lam)*s2 element by
+// element for every candidate (augmentations.py:111); the two products are rounded on their own,
+// so scaling each sample once and adding per candidate gives the same bits (the add is
+// commutative) with one operation per element instead of three.
+struct SeqAdd {
+  const float* l;
+  const float* s;
+  __device__ __forceinline__ float get(int i) const { return __fadd_rn(l[i], s[i]); }
+  __device__ __forceinline__ void get8(int i, float (&v)[8]) const {
+    float a[8], b[8];
+    lds_get8<true>(l + i, a);
+    lds_get8<true>(s + i, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = __fadd_rn(a[j], b[j]);
+  }
+};
+
 // The split tree is walked leaf by leaf, in order, without a memory stack.  A leaf is a PATH from
 // the root — DEPTH bits, MSB first, 0 = left child — and its range follows from the path by DEPTH
 // unrolled split steps (a node splits while it holds more than 128 elements, so subtrees end at
@@ -384,8 +402,14 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   // multiple of 4 floats.  Copies are `cs` floats apart with cs = 16 (mod 64): the 16 lanes of a
   // ds_read_b128 pass (4 consecutive offsets x 4 copies) then cover all 64 banks exactly once.
   const int cs = COPIES ? disp_copy_stride(max_len) : 0;
+  // MODE 1 with copies: the four copies and sht hold the segments already multiplied by lambda /
+  // (1 - lambda) (SeqAdd); the head and tail sums of the longer-is-own case need the unscaled
+  // segment, kept once in front of the copies (`raw`; its tail windows are read unaligned).
+  constexpr bool kPrescale = MODE == 1 && COPIES;
+  const float fl = own_longer ? lam : oml, fs = own_longer ? oml : lam;   // lng / sht multiplier
   float* sht = smem;
-  float* lng = smem + ((max_len + 3) & ~3);          // copy 0 == the segment itself
+  float* raw = smem + ((max_len + 3) & ~3);
+  float* lng = kPrescale ? raw + cs : raw;           // copy 0 == the (scaled) segment itself
   {  // both segments staged with all of a lane's loads in flight together (a loop with runtime
      // bounds compiles to load, wait, store, next load: up to eight serialised L2 round trips)
     constexpr int kMaxPer = 8;                       // covers states up to 2048 samples per pass
@@ -400,14 +424,16 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
       for (int u = 0; u < kMaxPer; ++u) {
         const int i = base + u * kDispThreads + threadIdx.x;
         if (i < nL) {
-          lng[i] = v[u];
+          const float sv = kPrescale ? __fmul_rn(v[u], fl) : v[u];
+          if (kPrescale) raw[i] = v[u];
+          lng[i] = sv;
           if (COPIES) {
 #pragma unroll
             for (int c = 1; c < 4; ++c)
-              if (i >= c) lng[c * cs + i - c] = v[u];
+              if (i >= c) lng[c * cs + i - c] = sv;
           }
         } else if (i < nL + nS) {
-          sht[i - nL] = v[u];
+          sht[i - nL] = kPrescale ? __fmul_rn(v[u], fs) : v[u];
         }
       }
     }
@@ -417,13 +443,16 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   float bv = -INFINITY;
   int bd = 0x7fffffff;
   for (int d = z * kDispThreads + threadIdx.x; d <= nL - nS; d += kDispSplit * kDispThreads) {
-    const SeqMid<MODE, COPIES> mid{COPIES ? lng + (d & 3) * cs + (d & ~3) : lng + d, sht, lam, oml,
-                                   own_longer};
-    float cur = pw_sum<DEPTH>(mid, nS);
+    const float* win = COPIES ? lng + (d & 3) * cs + (d & ~3) : lng + d;
+    float cur;
+    if (kPrescale) cur = pw_sum<DEPTH>(SeqAdd{win, sht}, nS);
+    else cur = pw_sum<DEPTH>(SeqMid<MODE, COPIES>{win, sht, lam, oml, own_longer}, nS);
     if (own_longer) {  // np.sum(s1[:d]) + np.sum(mid) + np.sum(s1[d+n2:])   (:76-78, :111-113)
       const int t0 = d + nS;
-      const float head = pw_sum<DEPTH>(SeqPlain<true>{lng}, d);
-      const float tail = pw_sum<DEPTH>(SeqPlain<COPIES>{COPIES ? lng + (t0 & 3) * cs + (t0 & ~3) : lng + t0},
+      const float head = pw_sum<DEPTH>(SeqPlain<true>{raw}, d);
+      float tail;
+      if (kPrescale) tail = pw_sum<DEPTH>(SeqPlain<false>{raw + t0}, nL - nS - d);
+      else tail = pw_sum<DEPTH>(SeqPlain<COPIES>{COPIES ? lng + (t0 & 3) * cs + (t0 & ~3) : lng + t0},
                                 nL - nS - d);
       cur = __fadd_rn(__fadd_rn(head, cur), tail);
     }
@@ -572,7 +601,8 @@ int pcgmix::launch_salopt_search(const float* sal, const int32_t* frames, const 
   if (B == 0) return hipSuccess;
   if (max_len <= 0 || max_len > T) max_len = T;
   const size_t seg = (size_t)((max_len + 3) & ~3);
-  size_t lds = sizeof(float) * (seg + 4 * (size_t)disp_copy_stride(max_len));
+  // mode 1 keeps one unscaled copy of the longer segment in front of the four scaled ones
+  size_t lds = sizeof(float) * (seg + (mode == 1 ? 5 : 4) * (size_t)disp_copy_stride(max_len));
   const bool copies = lds <= 96 * 1024;              // longer segments: one copy, unaligned windows
   if (!copies) lds = sizeof(float) * 2 * seg;
   if (lds > 150 * 1024) return hipErrorInvalidValue;

@@ -473,3 +473,49 @@ def test_salopt_fast_path_beyond_the_kernarg_batch(device):
         assert np.abs(plain[0].cpu().numpy() - ref["y"]).max() <= 1e-4
     finally:
         saliency.set_saliency_model(None)
+
+
+def test_salopt_begin_with_host_labels_all_paths(device):
+    """pcgmix_ctx_salopt_begin_labels (round 3): labels handed over on the host, no read-back.
+    B <= 256: seed, boundaries and a pending payload ride in ONE launch's arguments; B > 256: a
+    staged [frames | labels] block and a kernel.  Both == the read-back form; a payload set on
+    the context arrives at its destination (small batch) or stays pending for flush (large);
+    malformed boundaries and out-of-range labels are refused."""
+    import ctypes
+    from pcgmix_amd import _lib, synthetic
+    lib = _lib.load()
+    torch.manual_seed(2)
+    saliency.set_saliency_model(models.CNN_potes_TS(4, 2, "PhysioNet").to(device))
+    try:
+        for B in (48, 300):
+            x, frames, labels, wav = synthetic.make_batch(B, 4, 2500, seed=41 + B)
+            data = torch.from_numpy(x).to(device)
+            tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)
+            a = Args("(saloptenv)durmixmagwarp(0.2,4)")
+            ref = augmentations.augment(a, data, tgt, frames, wav, StepCounter(5), None, device, "")
+            ctx = augmentations.step_context(device.index)
+            pay = np.arange(40, dtype=np.float32) + B
+            dst = torch.zeros(40, device=device)
+            _lib.check(lib.pcgmix_ctx_set_payload(ctx, pay.ctypes.data, pay.nbytes, dst.data_ptr()), "payload")
+            got = augmentations.augment(a, data, tgt, frames, wav, StepCounter(5), None, device, "",
+                                        host_labels=labels)
+            assert np.array_equal(got[2], ref[2]) and torch.equal(got[0], ref[0])
+            if B <= 256:                       # rode in the begin kernel's arguments
+                assert np.array_equal(dst.cpu().numpy(), pay)
+            else:                              # still pending: goes on its own
+                assert float(dst.abs().sum()) == 0.0
+                _lib.check(lib.pcgmix_ctx_flush_payload(
+                    ctx, ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)), "flush")
+                assert np.array_equal(dst.cpu().numpy(), pay)
+            bad = frames.copy()
+            bad[1, 4] = 2501
+            with pytest.raises(ValueError):
+                augmentations.augment(a, data, tgt, bad, wav, StepCounter(5), None, device, "",
+                                      host_labels=labels)
+            wrong = labels.copy()
+            wrong[0] = 7                       # not a class of the (B, 2) seed
+            with pytest.raises(RuntimeError):
+                augmentations.augment(a, data, tgt, frames, wav, StepCounter(5), None, device, "",
+                                      host_labels=wrong)
+    finally:
+        saliency.set_saliency_model(None)
