@@ -17,7 +17,7 @@ adam = [i for i, r in enumerate(rows) if "adam_clip_multi_kernel" in r["Kernel_N
 steps = []
 for a, b in zip(adam, adam[1:]):
     seg = rows[a + 1:b + 1]
-    if len(seg) <= 14 and any("potes_bwd_kernel" in r["Kernel_Name"] for r in seg):
+    if len(seg) <= 14 and any("potes_bwd" in r["Kernel_Name"] for r in seg):
         steps.append((a, b))
 walls = [int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"]) for a, b in steps]
 # the eager leg of the bench launches the same kernels, host-bound (~2x the wall): keep the steps
