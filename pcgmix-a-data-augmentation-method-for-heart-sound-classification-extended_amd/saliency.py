@@ -30,6 +30,7 @@ _INJECTED: Optional[torch.nn.Module] = None
 _LOADED: dict = {}          # checkpoint path -> (mtime, model)
 _GRAPHS: dict = {}          # (id(model), shape, classes, k) -> _SaliencyGraph
 USE_GRAPHS = True           # replay the frozen model's fwd+bwd+post-processing as one hipGraph
+CHAIN_EAGER = os.environ.get("PCGMIX_SAL_CHAIN_GRAPH") is None   # see _SaliencyGraph.__init__
 
 
 def set_saliency_model(model: Optional[torch.nn.Module], freeze_copy: bool = True) -> None:
@@ -240,6 +241,17 @@ class _SaliencyGraph:
         # the batch copied into the static input and the whole pass captured.
         m = _potes_direct(model, self.x)
         self.chain = _PotesChain(m, (B, C, T), device) if m is not None else None
+        # The direct Potes chain is five plain launches with no autograd in between: replaying
+        # them as a hipGraph saves ~20 us of host time per step but costs a stream -> graph ->
+        # stream hand-over on the GPU (~9 us of idle queue behind the graph's last kernel,
+        # profiles/r3_cfg3_step_timeline.txt) — and the step is GPU-bound.  CHAIN_EAGER launches
+        # them directly instead (PCGMIX_SAL_CHAIN_GRAPH=1 restores the captured form).
+        self.eager = self.chain is not None and CHAIN_EAGER
+        if self.eager:
+            self.graph = None
+            self.chain.forward(self.x)
+            self.sal = self._run()
+            return
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
@@ -263,7 +275,10 @@ class _SaliencyGraph:
             self.chain.forward(data.detach())
         else:
             self.x.copy_(data, non_blocking=True)
-        self.graph.replay()
+        if self.eager:
+            self.sal = self._run()
+        else:
+            self.graph.replay()
 
     def replay(self, data):
         """``seed`` and ``fr`` are in place (``pcgmix_ctx_salopt_begin`` on this stream): run the
