@@ -133,6 +133,20 @@ __device__ __forceinline__ void conv1_window(const float (&xw)[12], const float 
   }
 }
 
+// ReLU + MaxPool(2) of one pair of conv outputs, branch-free: value, and which of the two won and
+// survived (0 none, 1 first, 2 second — torch's max-pool keeps the FIRST maximum: strict '>').
+// Written as selects: the nested-if form compiled to an exec-mask branch per position
+// (s_and_saveexec / s_cbranch_execz / s_or exec plus hazard nops, ~10 scalar instructions around
+// three vector ones).
+__device__ __forceinline__ void relu_pool2(float za, float zb, bool valid, float& a, uint32_t& sc) {
+  const float ra = fmaxf(za, 0.f), rb = fmaxf(zb, 0.f);
+  const bool second = rb > ra;
+  const float best = second ? rb : ra;
+  const uint32_t code = second ? 2u : (ra > 0.f ? 1u : 0u);
+  a = valid ? best : 0.f;
+  sc = valid ? code : 0u;
+}
+
 template <bool SWZ>
 __device__ __forceinline__ void layer1_t(const PotesWeights& W, const float* xs, float* a1s,
                                          uint8_t* sel, int qlo, int nq, int P1, int xplane,
@@ -162,15 +176,10 @@ __device__ __forceinline__ void layer1_t(const PotesWeights& W, const float* xs,
     uint32_t sels = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const float za = c[2 * u], zb = c[2 * u + 1];
       const int q = qlo + 4 * g + u;
-      const float ra = fmaxf(za, 0.f), rb = fmaxf(zb, 0.f);
-      float a = 0.f;
-      uint32_t sc = 0;
-      if (q >= 0 && q < P1) {
-        // torch's max-pool keeps the FIRST maximum (strict '>' scan)
-        if (rb > ra) { a = rb; sc = 2; } else { a = ra; sc = ra > 0.f ? 1 : 0; }
-      }
+      float a;
+      uint32_t sc;
+      relu_pool2(c[2 * u], c[2 * u + 1], q >= 0 && q < P1, a, sc);
       out[u] = a;
       sels |= sc << (8 * u);
     }
@@ -757,12 +766,9 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_fused_kernel(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int q = 2 * p0 + R0 - 1 + u;
-          const float ra = fmaxf(cv[2 * u], 0.f), rb = fmaxf(cv[2 * u + 1], 0.f);
-          float a = 0.f;
-          uint32_t sc = 0;
-          if (q >= 0 && q < d.P1) {
-            if (rb > ra) { a = rb; sc = 2; } else { a = ra; sc = ra > 0.f ? 1 : 0; }
-          }
+          float a;
+          uint32_t sc;
+          relu_pool2(cv[2 * u], cv[2 * u + 1], q >= 0 && q < d.P1, a, sc);
           out[u] = a;
           // owned by this tile (gradient accumulated here) only for 0 <= r < kBwdNS
           const int r = R0 - 1 + u;
