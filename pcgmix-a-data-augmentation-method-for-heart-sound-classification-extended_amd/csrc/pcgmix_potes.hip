@@ -390,7 +390,8 @@ __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
 // group of these and then lds_wait().
 __device__ __forceinline__ f2 lds_pair(const float* p) {
   f2 r;
-  asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(r) : "v"((unsigned)(uintptr_t)p));
+  // "memory": must not move above the block barrier that publishes the LDS data it reads
+  asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(r) : "v"((unsigned)(uintptr_t)p) : "memory");
   return r;
 }
 __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -840,11 +841,22 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_fused_kernel(
       if (s0 < kBwdNS) {
         const f2 d0 = {dd[0], dd[0]}, d1 = {dd[1], dd[1]}, d2 = {dd[2], dd[2]}, d3 = {dd[3], dd[3]};
 #pragma unroll
-        for (int ci = 0; ci < kC1; ++ci) {   // acc2[ci][k] += dd[u] * aw[u + k], aw = a1[ci][s0+4 ..]
+        for (int cg = 0; cg < kC1; cg += 2) {   // two channels' odd pairs per wait (12 registers)
+        f2 Q[2][3];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const float* ap = a1s + (cg + cc) * kBwdNQ + s0 + 4;
+          Q[cc][0] = lds_pair(ap + 1);
+          Q[cc][1] = lds_pair(ap + 3);
+          Q[cc][2] = lds_pair(ap + 5);
+        }
+        lds_wait();
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {     // acc2[ci][k] += dd[u] * aw[u + k], aw = a1[ci][s0+4 ..]
+          const int ci = cg + cc;
           const float* ap = a1s + ci * kBwdNQ + s0 + 4;
           const f4 A0 = *reinterpret_cast<const f4*>(ap), A1 = *reinterpret_cast<const f4*>(ap + 4);
-          const f2 Q1 = lds_pair(ap + 1), Q3 = lds_pair(ap + 3), Q5 = lds_pair(ap + 5);
-          lds_wait();
+          const f2 Q1 = Q[cc][0], Q3 = Q[cc][1], Q5 = Q[cc][2];
           const f2 P0 = {A0.x, A0.y}, P2 = {A0.z, A0.w}, P4 = {A1.x, A1.y};
           f2 a = acc2a[ci], b = acc2b[ci];
           float c = acc2c[ci];
@@ -853,6 +865,7 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_fused_kernel(
           a = __builtin_elementwise_fma(d2, P2, a); b = __builtin_elementwise_fma(d2, P4, b); c = fmaf(dd[2], A1.z, c);
           a = __builtin_elementwise_fma(d3, Q3, a); b = __builtin_elementwise_fma(d3, Q5, b); c = fmaf(dd[3], A1.w, c);
           acc2a[ci] = a; acc2b[ci] = b; acc2c[ci] = c;
+        }
         }
       }
     }
