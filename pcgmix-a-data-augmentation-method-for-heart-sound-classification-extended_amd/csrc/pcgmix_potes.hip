@@ -72,7 +72,6 @@ __device__ __forceinline__ void stage_x(float* xs, const float* __restrict__ xro
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));   // LDS pair at an odd float offset
 
 __device__ __forceinline__ void lds_load12(const float* p, float (&v)[12]) {  // p 16-byte aligned
   const f4 a = *reinterpret_cast<const f4*>(p), b = *reinterpret_cast<const f4*>(p + 4),
@@ -382,20 +381,6 @@ __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
 // row_bcast31 carry it across the four rows.  The kernel-end reduction of the backward's 53
 // accumulators was 318 ds_bpermute_b32 per wave through __shfl_xor — 6.5 us of a 78 us kernel, all
 // of it in the tail where every block of the launch does nothing else.
-// Two consecutive floats from LDS at a 4-byte aligned address, as ONE ds_read2_b32 into an aligned
-// register pair — a packed-math operand that starts at an odd float offset of a window the lane
-// also holds as aligned b128 reads.  Inline asm on purpose: written as a C++ load the compiler
-// forwards the value from the overlapping aligned loads and assembles the pair with two v_mov
-// (that is what the ~200 v_mov_b32 per item in the backward kernels are).  The caller issues a
-// group of these and then lds_wait().
-__device__ __forceinline__ f2 lds_pair(const float* p) {
-  f2 r;
-  // "memory": must not move above the block barrier that publishes the LDS data it reads
-  asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(r) : "v"((unsigned)(uintptr_t)p) : "memory");
-  return r;
-}
-__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v) {
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
@@ -702,17 +687,11 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_fused_kernel(
   load_weights(&W, w1, b1, w2, b2);
   for (int i = threadIdx.x; i < kC2 * kDz2Row; i += kPotThreads) dz2s[i] = 0.f;
 
-  // gw2[w][ci][k] as packed pairs over k: (k0,k1), (k2,k3) and k4 alone — every multiply-add of the
-  // gw2 phase is then a v_pk_fma_f32 whose operands are register pairs as they come out of LDS
-  // (aligned pairs of the 8-float a1 window, and the odd-offset pairs read separately with
-  // ds_read2_b32), the dz2 factor broadcast by op_sel: no pair-assembly moves (§3.5).
-  f2 acc2a[kC1], acc2b[kC1];
-  float acc2c[kC1], acc1[2][kK], accb1[2] = {0.f, 0.f}, accb2 = 0.f;
+  float acc2[kC1][kK], acc1[2][kK], accb1[2] = {0.f, 0.f}, accb2 = 0.f;
 #pragma unroll
-  for (int ci = 0; ci < kC1; ++ci) {
-    acc2a[ci] = acc2b[ci] = f2{0.f, 0.f};
-    acc2c[ci] = 0.f;
-  }
+  for (int ci = 0; ci < kC1; ++ci)
+#pragma unroll
+    for (int k = 0; k < kK; ++k) acc2[ci][k] = 0.f;
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -839,33 +818,14 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_fused_kernel(
         if (s0 + u >= kBwdNS) dd[u] = 0.f;
       accb2 += (dd[0] + dd[1]) + (dd[2] + dd[3]);
       if (s0 < kBwdNS) {
-        const f2 d0 = {dd[0], dd[0]}, d1 = {dd[1], dd[1]}, d2 = {dd[2], dd[2]}, d3 = {dd[3], dd[3]};
 #pragma unroll
-        for (int cg = 0; cg < kC1; cg += 2) {   // two channels' odd pairs per wait (12 registers)
-        f2 Q[2][3];
+        for (int ci = 0; ci < kC1; ++ci) {
+          float aw[8];
+          lds_load8(a1s + ci * kBwdNQ + s0 + 4, aw);
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-          const float* ap = a1s + (cg + cc) * kBwdNQ + s0 + 4;
-          Q[cc][0] = lds_pair(ap + 1);
-          Q[cc][1] = lds_pair(ap + 3);
-          Q[cc][2] = lds_pair(ap + 5);
-        }
-        lds_wait();
+          for (int k = 0; k < kK; ++k)
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {     // acc2[ci][k] += dd[u] * aw[u + k], aw = a1[ci][s0+4 ..]
-          const int ci = cg + cc;
-          const float* ap = a1s + ci * kBwdNQ + s0 + 4;
-          const f4 A0 = *reinterpret_cast<const f4*>(ap), A1 = *reinterpret_cast<const f4*>(ap + 4);
-          const f2 Q1 = Q[cc][0], Q3 = Q[cc][1], Q5 = Q[cc][2];
-          const f2 P0 = {A0.x, A0.y}, P2 = {A0.z, A0.w}, P4 = {A1.x, A1.y};
-          f2 a = acc2a[ci], b = acc2b[ci];
-          float c = acc2c[ci];
-          a = __builtin_elementwise_fma(d0, P0, a); b = __builtin_elementwise_fma(d0, P2, b); c = fmaf(dd[0], A1.x, c);
-          a = __builtin_elementwise_fma(d1, Q1, a); b = __builtin_elementwise_fma(d1, Q3, b); c = fmaf(dd[1], A1.y, c);
-          a = __builtin_elementwise_fma(d2, P2, a); b = __builtin_elementwise_fma(d2, P4, b); c = fmaf(dd[2], A1.z, c);
-          a = __builtin_elementwise_fma(d3, Q3, a); b = __builtin_elementwise_fma(d3, Q5, b); c = fmaf(dd[3], A1.w, c);
-          acc2a[ci] = a; acc2b[ci] = b; acc2c[ci] = c;
-        }
+            for (int u = 0; u < 4; ++u) acc2[ci][k] = fmaf(dd[u], aw[u + k], acc2[ci][k]);
         }
       }
     }
@@ -873,13 +833,9 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_fused_kernel(
 
   float flat[kNAcc];
 #pragma unroll
-  for (int ci = 0; ci < kC1; ++ci) {
-    flat[ci * kK + 0] = acc2a[ci].x;
-    flat[ci * kK + 1] = acc2a[ci].y;
-    flat[ci * kK + 2] = acc2b[ci].x;
-    flat[ci * kK + 3] = acc2b[ci].y;
-    flat[ci * kK + 4] = acc2c[ci];
-  }
+  for (int ci = 0; ci < kC1; ++ci)
+#pragma unroll
+    for (int k = 0; k < kK; ++k) flat[ci * kK + k] = acc2[ci][k];
   flat[40] = accb2;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
