@@ -331,15 +331,6 @@ int pcgmix_potes_stack_bwd_mask_f32(const float* x, const float* grad_h2, const 
 int pcgmix_potes_stack_input_grad_mask_f32(const float* grad_h2, const uint8_t* m2,
                                            const uint8_t* s1, const float* w1, const float* w2,
                                            float* grad_x, int N, int T, pcgmix_stream_t stream);
-/* The same for saliency maps, which need sum_c |d score / d x[b, c, t]| only (saliency.py:63-70):
- * rows b*bands + band of the (B*bands, T) row matrix are the band channels of sample b; writes
- * sabs (DEVICE, float32 (B, T)) = (((0 + |dx_0|) + |dx_1|) + ...), the order in which
- * pcgmix_saliency_post_f32 adds channels — feeding it sabs with C = 1 gives bit-identical maps
- * while the (B, bands, T) gradient is never written or re-read. */
-int pcgmix_potes_stack_input_grad_mask_abssum_f32(const float* grad_h2, const uint8_t* m2,
-                                                  const uint8_t* s1, const float* w1,
-                                                  const float* w2, float* sabs, int B, int bands,
-                                                  int T, pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Skinny linear layer forward (the Potes head's `dimreduc`, models.py:376, 430).    [device]

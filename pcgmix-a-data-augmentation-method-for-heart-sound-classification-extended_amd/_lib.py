@@ -56,7 +56,6 @@ SIGNATURES = {
                                                  _ptr, ctypes.c_uint64, _ptr]),
     "pcgmix_potes_stack_bwd_mask_f32": (_c_int, [_ptr] * 9 + [_c_int, _c_int, _ptr]),
     "pcgmix_potes_stack_input_grad_mask_f32": (_c_int, [_ptr] * 6 + [_c_int, _c_int, _ptr]),
-    "pcgmix_potes_stack_input_grad_mask_abssum_f32": (_c_int, [_ptr] * 6 + [_c_int, _c_int, _c_int, _ptr]),
     "pcgmix_skinny_linear_splits": (_c_int, [_c_int, _c_int]),
     "pcgmix_skinny_linear_fwd_f32": (_c_int, [_ptr] * 5 + [_c_int, _c_int, _c_int, _ptr]),
     "pcgmix_adam_clip_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, ctypes.c_longlong, _c_float, _c_float,

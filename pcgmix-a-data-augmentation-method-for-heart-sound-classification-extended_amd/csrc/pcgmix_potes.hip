@@ -997,16 +997,16 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_kernel(
 // neither x nor the activations are needed — dz2 = route(gh2, m2), dL/da1 = conv2^T dz2,
 // dz1 = route(dL/da1, s1), dL/dx = conv1^T dz1.  Half the multiply-adds of the kernel above and
 // two barrier phases instead of four.  Same tile geometry.
-// One tile of one row: dz2 from the saved routing -> dL/da1 -> dz1 (through LDS) -> the transposed
-// first convolution.  Thread t ends up with dL/dx at u = 4*p0 + 2t - 1 and u + 1 (acc0, acc1; valid
-// as flagged).  Two block barriers; the caller may call it again at once (the first barrier of the
-// next call also orders this call's last LDS reads before the next call's dz1 writes).
-__device__ __forceinline__ void input_grad_mask_tile(
+__global__ __launch_bounds__(kPotThreads) void potes_input_grad_mask_kernel(
     const float* __restrict__ gh2, const uint8_t* __restrict__ m2, const uint8_t* __restrict__ s1,
-    const float* __restrict__ w1, const float* __restrict__ w2, float* dz2s, float* dz1s,
-    const PotesDims& d, int n, int p0, float& acc0, float& acc1) {
+    const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ gx, int N,
+    int T) {
   constexpr int kDz2Row = kBwdNJ + 12;
+  __shared__ __align__(16) float dz2s[kC2 * kDz2Row];
+  __shared__ __align__(16) float dz1s[kC1 * kBwdNIpad];
+  const PotesDims d = potes_dims(T);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.y, p0 = blockIdx.x * kInTP;
   const int m2s = (d.P2 + 3) / 4;
   // first-layer selectors of this lane's 4 positions q = 2p0-2+4*lane+u for its two channels:
   // issued now, consumed after the first barrier
@@ -1081,8 +1081,8 @@ __device__ __forceinline__ void input_grad_mask_tile(
      // come through the scalar cache (block-uniform) instead of 40 more LDS reads per thread:
      // this phase issued 88 LDS reads for its 80 multiply-adds.
     const int v0 = 2 * (int)threadIdx.x - 1;
-    acc0 = acc1 = 0.f;
     if (v0 < kInNU) {
+      float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
       for (int ci = 0; ci < kC1; ++ci) {
         float dw[6];
@@ -1099,60 +1099,13 @@ __device__ __forceinline__ void input_grad_mask_tile(
           acc1 = fmaf(dw[5 - k], w, acc1);
         }
       }
+      const int u = 4 * p0 + v0;
+      float* dst = gx + (size_t)n * T + u;
+      if (v0 >= 0 && u < T) dst[0] = acc0;
+      if (v0 + 1 < kInNU && u + 1 < T) dst[1] = acc1;
     }
   }
 }
-
-__global__ __launch_bounds__(kPotThreads) void potes_input_grad_mask_kernel(
-    const float* __restrict__ gh2, const uint8_t* __restrict__ m2, const uint8_t* __restrict__ s1,
-    const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ gx, int N,
-    int T) {
-  constexpr int kDz2Row = kBwdNJ + 12;
-  __shared__ __align__(16) float dz2s[kC2 * kDz2Row];
-  __shared__ __align__(16) float dz1s[kC1 * kBwdNIpad];
-  const PotesDims d = potes_dims(T);
-  const int n = blockIdx.y, p0 = blockIdx.x * kInTP;
-  float acc0, acc1;
-  input_grad_mask_tile(gh2, m2, s1, w1, w2, dz2s, dz1s, d, n, p0, acc0, acc1);
-  const int v0 = 2 * (int)threadIdx.x - 1, u = 4 * p0 + v0;
-  if (v0 < kInNU) {
-    float* dst = gx + (size_t)n * T + u;
-    if (v0 >= 0 && u < T) dst[0] = acc0;
-    if (v0 + 1 < kInNU && u + 1 < T) dst[1] = acc1;
-  }
-}
-
-// The same for saliency maps (saliency.py:63-70 wants sum_c |d score / d x[b, c, t]| only): one
-// block takes the same tile of all BANDS rows of sample b (rows b*BANDS + band: the four band
-// channels share cnn1, models.py:444-455) one after the other and keeps the running sum of |dx|
-// in registers, in the order the post-processing kernel adds channels (((0 + |g0|) + |g1|) + ...).
-// Writes (B, T) instead of (B, BANDS, T): 5 MB instead of 20 MB out, and the post-processing kernel
-// reads 5 MB instead of 20 MB (pcgmix_saliency_post_f32 with C = 1 on a non-negative input gives
-// bit-identical maps).
-__global__ __launch_bounds__(kPotThreads) void potes_input_grad_mask_abs_kernel(
-    const float* __restrict__ gh2, const uint8_t* __restrict__ m2, const uint8_t* __restrict__ s1,
-    const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ sabs, int B,
-    int bands, int T) {
-  constexpr int kDz2Row = kBwdNJ + 12;
-  __shared__ __align__(16) float dz2s[kC2 * kDz2Row];
-  __shared__ __align__(16) float dz1s[kC1 * kBwdNIpad];
-  const PotesDims d = potes_dims(T);
-  const int b = blockIdx.y, p0 = blockIdx.x * kInTP;
-  float s0 = 0.f, s1v = 0.f;
-  for (int band = 0; band < bands; ++band) {
-    float acc0, acc1;
-    input_grad_mask_tile(gh2, m2, s1, w1, w2, dz2s, dz1s, d, b * bands + band, p0, acc0, acc1);
-    s0 = __fadd_rn(s0, fabsf(acc0));
-    s1v = __fadd_rn(s1v, fabsf(acc1));
-  }
-  const int v0 = 2 * (int)threadIdx.x - 1, u = 4 * p0 + v0;
-  if (v0 < kInNU) {
-    float* dst = sabs + (size_t)b * T + u;
-    if (v0 >= 0 && u < T) dst[0] = s0;
-    if (v0 + 1 < kInNU && u + 1 < T) dst[1] = s1v;
-  }
-}
-
 
 // ---------------------------------------------------------------------------------- dimreduc
 // z[B][O] = h[B][K] . W[O][K]^T + bias for a SKINNY output (O <= 32; the Potes head is 19968 -> 20,
@@ -1617,22 +1570,6 @@ extern "C" int pcgmix_potes_stack_input_grad_mask_f32(const float* grad_h2, cons
   dim3 grid((unsigned)((T + kInNU - 1) / kInNU), (unsigned)N), block(kPotThreads);
   hipLaunchKernelGGL(potes_input_grad_mask_kernel, grid, block, 0,
                      reinterpret_cast<hipStream_t>(stream), grad_h2, m2, s1, w1, w2, grad_x, N, T);
-  return (int)hipGetLastError();
-}
-
-extern "C" int pcgmix_potes_stack_input_grad_mask_abssum_f32(const float* grad_h2, const uint8_t* m2,
-                                                             const uint8_t* s1, const float* w1,
-                                                             const float* w2, float* sabs, int B,
-                                                             int bands, int T,
-                                                             pcgmix_stream_t stream) {
-  using namespace pcgmix;
-  if (!grad_h2 || !m2 || !s1 || !w1 || !w2 || !sabs || B < 0 || bands <= 0 || bands > 64 ||
-      (long long)B * bands > 65535 || T < 14)
-    return hipErrorInvalidValue;
-  if (B == 0) return hipSuccess;
-  dim3 grid((unsigned)((T + kInNU - 1) / kInNU), (unsigned)B), block(kPotThreads);
-  hipLaunchKernelGGL(potes_input_grad_mask_abs_kernel, grid, block, 0,
-                     reinterpret_cast<hipStream_t>(stream), grad_h2, m2, s1, w1, w2, sabs, B, bands, T);
   return (int)hipGetLastError();
 }
 

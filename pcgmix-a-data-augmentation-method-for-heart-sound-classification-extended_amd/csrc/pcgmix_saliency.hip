@@ -88,24 +88,6 @@ __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
         if (i < a_len) a[i] = acc;
       }
     }
-  } else if (C == 1) {
-    // One channel (e.g. the |gradient| already summed over the bands by
-    // pcgmix_potes_stack_input_grad_mask_abssum_f32): eight loads per thread in flight together.
-    constexpr int kPer = 8;
-    for (int base = 0; base < a_len; base += kPer * kSalThreads) {
-      float v[kPer];
-#pragma unroll
-      for (int u = 0; u < kPer; ++u) {
-        const int t = base + u * kSalThreads + (int)threadIdx.x - half;
-        const bool in = t >= 0 && t < f4;
-        v[u] = in ? grad[(size_t)b * T + t] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < kPer; ++u) {
-        const int i = base + u * kSalThreads + (int)threadIdx.x;
-        if (i < a_len) a[i] = __fadd_rn(0.f, fabsf(v[u]));
-      }
-    }
   } else {
     for (int i = threadIdx.x; i < a_len; i += kSalThreads) {
       const int t = i - half;

@@ -152,34 +152,6 @@ class _PotesChain:
             self.h2.data_ptr(), self.m2.data_ptr(), self.s1.data_ptr(), self.N, T, None, 0, None, 0,
             stream), "pcgmix_potes_stack_fwd_save_f32")
 
-    def backward_abs(self, seed: torch.Tensor) -> torch.Tensor:
-        """As ``backward`` but returns sum_c |d/dx[b, c, t]| as a (B, 1, T) tensor — all the
-        saliency post-processing needs (saliency.py:63-70): the band channels of a sample are
-        accumulated inside the input-gradient kernel, 5 MB written instead of 20 MB and 5 MB read
-        by the post-processing instead of 20 MB; bit-identical maps."""
-        B, C, T = self.shape
-        self._head(seed)
-        w1, _b1, w2, _b2 = self._weights()
-        sabs = torch.empty((B, 1, T), dtype=torch.float32, device=seed.device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(seed.device).cuda_stream)
-        _lib.check(_lib.load().pcgmix_potes_stack_input_grad_mask_abssum_f32(
-            self.gfeat.data_ptr(), self.m2.data_ptr(), self.s1.data_ptr(), w1.data_ptr(), w2.data_ptr(),
-            sabs.data_ptr(), B, C, T, stream), "pcgmix_potes_stack_input_grad_mask_abssum_f32")
-        return sabs
-
-    def _head(self, seed: torch.Tensor) -> None:
-        B, C, T = self.shape
-        m, lib = self.m, _lib.load()
-        if seed.shape != (B, self.ncls) or seed.dtype != torch.float32 or not seed.is_contiguous():
-            raise ValueError("saliency seed does not match the model head")
-        W1, W2 = m.dimreduc.weight.detach().contiguous(), m.linear.weight.detach().contiguous()
-        bh = m.dimreduc.bias.detach() if m.dimreduc.bias is not None else None
-        stream = ctypes.c_void_p(torch.cuda.current_stream(seed.device).cuda_stream)
-        _lib.check(lib.pcgmix_potes_head_saliency_f32(
-            self.h2.data_ptr(), W1.data_ptr(), bh.data_ptr() if bh is not None else None, W2.data_ptr(),
-            seed.data_ptr(), self.partial.data_ptr(), self.dz.data_ptr(), self.gfeat.data_ptr(), B,
-            self.K, self.ncls, stream), "pcgmix_potes_head_saliency_f32")
-
     def backward(self, seed: torch.Tensor) -> torch.Tensor:
         B, C, T = self.shape
         m, lib = self.m, _lib.load()
@@ -294,7 +266,7 @@ class _SaliencyGraph:
             self.sal = self._run()
 
     def _run(self):
-        grad = self.chain.backward_abs(self.seed) if self.chain is not None \
+        grad = self.chain.backward(self.seed) if self.chain is not None \
             else input_gradient_seeded(self.model, self.x, self.seed)
         return saliency_post(grad, self.fr.data_ptr(), self.k)
 

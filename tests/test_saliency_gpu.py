@@ -519,27 +519,3 @@ def test_salopt_begin_with_host_labels_all_paths(device):
                                       host_labels=wrong)
     finally:
         saliency.set_saliency_model(None)
-
-
-def test_band_summed_input_gradient_gives_identical_maps(device):
-    """pcgmix_potes_stack_input_grad_mask_abssum_f32 (|dx| summed over the four band rows of a
-    sample inside the input-gradient kernel) + post-processing with C = 1  ==  the (B, 4, T)
-    gradient + post-processing with C = 4, bit for bit; and the summed gradient itself equals
-    ((|g0| + |g1|) + |g2|) + |g3| of the full one."""
-    from pcgmix_amd import synthetic
-    torch.manual_seed(3)
-    m = models.CNN_potes_TS(4, 2, "PhysioNet", sig_len=5000).to(device).eval()
-    for p in m.parameters():
-        p.requires_grad_(False)
-    for B, T in ((24, 5000), (7, 5000)):
-        x, frames, labels, _ = synthetic.make_batch(B, 4, T, sample_rate=2000, seed=60 + B)
-        data = torch.from_numpy(x).to(device)
-        seed = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).float().to(device)
-        chain = saliency._PotesChain(m, (B, 4, T), device)
-        chain.forward(data)
-        gx = chain.backward(seed)
-        sabs = chain.backward_abs(seed)
-        want = ((gx[:, 0].abs() + gx[:, 1].abs()) + gx[:, 2].abs()) + gx[:, 3].abs()
-        assert torch.equal(sabs[:, 0], want)
-        fr = torch.from_numpy(frames.astype(np.int32)).to(device)
-        assert torch.equal(saliency.saliency_post(sabs, fr.data_ptr()), saliency.saliency_post(gx, fr.data_ptr()))
