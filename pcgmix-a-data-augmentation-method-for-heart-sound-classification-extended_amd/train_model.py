@@ -561,8 +561,8 @@ class GraphedTrainStep:
                 for _ in range(3):
                     self.opt.zero_grad(set_to_none=True)
                     self._fwd_bwd()
-                if sync is not None:
-                    sync.attach()
+                if sync is not None and sync.params is None:    # once per sync: a second captured
+                    sync.attach()                               # step (PipelinedTrainStep) shares it
                 if self.adam_in_graph:
                     self.opt.prepare_capture([p for p in self.params if p.grad is not None])
         finally:
@@ -637,11 +637,24 @@ class GraphedTrainStep:
         self._pay_key[1] = z >> 32
 
     def step(self, batch, epoch, step_counter, stats: Optional[dict] = None):
+        """One training step: ``prepare`` (augmentation into the static input, payload) then
+        ``launch`` (replay, optimiser, scheduler, counters) on the current stream."""
+        self.prepare(batch, epoch, step_counter)
+        return self.launch(step_counter, stats)
+
+    def prepare(self, batch, epoch, step_counter):
+        """First half of a step, everything in front of the replay: the host image of the static
+        block (targets, dropout key, Adam scalars — read from generator / optimiser state as the
+        PREVIOUS step's ``launch`` left it, so prepare(k+1) must follow launch(k) on the host) and
+        the augmentation launches, which write this object's static input and ``aux`` on the
+        CURRENT stream.  ``PipelinedTrainStep`` runs it on a side stream for batch k+1 while the
+        graph of batch k replays."""
         from . import hostprep, _lib, saliency as _saliency
         data, target, frames, wav, _sq, _idx = batch
         if self.es is not None and epoch > self.es:
             raise NotImplementedError("SELC phase is not captured; use train_step")
         args = self.args
+        self._batch_size = int(data.shape[0])
         data = data.to(self.device, non_blocking=True)
         frames_np = augmentations._as_numpy_frames(frames)
         B, C, T = data.shape
@@ -699,6 +712,11 @@ class GraphedTrainStep:
         if plan.fired and plan.mix_all:                 # float blend of the one-hot rows
             t_ohe = F.one_hot(target, args.num_classes).to(self.device, non_blocking=True)
             self.t.copy_(augmentations.blend_targets(t_ohe, plan))
+
+    def launch(self, step_counter, stats: Optional[dict] = None):
+        """Second half: replay the captured forward + backward (+ update), the gradient all-reduce
+        and update graph under torch.distributed, scheduler, step counter, statistics."""
+        B = self._batch_size
         self.graph.replay()
         reseed_device_rng(self.args, self.device)
         if self.graph_update is not None:
@@ -720,6 +738,90 @@ class GraphedTrainStep:
                 stats["hits"] += (self.out.argmax(1) == truth).sum()
                 stats["seen"] += B
         return self.loss
+
+
+class PipelinedTrainStep:
+    """Two ``GraphedTrainStep`` slots over the same model / optimiser, used alternately so that the
+    augmentation of batch k+1 runs on a side stream WHILE the captured training graph of batch k
+    replays on the main stream.
+
+    The augmentation of a batch depends on that batch, its labels and the step count only
+    (train_model.py:507: ``augment(args, data, target_ohe, frames, wav, step_counter, ...)``), never
+    on the weights being trained — the saliency-guided methods use a FROZEN model
+    (saliency.py:26-51) — so it can run ahead by one batch without changing a single value; it is
+    the data-loader prefetch the reference does not have.  For BASELINE config 3 the augmentation
+    (frozen forward + input gradient + search + splice, ~160 us) is as long as the training graph
+    (~147 us) and both are issue/latency-bound kernels that leave the other room: measured
+    309 -> 225 us per step with the two on separate streams (profiles/probes/overlap_probe.py);
+    for the plain splice (10 us) the gain is 2 %.
+
+    Host order is unchanged — prepare(k+1) follows launch(k), so dropout keys, Adam scalars,
+    scheduler and step counter advance exactly as in the sequential loop — only the STREAM of the
+    augmentation launches differs.  Buffer hazards: slot s's static input / ``aux`` are rewritten
+    by prepare(k+2) only after the replay of batch k (same slot) has finished (event), and a replay
+    waits for its slot's prepare (event).
+
+        pipe = PipelinedTrainStep(args, model, opt, sched, crit, device, B, C, T, sync=...)
+        for batch, nxt in pipe.pairs(loader):           # or: pipe.step(batch, epoch, sc, stats, nxt)
+            pipe.step(batch, epoch, step_counter, stats, next_batch=nxt)
+    """
+
+    def __init__(self, *a, **kw):
+        self.slots = [GraphedTrainStep(*a, **kw), GraphedTrainStep(*a, **kw)]
+        self.device = self.slots[0].device
+        self.side = torch.cuda.Stream(self.device)
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]     # slot prepared (side stream)
+        self.done = [torch.cuda.Event(), torch.cuda.Event()]      # slot's replay finished (main stream)
+        self._fetched = torch.cuda.Event()
+        self.cur = 0
+        self.prepared = None            # id() of the batch already prepared into slot `cur`
+
+    @property
+    def loss(self):
+        return self.slots[self.cur ^ 1].loss          # the step that ran last
+
+    @staticmethod
+    def pairs(loader):
+        """(batch, next batch or None) over ``loader`` — the one-batch lookahead ``step`` wants."""
+        it = iter(loader)
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+        for nxt in it:
+            yield cur, nxt
+            cur = nxt
+        yield cur, None
+
+    def _prepare_on_side(self, slot, batch, epoch, step_counter, fetched):
+        self.side.wait_event(fetched)                   # the batch itself (loader gather, main stream)
+        self.side.wait_event(self.done[slot])           # the slot's previous replay has read its buffers
+        with torch.cuda.stream(self.side):
+            self.slots[slot].prepare(batch, epoch, step_counter)
+            self.ready[slot].record(self.side)
+        if batch[0].is_cuda:    # allocated on the main stream (loader gather), read on the side stream
+            batch[0].record_stream(self.side)
+
+    def step(self, batch, epoch, step_counter, stats: Optional[dict] = None, next_batch=None):
+        main = torch.cuda.current_stream(self.device)
+        s = self.cur
+        if next_batch is not None:
+            # next_batch exists already (the caller's lookahead fetched it before this call): mark the
+            # point on the main stream BEFORE this step's graph, so that the side stream waits for
+            # the batch and not for the graph it is meant to overlap
+            self._fetched.record(main)
+        if self.prepared != id(batch):                  # first step, or the caller gave no lookahead
+            self.slots[s].prepare(batch, epoch, step_counter)
+        else:
+            main.wait_event(self.ready[s])
+        self.prepared = None
+        loss = self.slots[s].launch(step_counter, stats)
+        self.done[s].record(main)
+        if next_batch is not None:
+            self._prepare_on_side(s ^ 1, next_batch, epoch, step_counter, self._fetched)
+            self.prepared = id(next_batch)
+        self.cur = s ^ 1
+        return loss
 
 
 def train_epoch(args, model, train_loader, device, optimizer, scheduler, criterion, epoch,
@@ -813,7 +915,7 @@ def test_data_accuracy(args, model, test_loader, device, criterion=None):
             "loss": float(loss_sum) / max(1, n) if criterion is not None else None}
 
 
-def train_model(args, dataset, device, use_graph: bool = True, log=print):
+def train_model(args, dataset, device, use_graph: bool = True, log=print, pipeline: bool = True):
     """The reference's run driver (train_model.py:197-488) reduced to the hot path: seeds (:216-223),
     loaders (:244-248), model (:293-386), criterion/optimiser/scheduler (:390-410), the epoch loop
     (:428-478) with evaluation at the reference's 11 "plot epochs", and ``model.pth`` written with the
@@ -868,9 +970,11 @@ def train_model(args, dataset, device, use_graph: bool = True, log=print):
     step_counter = step_counter_class()
     graphed = None
     if graphable:
-        graphed = GraphedTrainStep(args, model, optimizer, scheduler, criterion, device,
-                                   args.batch_size // world, args.num_channels, args.sig_len,
-                                   sync=FlatGradSync(model, device) if distributed else None)
+        # two captured slots: the augmentation of batch k+1 overlaps the training graph of batch k
+        cls = PipelinedTrainStep if pipeline else GraphedTrainStep
+        graphed = cls(args, model, optimizer, scheduler, criterion, device,
+                      args.batch_size // world, args.num_channels, args.sig_len,
+                      sync=FlatGradSync(model, device) if distributed else None)
     perf = {k: [] for k in ("epochs", "steps", "train_loss", "train_accuracy", "test_accuracy",
                             "test_loss", "test_sensitivity", "test_specificity", "test_f1",
                             "test_rocauc", "times")}
@@ -884,10 +988,13 @@ def train_model(args, dataset, device, use_graph: bool = True, log=print):
         stats = {"loss_sum": torch.zeros((), device=device),
                  "hits": torch.zeros((), device=device, dtype=torch.long), "seen": 0}
         n_batches = 0
-        for batch in train_loader:
-            if distributed:
-                batch = shard_batch(batch, rank, world)
-            if graphed is not None:
+        shard = (lambda b: shard_batch(b, rank, world)) if distributed else (lambda b: b)
+        pairs = PipelinedTrainStep.pairs(shard(b) for b in train_loader)
+        for batch, nxt in pairs:
+            if isinstance(graphed, PipelinedTrainStep):
+                last = not step_counter.count + 1 < args.num_steps        # :584-586 stops behind this one
+                graphed.step(batch, epoch, step_counter, stats, next_batch=None if last else nxt)
+            elif graphed is not None:
                 graphed.step(batch, epoch, step_counter, stats)
             else:
                 train_step(args, model, batch, device, optimizer, scheduler, criterion, epoch,

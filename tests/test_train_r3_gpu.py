@@ -381,3 +381,43 @@ def test_train_model_driver_on_spectrograms(device, tmp_path):
     assert perf["train_loss"][-1] < perf["train_loss"][0]
     import glob
     assert len(glob.glob(str(tmp_path / "*" / "model.pth"))) == 1
+
+
+@pytest.mark.parametrize("method", ["durmixmagwarp(0.2,4)+0.8", "(saloptenv)durmixmagwarp(0.2,4)"])
+def test_pipelined_step_is_bit_identical_to_the_sequential_one(method, device, tmp_path):
+    """PipelinedTrainStep (augmentation of batch k+1 on a side stream while the captured graph of
+    batch k replays; two slots) == GraphedTrainStep called batch after batch: same kernels, same
+    values, only the stream of the augmentation launches differs — every loss and every parameter
+    bit for bit over 7 steps (dropout ON: the keys advance in the same host order)."""
+    B, T = 32, 2500
+    batches = []
+    for i in range(7):
+        x, frames, labels, wav = synthetic.make_batch(B, 4, T, sample_rate=1000, seed=900 + i)
+        batches.append((torch.from_numpy(x).to(device), torch.from_numpy(labels), torch.from_numpy(frames),
+                        wav, torch.ones(B, dtype=torch.long), torch.arange(B)))
+    res = {}
+    for mode in ("sequential", "pipelined"):
+        args = TC.salopt_traj_args(str(tmp_path / mode))
+        args.method, args.batch_size, args.seed_fix = method, B, 4
+        _write_base_checkpoint(args)
+        torch.manual_seed(7)
+        net = tm.build_model(args).to(device).train()
+        opt, sched = tm.make_optimizer(args, net)
+        crit = tm.SELCLoss(np.zeros(B * 7, int), 2, es=args.num_epochs + 1, device=device)
+        sc = tm.step_counter_class()
+        torch.cuda.manual_seed(4)
+        cls = tm.PipelinedTrainStep if mode == "pipelined" else tm.GraphedTrainStep
+        g = cls(args, net, opt, sched, crit, device, B, 4, T)
+        losses = []
+        if mode == "pipelined":
+            for b, nxt in tm.PipelinedTrainStep.pairs(batches):
+                losses.append(g.step(b, 1, sc, None, next_batch=nxt).clone())
+        else:
+            for b in batches:
+                losses.append(g.step(b, 1, sc).clone())
+        torch.cuda.synchronize()
+        res[mode] = (torch.stack(losses).cpu(), [p.detach().cpu().clone() for p in net.parameters()])
+        assert sc.count == 7
+    assert torch.equal(res["sequential"][0], res["pipelined"][0]), (res["sequential"][0], res["pipelined"][0])
+    for a, b in zip(res["sequential"][1], res["pipelined"][1]):
+        assert torch.equal(a, b)
