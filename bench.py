@@ -342,13 +342,21 @@ def build_train_step(method, model_name, B, C, T, rate, device, total_steps, ran
     crit = tm.SELCLoss(labels, 2, es=args.num_epochs + 1, device=device)
     sc = tm.step_counter_class()
     if graphed:
-        g = tm.GraphedTrainStep(args, model, opt, sched, crit, device, B, C, T,
-                                sync=tm.FlatGradSync(model, device) if distributed else None)
-        step = lambda: g.step(batch, 0, sc)                                  # noqa: E731
+        # what train_model() runs: two captured slots, the augmentation of the next batch on a side
+        # stream while this batch's graph replays (PCGMIX_BENCH_NO_PIPELINE=1: one slot, for A/B)
+        if os.environ.get("PCGMIX_BENCH_NO_PIPELINE"):
+            g = tm.GraphedTrainStep(args, model, opt, sched, crit, device, B, C, T,
+                                    sync=tm.FlatGradSync(model, device) if distributed else None)
+            step = lambda: g.step(batch, 0, sc)                              # noqa: E731
+        else:
+            g = tm.PipelinedTrainStep(args, model, opt, sched, crit, device, B, C, T,
+                                      sync=tm.FlatGradSync(model, device) if distributed else None)
+            step = lambda: g.step(batch, 0, sc, None, next_batch=batch)      # noqa: E731
     else:
         step = lambda: tm.train_step(args, model, batch, device, opt, sched, crit, 0, sc)  # noqa: E731
     return step, {"model": model_name, "method": method, "batch_per_gpu": B, "shape": [B, C, T],
-                  "hipgraph": bool(graphed)}
+                  "hipgraph": bool(graphed),
+                  "pipelined": bool(graphed) and not os.environ.get("PCGMIX_BENCH_NO_PIPELINE")}
 
 
 def run_train_steps(step, info, steps, warmup, barrier, tag):
