@@ -342,9 +342,10 @@ def build_train_step(method, model_name, B, C, T, rate, device, total_steps, ran
     crit = tm.SELCLoss(labels, 2, es=args.num_epochs + 1, device=device)
     sc = tm.step_counter_class()
     if graphed:
-        # what train_model() runs: two captured slots, the augmentation of the next batch on a side
-        # stream while this batch's graph replays (PCGMIX_BENCH_NO_PIPELINE=1: one slot, for A/B)
-        if os.environ.get("PCGMIX_BENCH_NO_PIPELINE"):
+        # what train_model() runs: one captured slot; for the saliency-guided methods two, the
+        # augmentation of the next batch on a side stream while this batch's graph replays
+        # (PCGMIX_BENCH_NO_PIPELINE=1: one slot, for A/B)
+        if os.environ.get("PCGMIX_BENCH_NO_PIPELINE") or "(salopt" not in method:
             g = tm.GraphedTrainStep(args, model, opt, sched, crit, device, B, C, T,
                                     sync=tm.FlatGradSync(model, device) if distributed else None)
             step = lambda: g.step(batch, 0, sc)                              # noqa: E731
@@ -356,7 +357,8 @@ def build_train_step(method, model_name, B, C, T, rate, device, total_steps, ran
         step = lambda: tm.train_step(args, model, batch, device, opt, sched, crit, 0, sc)  # noqa: E731
     return step, {"model": model_name, "method": method, "batch_per_gpu": B, "shape": [B, C, T],
                   "hipgraph": bool(graphed),
-                  "pipelined": bool(graphed) and not os.environ.get("PCGMIX_BENCH_NO_PIPELINE")}
+                  "pipelined": bool(graphed) and "(salopt" in method
+                  and not os.environ.get("PCGMIX_BENCH_NO_PIPELINE")}
 
 
 def run_train_steps(step, info, steps, warmup, barrier, tag):

@@ -753,7 +753,8 @@ class PipelinedTrainStep:
     (frozen forward + input gradient + search + splice, ~160 us) is as long as the training graph
     (~147 us) and both are issue/latency-bound kernels that leave the other room: measured
     309 -> 225 us per step with the two on separate streams (profiles/probes/overlap_probe.py);
-    for the plain splice (10 us) the gain is 2 %.
+    for the plain splice (10 us) the cross-stream hand-overs cost more than the overlap gains
+    (148 -> 166 us), so ``train_model`` uses this class for the saliency-guided methods only.
 
     Host order is unchanged — prepare(k+1) follows launch(k), so dropout keys, Adam scalars,
     scheduler and step counter advance exactly as in the sequential loop — only the STREAM of the
@@ -970,8 +971,11 @@ def train_model(args, dataset, device, use_graph: bool = True, log=print, pipeli
     step_counter = step_counter_class()
     graphed = None
     if graphable:
-        # two captured slots: the augmentation of batch k+1 overlaps the training graph of batch k
-        cls = PipelinedTrainStep if pipeline else GraphedTrainStep
+        # Saliency-guided methods: two captured slots, the augmentation of batch k+1 (as long as the
+        # training graph itself) overlaps the graph of batch k: 297 -> 258 us per step.  For the plain
+        # splice (10 us) the cross-stream hand-overs cost more than the overlap gains (148 -> 166 us,
+        # profiles/r3_pipeline_ab.txt): one slot.
+        cls = PipelinedTrainStep if pipeline and "(salopt" in args.method else GraphedTrainStep
         graphed = cls(args, model, optimizer, scheduler, criterion, device,
                       args.batch_size // world, args.num_channels, args.sig_len,
                       sync=FlatGradSync(model, device) if distributed else None)
