@@ -421,3 +421,29 @@ def test_pipelined_step_is_bit_identical_to_the_sequential_one(method, device, t
     assert torch.equal(res["sequential"][0], res["pipelined"][0]), (res["sequential"][0], res["pipelined"][0])
     for a, b in zip(res["sequential"][1], res["pipelined"][1]):
         assert torch.equal(a, b)
+
+
+def test_train_model_driver_salopt_with_its_own_base_checkpoint(device, tmp_path):
+    """The reference's workflow for saliency-guided PCGmix end to end: a 'base' run writes
+    model.pth (train_model.py:481-482), the '(saloptenv)…' run of the same configuration loads it as
+    its frozen saliency model (saliency.py:26-51) — through ``train_model()``, which pipelines the
+    saliency-guided augmentation of batch k+1 with the captured graph of batch k.  Pipelined and
+    one-slot runs end with bit-identical parameters."""
+    from conftest import learnable_dataset
+    ds = learnable_dataset(n_rec=24)
+    def make(method):
+        return argparse.Namespace(dataset="PhysioNet", model="Potes", method=method, num_epochs=2,
+                                  batch_size=16, op="adam", use_sched=True, lr_max=0.003,
+                                  weight_decay=1e-4, grad_clip=0.1, seed=4, seed_data=1100001,
+                                  n_fraction=1.0, train_balance=True, num_classes=2, sample_rate=1000,
+                                  num_channels=4, valid=False, depth=0, EXPERIMENTS=str(tmp_path))
+    tm.train_model(make("base"), ds, device, log=None)
+    finals = []
+    for pipeline in (True, False):
+        saliency._LOADED.clear()
+        perf = tm.train_model(make("(saloptenv)durmixmagwarp(0.2,4)+0.8"), ds, device, log=None,
+                              pipeline=pipeline)
+        assert perf["steps"][-1] == 2 * (96 // 16) and all(np.isfinite(v) for v in perf["train_loss"])
+        finals.append([p.detach().cpu().clone() for p in perf["model"].parameters()])
+    for a, b in zip(*finals):
+        assert torch.equal(a, b)
