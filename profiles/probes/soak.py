@@ -52,4 +52,15 @@ step, info = bench.build_train_step("durratiomixup", "Potes", 256, 4, 5000, 2000
 loss = loop("captured train step", 30_000, step)
 print("final loss", float(loss))
 assert torch.isfinite(loss)
+# round 3: BASELINE config 3 as a training step — pipelined (two captured slots, the augmentation
+# of the next batch on a side stream), host labels, payload in the begin kernel's arguments
+torch.manual_seed(5)
+saliency.set_saliency_model(models.CNN_potes_TS(4, 2, "PhysioNet", sig_len=5000).to(dev))
+step3, info3 = bench.build_train_step("(saloptenv)durmixmagwarp(0.2,4)", "Potes", 256, 4, 5000, 2000, dev,
+                                      20_000, 0)
+assert info3["pipelined"]
+loss = loop("pipelined cfg3 train step", 10_000, step3)
+print("final loss", float(loss))
+assert torch.isfinite(loss)
+saliency.set_saliency_model(None)
 print("soak ok")
