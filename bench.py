@@ -138,7 +138,8 @@ def run_augment_steps(method, data, tgt, frames, wav, device, steps, warmup, bar
     # Heap settling (tens of ms of host-only work) comes BEFORE the warm-up: nothing but the
     # barrier sits between the last warm-up call and t0, so a 20-step region is steady state.
     settle_heap()
-    out = None      # (no settle_clocks here: measured, it does not change this host-bound leg)
+    settle_clocks(device)     # A/B on one box, four fresh processes each: 24.9 against 25.4 us per step
+    out = None
     for _ in range(warmup):
         # bound to `out` exactly as in the timed loop: while the previous output is still alive the
         # next call needs a SECOND 20 MB block from torch's caching allocator — with the result
@@ -768,8 +769,8 @@ def main():
                                f"({B},{C},{T}) float32 per GPU (BASELINE.json configs[1])",
                    "batch_per_gpu": B, "channels": C, "sig_len": T, "method": a.method,
                    "parallelism": f"dp{world}",
-                   "pre_settle": "heap collected + frozen before the W warm-up steps of every leg; train legs: plus 40 ms "
-                                 "of neutral GPU work (GEMM + streaming add) to reach loaded clocks first, see "
+                   "pre_settle": "before the W warm-up steps of every leg: heap collected + frozen, then 40 ms of "
+                                 "neutral GPU work (GEMM + streaming add) to reach loaded clocks, see "
                                  "bench.settle_clocks"},
         "roofline": roof,
         "call_trace": headline_trace,
