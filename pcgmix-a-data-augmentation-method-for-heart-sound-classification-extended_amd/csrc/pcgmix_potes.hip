@@ -376,6 +376,334 @@ __global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------- forward, MFMA
+// The same stack on the matrix cores (round 3).  A k5 convolution with 8 or 4 output channels is a
+// GEMM with a tiny N, which the block form v_mfma_f32_4x4x1_16b_f32 fits exactly: 16 independent
+// 4x4 outer products per instruction, D_b[i][j] += A_b[i] * B_b[j].  Operand map (probed on the
+// hardware, profiles/probes/mfma_f32_4x4_rate.hip): A lane 4b+i = row i of block b, B lane 4b+j =
+// column j, D lane 4b+j register i = element (i, j).  Here
+//     row    = a conv output POSITION  (lane L = 4b+i owns positions 8L .. 8L+7, one per accumulator r)
+//     column = an output CHANNEL       (lane&3 = channel; B = that channel's weight, one VGPR per tap)
+// so with the lane's 12-float input window xw[0..11] in registers (three conflict-free
+// ds_read_b128 from the even/odd float4 planes) the update for tap k and position offset r is
+//     D[r] = mfma(xw[r + k], w[k], D[r])
+// — no operand assembly at all (the VALU kernel spends about one v_mov per packed multiply-add on
+// it), 64 distinct LDS words feed 40 instructions, and the K = 1 form makes every accumulator an
+// in-order fmaf chain from the bias (exact f32: what a scalar loop over (ci, k) would give).
+// D[r] register i' of lane 4b+j is position 32b + 8i' + r of channel j: a lane ends up with 32
+// CONSECUTIVE positions of one channel, so ReLU + MaxPool(2) and the routing codes are in-lane.
+// Measured issue interval of this instruction: ~12 cycles (two passes + 4), 256 multiply-adds each,
+// i.e. 2/3 of the f32 peak when nothing else issues; VALU work between two of them costs ~7 cycles
+// extra on top of its own, so the matrix instructions are kept in runs of 40 or more.
+//
+// Block = 256 threads = one tile of kFwdTP = 252 pooled outputs of one row, as in the VALU kernel:
+// 504 conv2 positions fed by 508 a1 positions = 1016 conv1 positions.
+//   layer 1: wave w takes conv1 unit u = w >> 1 (512 positions, 8 per lane) and channel half
+//            h = w & 1: one run of 40 instructions on 8 independent accumulators; pooled values to
+//            the a1 rows in LDS (row pitch 516 floats = 16 B mod 256: the 16-byte stores of a
+//            quarter wave, 64 B apart per block and one row apart per channel, tile the banks);
+//   layer 2: wave w takes conv2 positions 128w .. 128w+127, two per lane (window = 6 floats, three
+//            ds_read_b64, conflict-free), 8 x 5 x 2 = 80 instructions; even and odd input channels
+//            accumulate separately (four independent chains) and are added at the end.  A lane ends
+//            with 4 consecutive pooled outputs of channel j: stores and the m2 byte as in the VALU
+//            kernel.
+// 480 matrix instructions per tile, 120 per wave.
+constexpr int kMfXE = 132 * 4;                  // x: even float4 plane (indices 0..128 used), floats
+constexpr int kMfXFloats = (132 + 128) * 4;     // + odd plane (0..127)
+constexpr int kMfXN = 1028;                     // generic path: staged samples (float4 index <= 256)
+constexpr int kMfAPitch = 516;                  // a1 row: positions 0..515
+
+__device__ __forceinline__ void mf_window(const float* planeE, const float* planeO, int g,
+                                          float (&w)[12]) {
+  const f4 a = *reinterpret_cast<const f4*>(planeE + 4 * g),
+           b = *reinterpret_cast<const f4*>(planeO + 4 * g),
+           c = *reinterpret_cast<const f4*>(planeE + 4 * g + 4);
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+  w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+}
+
+// The matrix instruction as inline assembly: the compiler's scheduler otherwise re-orders a run
+// (depth-first along one accumulator, results read out through v_accvgpr_read in between), which
+// turns 8 independent chains into dependent pairs with VALU instructions among them.  Volatile
+// statements keep their order; the accumulators stay in VGPRs.  The hazard recogniser does not
+// see an MFMA in an asm statement, so a run is bracketed by explicit wait states: mf_run_begin
+// after the VALU writes of the operands, mf_run_end before anything reads the accumulators
+// (a 2-pass XDL result needs 5; 16 are cheap next to a run of 40).
+__device__ __forceinline__ void mfma4(f4& acc, float a, float b) {
+  asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+// first tap of a chain: the accumulator starts from c (a bias quad, or the inline constant 0)
+__device__ __forceinline__ void mfma4_from(f4& acc, float a, float b, const f4& c) {
+  asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void mfma4_from0(f4& acc, float a, float b) {
+  asm volatile("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mf_run_begin() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 4");
+}
+__device__ __forceinline__ void mf_run_end() {
+  asm volatile("s_nop 7\n\ts_nop 7");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Persistent blocks: tile = item of a strided list (item -> row item / tiles, tile item % tiles);
+// the NEXT item's samples are requested from global memory into registers before the current
+// item's matrix work starts and go to LDS after it, so the load latency (the kernel's skeleton —
+// stage, barrier, compute, barrier, compute, store — used to run once per block: 13.5 us of the
+// 27 us VALU kernel) hides behind 120 matrix instructions per wave.
+struct MfStage {           // one thread's share of a tile's samples
+  f4 v;                    // aligned path: x[4 p0 - 4 + 4t .. +3]; generic path: elements t + 256 c,
+  float v4;                // c < 4, and c = 4
+};
+
+// Tile element e is x[4 p0 - 3 + e].  Elements 0 .. 1019 feed the 1016 conv1 positions whose
+// pooled values reach a kept output; the aligned path stages -1 .. 1022 (element -1 lands in the
+// even plane's padding), the rest of the planes is never initialised and only ever feeds matrix
+// rows (positions) that nobody keeps.
+__device__ __forceinline__ float mf_x_at(const float* __restrict__ xrow, int g, int T) {
+  const float val = xrow[g < 0 ? 0 : (g >= T ? T - 1 : g)];
+  return (g >= 0 && g < T) ? val : 0.f;
+}
+__device__ __forceinline__ void mf_stage_load(MfStage& st, const float* __restrict__ xrow, int p0,
+                                              int T, bool fast) {
+  const int t = threadIdx.x;
+  if (fast) {
+    // rows are 16-byte aligned and T % 4 == 0: a quad is wholly inside the row or wholly outside
+    const int g0 = 4 * p0 - 4 + 4 * t;
+    const int gc = g0 < 0 ? 0 : (g0 >= T ? T - 4 : g0);
+    const f4 v = *reinterpret_cast<const f4*>(xrow + gc);
+    const bool in = g0 >= 0 && g0 < T;
+    st.v = f4{in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f};
+  } else {
+    const int g = 4 * p0 - 3 + t;
+    st.v = f4{mf_x_at(xrow, g, T), mf_x_at(xrow, g + 256, T), mf_x_at(xrow, g + 512, T),
+              mf_x_at(xrow, g + 768, T)};
+    st.v4 = mf_x_at(xrow, g + 1024, T);
+  }
+}
+
+__device__ __forceinline__ void mf_put(float* xs, int e, float v) {   // tile element e -> planes
+  const int i = e >> 2;
+  xs[(i & 1) * kMfXE + 4 * (i >> 1) + (e & 3)] = v;
+}
+__device__ __forceinline__ void mf_stage_store(const MfStage& st, float* xs, bool fast) {
+  const int t = threadIdx.x;
+  if (fast) {
+    mf_put(xs, 4 * t - 1, st.v.x);
+    mf_put(xs, 4 * t, st.v.y);
+    mf_put(xs, 4 * t + 1, st.v.z);
+    mf_put(xs, 4 * t + 2, st.v.w);
+  } else {
+    mf_put(xs, t, st.v.x);
+    mf_put(xs, t + 256, st.v.y);
+    mf_put(xs, t + 512, st.v.z);
+    mf_put(xs, t + 768, st.v.w);
+    if (t + 1024 < kMfXN) mf_put(xs, t + 1024, st.v4);
+  }
+}
+
+// max(a, b, 0) in one instruction.  fmaxf(fmaxf(a, 0), fmaxf(b, 0)) compiles to three v_max_f32
+// plus a canonicalising v_max(x, x) per operand under the IEEE mode; the operands here are finite.
+__device__ __forceinline__ float relu_max2(float a, float b) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(kPotThreads, 4) void potes_fwd_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ h2,
+    uint8_t* __restrict__ m2, uint8_t* __restrict__ s1, int N, int T, uint4* __restrict__ rnd,
+    long long rnd_n16, const uint32_t* __restrict__ key, uint32_t key_lo, uint32_t key_hi) {
+  if (SAVE && rnd) {
+    const uint32_t k0 = key ? key[0] : key_lo, k1 = key ? key[1] : key_hi;
+    const long long stride = (long long)gridDim.x * kPotThreads;
+    for (long long i = (long long)blockIdx.x * kPotThreads + threadIdx.x; i < rnd_n16; i += stride) {
+      const uint32_t c = (uint32_t)i * 4u;
+      rnd[i] = make_uint4(counter_hash(c, k0, k1), counter_hash(c + 1, k0, k1),
+                          counter_hash(c + 2, k0, k1), counter_hash(c + 3, k0, k1));
+    }
+  }
+  __shared__ __align__(16) float xs[kMfXFloats];
+  __shared__ __align__(16) float a1s[kC1 * kMfAPitch];
+  const PotesDims d = potes_dims(T);
+  const int tiles = (d.P2 + kFwdTP - 1) / kFwdTP, items = N * tiles;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int blk = lane >> 2, j = lane & 3;
+  const int u = wave >> 1, h = wave & 1;
+  const bool fast = !(T & 3) && !(reinterpret_cast<uintptr_t>(x) & 15);
+  // this lane's B operands: channel j + 4h of layer 1, channel j of layer 2
+  float wb1[kK], wb2[kC1][kK];
+#pragma unroll
+  for (int k = 0; k < kK; ++k) wb1[k] = w1[(j + 4 * h) * kK + k];
+#pragma unroll
+  for (int ci = 0; ci < kC1; ++ci)
+#pragma unroll
+    for (int k = 0; k < kK; ++k) wb2[ci][k] = w2[(j * kC1 + ci) * kK + k];
+  const float bias1 = b1[j + 4 * h], bias2 = b2[j];
+  const f4 bias1q = {bias1, bias1, bias1, bias1}, bias2q = {bias2, bias2, bias2, bias2};
+  // positions 512 .. 515 of every a1 row are read (by conv2 positions nobody keeps), never written
+  if (threadIdx.x < kC1) *reinterpret_cast<f4*>(a1s + threadIdx.x * kMfAPitch + 512) = f4{0.f, 0.f, 0.f, 0.f};
+  const int s1row = potes_s1_row_bytes(d), m2row = (d.P2 + 3) / 4;
+
+  int item = blockIdx.x;
+  MfStage st;
+  st.v = f4{0.f, 0.f, 0.f, 0.f};
+  st.v4 = 0.f;
+  if (item < items) mf_stage_load(st, x + (size_t)(item / tiles) * T, (item % tiles) * kFwdTP, T, fast);
+  for (; item < items; item += gridDim.x) {
+    const int n = item / tiles, p0 = (item - n * tiles) * kFwdTP;
+    const int qlo = 2 * p0 - 1;
+    mf_stage_store(st, xs, fast);
+    __syncthreads();
+    {
+      const int nxt = item + gridDim.x;
+      if (nxt < items) mf_stage_load(st, x + (size_t)(nxt / tiles) * T, (nxt % tiles) * kFwdTP, T, fast);
+    }
+    // ---- layer 1: conv1 positions 512u + 8 lane + r of channel j + 4h.  The lane's 16 pooled
+    // values are a1 positions 256u + 16 blk + 4 i + t (t <-> accumulators 2t, 2t+1).
+    {
+      float xw[12];
+      mf_window(xs, xs + kMfXE, 64 * u + lane, xw);
+      f4 acc[8];
+      mf_run_begin();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) mfma4_from(acc[r], xw[r], wb1[0], bias1q);
+#pragma unroll
+      for (int k = 1; k < kK; ++k)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) mfma4(acc[r], xw[r + k], wb1[k]);
+      mf_run_end();
+      const int qq0 = 256 * u + 16 * blk, qb = qlo + qq0;
+      const bool edge = qlo + 256 * u < 0 || qlo + 256 * u + 256 > d.P1;   // wave-uniform
+      float* arow = a1s + (j + 4 * h) * kMfAPitch + qq0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f4 out;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) out[t] = relu_max2(acc[2 * t][i], acc[2 * t + 1][i]);
+        if (edge) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int q = qb + 4 * i + t;
+            out[t] = (q >= 0 && q < d.P1) ? out[t] : 0.f;
+          }
+        }
+        *reinterpret_cast<f4*>(arow + 4 * i) = out;
+      }
+      if (SAVE && s1) {
+        // packed selectors (layer1_t): position q in bits 2*((q+1)&3) of byte (q+1)>>2; q + 1 =
+        // 2 p0 + 4 g + t with g = 64u + 4 blk + i, so a float4 group is exactly byte p0/2 + g and
+        // the lane's four groups are four consecutive bytes: one (unaligned) 32-bit store.
+        uint32_t sel4 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            // relu_pool2's rule: 2 if the second candidate's ReLU is strictly larger, else 1 if the
+            // first survives its ReLU, else 0; 0 outside [0, P1)
+            const float za = acc[2 * t][i], zb = acc[2 * t + 1][i];
+            uint32_t sc = (zb > za && zb > 0.f) ? 2u : (za > 0.f ? 1u : 0u);
+            if (edge) {
+              const int q = qb + 4 * i + t;
+              sc = (q >= 0 && q < d.P1) ? sc : 0u;
+            }
+            sel4 |= sc << (8 * i + 2 * t);
+          }
+        uint8_t* row = s1 + ((size_t)n * kC1 + j + 4 * h) * s1row;
+        const int g0 = 64 * u + 4 * blk, bi0 = (p0 >> 1) + g0;
+        if (g0 + 3 < kFwdNQ / 4 && bi0 + 3 < s1row) {
+          typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+          *reinterpret_cast<u32_unaligned*>(row + bi0) = sel4;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (g0 + i < kFwdNQ / 4 && bi0 + i < s1row) row[bi0 + i] = (uint8_t)(sel4 >> (8 * i));
+        }
+      }
+    }
+    __syncthreads();
+    // ---- layer 2: conv2 positions 128 wave + 2 lane + r of channel j
+    f4 acc2[2][2];
+    {
+      // channel pairs: the next pair's windows are requested before the current run of 20
+      float aw[2][2][6];
+      const float* abase = a1s + 128 * wave + 2 * lane;
+      auto window = [&](int ci, float (&w)[6]) {
+        const f2 a = *reinterpret_cast<const f2*>(abase + ci * kMfAPitch),
+                 b = *reinterpret_cast<const f2*>(abase + ci * kMfAPitch + 2),
+                 c = *reinterpret_cast<const f2*>(abase + ci * kMfAPitch + 4);
+        w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y; w[4] = c.x; w[5] = c.y;
+      };
+      window(0, aw[0][0]);
+      window(1, aw[0][1]);
+#pragma unroll
+      for (int cp = 0; cp < kC1; cp += 2) {
+        const int cur = (cp >> 1) & 1;
+        if (cp + 2 < kC1) {
+          window(cp + 2, aw[cur ^ 1][0]);
+          window(cp + 3, aw[cur ^ 1][1]);
+        }
+        mf_run_begin();
+#pragma unroll
+        for (int k = 0; k < kK; ++k)
+#pragma unroll
+          for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+              if (cp == 0 && k == 0) {             // the chains start: bias on the even channels
+                if (par == 0) mfma4_from(acc2[0][r], aw[cur][0][r], wb2[0][0], bias2q);
+                else mfma4_from0(acc2[1][r], aw[cur][1][r], wb2[1][0]);
+              } else {
+                mfma4(acc2[par][r], aw[cur][par][r + k], wb2[cp + par][k]);
+              }
+            }
+        mf_run_end();
+      }
+    }
+    // register i of acc2[.][r] is conv2 position 128 wave + 8 blk + 2 i + r: pooled output
+    // pp = 64 wave + 4 blk + i  (r = 0, 1 are its two candidates)
+    const int pp = 64 * wave + 4 * blk, p = p0 + pp;
+    f4 o;
+    uint32_t code = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // relu_pool2's rule: 2 if the second candidate's ReLU is strictly larger, else 1 if the
+      // first survives its ReLU, else 0
+      const float za = acc2[0][0][i] + acc2[1][0][i], zb = acc2[0][1][i] + acc2[1][1][i];
+      o[i] = relu_max2(za, zb);
+      if (SAVE) code |= ((zb > za && zb > 0.f) ? 2u : (za > 0.f ? 1u : 0u)) << (2 * i);
+    }
+    if (pp < kFwdTP) {                               // else: outputs owned by the next tile
+      float* dst = h2 + ((size_t)n * kC2 + j) * d.P2 + p;
+      uint8_t* mdst = m2 + ((size_t)n * kC2 + j) * m2row + (p >> 2);
+      if (p0 + kFwdTP <= d.P2) {                     // tile wholly inside the row (block-uniform)
+        if (SAVE) *mdst = (uint8_t)code;
+        if ((d.P2 & 3) == 0) {
+          *reinterpret_cast<f4*>(dst) = o;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dst[i] = o[i];
+        }
+      } else {
+        if (SAVE && p < d.P2) {
+          uint32_t keep = 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (p + i < d.P2) keep |= 3u << (2 * i);
+          *mdst = (uint8_t)(code & keep);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (p + i < d.P2) dst[i] = o[i];
+      }
+    }
+  }
+}
+
 // Sum over the 64 lanes of a wave on the VALU alone (DPP: no LDS traffic), total in lane 63.
 // quad swaps, half-row and row mirrors leave every lane of a row with the row's sum; row_bcast15 /
 // row_bcast31 carry it across the four rows.  The kernel-end reduction of the backward's 53
@@ -1468,6 +1796,23 @@ extern "C" int pcgmix_potes_bwd_blocks(int N, int T) {
   return (int)(work < cap ? work : cap);
 }
 
+// The forward runs on the matrix cores unless PCGMIX_POTES_FWD_VALU=1 (A/B runs).
+static bool potes_fwd_use_mfma() {
+  static const bool on = getenv("PCGMIX_POTES_FWD_VALU") == nullptr;
+  return on;
+}
+
+// Persistent blocks of the matrix-core forward: four per CU (128 VGPRs), tiles handed out by stride.
+static unsigned potes_fwd_mfma_blocks(int N, const pcgmix::PotesDims& d) {
+  const long long items = (long long)N * ((d.P2 + pcgmix::kFwdTP - 1) / pcgmix::kFwdTP);
+  long long cap = 4 * 256;
+  if (const char* env = getenv("PCGMIX_POTES_FWD_BLOCKS")) {   // tuning runs
+    const long long v = atoll(env);
+    if (v >= 1 && v <= (1 << 20)) cap = v;
+  }
+  return (unsigned)(items < cap ? items : cap);
+}
+
 extern "C" int pcgmix_potes_stack_fwd_f32(const float* x, const float* w1, const float* b1,
                                           const float* w2, const float* b2, float* h2, int N, int T,
                                           pcgmix_stream_t stream) {
@@ -1476,6 +1821,12 @@ extern "C" int pcgmix_potes_stack_fwd_f32(const float* x, const float* w1, const
     return hipErrorInvalidValue;
   if (N == 0) return hipSuccess;
   const PotesDims d = potes_dims(T);
+  if (potes_fwd_use_mfma()) {
+    hipLaunchKernelGGL(potes_fwd_mfma_kernel<false>, dim3(potes_fwd_mfma_blocks(N, d)),
+                       dim3(kPotThreads), 0, reinterpret_cast<hipStream_t>(stream), x, w1, b1, w2, b2, h2,
+                       nullptr, nullptr, N, T, nullptr, 0ll, nullptr, 0u, 0u);
+    return (int)hipGetLastError();
+  }
   dim3 grid((unsigned)((d.P2 + kFwdTP - 1) / kFwdTP), (unsigned)N), block(kPotThreads);
   hipLaunchKernelGGL(potes_fwd_kernel<false>, grid, block, 0, reinterpret_cast<hipStream_t>(stream),
                      x, w1, b1, w2, b2, h2, nullptr, nullptr, N, T, nullptr, 0ll, nullptr, 0u, 0u);
@@ -1503,6 +1854,13 @@ extern "C" int pcgmix_potes_stack_fwd_save_f32(const float* x, const float* w1, 
     return hipErrorInvalidValue;
   if (N == 0) return hipSuccess;
   const PotesDims d = potes_dims(T);
+  if (potes_fwd_use_mfma()) {
+    hipLaunchKernelGGL(potes_fwd_mfma_kernel<true>, dim3(potes_fwd_mfma_blocks(N, d)),
+                       dim3(kPotThreads), 0, reinterpret_cast<hipStream_t>(stream), x, w1, b1, w2, b2, h2, m2, s1, N, T,
+                       reinterpret_cast<uint4*>(rnd_out), rnd_out ? rnd_bytes / 16 : 0ll, key_dev,
+                       (uint32_t)key, (uint32_t)(key >> 32));
+    return (int)hipGetLastError();
+  }
   dim3 grid((unsigned)((d.P2 + kFwdTP - 1) / kFwdTP), (unsigned)N), block(kPotThreads);
   hipLaunchKernelGGL(potes_fwd_kernel<true>, grid, block, 0, reinterpret_cast<hipStream_t>(stream),
                      x, w1, b1, w2, b2, h2, m2, s1, N, T, reinterpret_cast<uint4*>(rnd_out),
