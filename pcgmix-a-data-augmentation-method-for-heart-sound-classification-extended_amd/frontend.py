@@ -126,29 +126,33 @@ def recording_plan(lengths, boundaries, seg_starts, hop: int, width: int, tile_f
     ``frames_spec = round(f * n_frames / len(y))`` with Python's round-half-even, cell 6:101."""
     rec_off, tiles, cycles, fspec, rec_of = [], [], [], [], []
     off = col = 0
-    for r, n in enumerate(lengths):
+    five = np.arange(5, dtype=np.int64)
+    for r, n in enumerate(lengths):                 # numpy per recording: O(recordings) Python steps
         n = int(n)
         n_frames = 1 + n // hop
         rec_off.append(off)
-        for f0 in range(0, n_frames, tile_frames):
-            tiles.append((r, f0, min(tile_frames, n_frames - f0), col + f0))
+        f0 = np.arange(0, n_frames, tile_frames, dtype=np.int64)
+        tiles.append(np.stack([np.full_like(f0, r), f0, np.minimum(tile_frames, n_frames - f0), col + f0], 1))
         b = np.asarray(boundaries[r], dtype=np.int64)
         cols = np.rint(b * n_frames / float(n)).astype(np.int64)          # cell 6:101
-        for i in seg_starts[r]:
-            c = cols[i:i + 5]
-            keep = int(min(max(c[4] - c[0], 0), width, n_frames - c[0]))
-            cycles.append((r, col + int(c[0]), max(keep, 0), 0))
-            fspec.append(c - c[0])                                         # cell 6:130
-            rec_of.append(r)
+        st = np.asarray(seg_starts[r], dtype=np.int64).reshape(-1)
+        if st.size:
+            c = cols[st[:, None] + five]                                   # (cycles, 5)
+            keep = np.minimum(np.minimum(np.maximum(c[:, 4] - c[:, 0], 0), width), n_frames - c[:, 0])
+            cycles.append(np.stack([np.full_like(keep, r), col + c[:, 0], np.maximum(keep, 0),
+                                    np.zeros_like(keep)], 1))
+            fspec.append(c - c[:, :1])                                     # cell 6:130
+            rec_of.append(np.full(st.size, r, dtype=np.int64))
         off += n
         col += n_frames
+    cat = lambda parts, width_: (np.concatenate(parts) if parts else np.zeros((0, width_), np.int64))
     return {"rec_off": np.asarray(rec_off, dtype=np.int64),
             "rec_len": np.asarray(lengths, dtype=np.int32),
-            "tiles": np.asarray(tiles, dtype=np.int32).reshape(-1, 4),
-            "cycles": np.asarray(cycles, dtype=np.int32).reshape(-1, 4),
+            "tiles": cat(tiles, 4).astype(np.int32).reshape(-1, 4),
+            "cycles": cat(cycles, 4).astype(np.int32).reshape(-1, 4),
             "scratch_cols": int(col),
-            "frames_spec": np.asarray(fspec, dtype=np.int64).reshape(-1, 5),
-            "rec_of_cycle": np.asarray(rec_of, dtype=np.int64)}
+            "frames_spec": cat(fspec, 5).astype(np.int64).reshape(-1, 5),
+            "rec_of_cycle": (np.concatenate(rec_of) if rec_of else np.zeros(0, np.int64))}
 
 
 def logmel_recordings(y: torch.Tensor, lengths, boundaries, seg_starts, sample_rate: int = 2000,
