@@ -198,3 +198,51 @@ def test_plain_recipe_selects_the_one_call_path():
     assert H.plain_recipe("base", False) is None and H.plain_recipe("base", True) is None
     assert H.plain_recipe("(alpha=0.4)durratiomixup", True) == ("durratiomixup", 1.0, 1.0, 0.0, 0)
     assert H.plain_recipe("durmixcutout(0.2,0.2)", True) is None
+
+
+def _recording_plan_loop(lengths, boundaries, seg_starts, hop, width, tile_frames):
+    """databuilder.ipynb cell 6:93-101, 127-134 as a plain loop per tile and per cycle — the checker
+    for the vectorised ``frontend.recording_plan``."""
+    rec_off, tiles, cycles, fspec, rec_of = [], [], [], [], []
+    off = col = 0
+    for r, n in enumerate(lengths):
+        n = int(n)
+        n_frames = 1 + n // hop
+        rec_off.append(off)
+        for f0 in range(0, n_frames, tile_frames):
+            tiles.append((r, f0, min(tile_frames, n_frames - f0), col + f0))
+        b = np.asarray(boundaries[r], dtype=np.int64)
+        cols = [int(round(float(v) * n_frames / float(n))) for v in b]      # Python round: half-even
+        for i in seg_starts[r]:
+            c = cols[i:i + 5]
+            keep = max(min(max(c[4] - c[0], 0), width, n_frames - c[0]), 0)
+            cycles.append((r, col + c[0], keep, 0))
+            fspec.append([v - c[0] for v in c])
+            rec_of.append(r)
+        off += n
+        col += n_frames
+    return rec_off, tiles, cycles, fspec, rec_of, col
+
+
+def test_recording_plan_matches_loop_restatement():
+    from pcgmix_amd import frontend
+    rng = np.random.default_rng(3)
+    lengths = rng.integers(3000, 90000, 40)
+    bounds, starts = [], []
+    for k, n in enumerate(lengths):
+        b = np.cumsum(rng.integers(250, 550, 300))
+        b = b[b < n - 200]
+        bounds.append(b)
+        starts.append([] if k % 7 == 3 else list(range(0, max(len(b) - 4, 0), 4)))
+    plan = frontend.recording_plan(lengths, bounds, starts, 34, 128, 128)
+    rec_off, tiles, cycles, fspec, rec_of, col = _recording_plan_loop(lengths, bounds, starts, 34, 128, 128)
+    assert plan["scratch_cols"] == col
+    assert np.array_equal(plan["rec_off"], np.asarray(rec_off, dtype=np.int64))
+    assert np.array_equal(plan["tiles"], np.asarray(tiles, dtype=np.int32).reshape(-1, 4))
+    assert np.array_equal(plan["cycles"], np.asarray(cycles, dtype=np.int32).reshape(-1, 4))
+    assert np.array_equal(plan["frames_spec"], np.asarray(fspec, dtype=np.int64).reshape(-1, 5))
+    assert np.array_equal(plan["rec_of_cycle"], np.asarray(rec_of, dtype=np.int64))
+    assert plan["tiles"].dtype == np.int32 and plan["cycles"].dtype == np.int32
+    # no cycles at all: empty, correctly shaped tables
+    empty = frontend.recording_plan([5000], [np.asarray([100, 600, 1100])], [[]], 34, 128, 128)
+    assert empty["cycles"].shape == (0, 4) and empty["frames_spec"].shape == (0, 5) and empty["rec_of_cycle"].shape == (0,)
