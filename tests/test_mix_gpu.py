@@ -301,3 +301,52 @@ def test_kernarg_splice_equals_the_copy_path(B, C, T, device):
                                    ctypes.c_float(lam), 257, C, T, st) != 0
     assert lib.pcgmix_mix_karg_f32(data.data_ptr(), out.data_ptr(), fr16.ctypes.data, mx16.ctypes.data,
                                    ctypes.c_float(lam), B, C, T - 1, st) != 0       # T % 4
+
+
+def _random_frames(rs, B, T):
+    """Monotone boundaries 0 = f0 <= f1 <= f2 <= f3 <= f4 <= T per row, ragged: cycle lengths from a
+    few samples to the whole row, some states empty."""
+    f = np.zeros((B, 5), dtype=np.int64)
+    for b in range(B):
+        end = int(rs.randint(4, T + 1)) if rs.rand() > 0.1 else T
+        cuts = np.sort(rs.randint(0, end + 1, 3))
+        if rs.rand() < 0.15:
+            cuts[rs.randint(0, 3)] = cuts[rs.randint(0, 3)]          # an empty state now and then
+            cuts = np.sort(cuts)
+        f[b] = [0, cuts[0], cuts[1], cuts[2], end]
+    return f
+
+
+_FUZZ_METHODS = ["durratiomixup", "durratiomixup+0.7", "(alpha=0.5)durratiomixup", "(rand)durratiomixup",
+                 "durmixmagwarp(0.2,4)", "durmixmagwarp(0.05,7)+0.8", "(rand)durmixmagwarp(0.1,3)",
+                 "(alpha=2.0)durmixmagwarp(0.3,2)", "(mixAll)durmixmagwarp(0.3,5)", "(mixAll)durratiomixup",
+                 "(samePCG)durratiomixup", "(sameDataset)durmixmagwarp(0.2,4)"]
+
+
+@pytest.mark.parametrize("case", range(36))
+def test_random_cases_against_oracle(case, device):
+    """Seeded differential test: random batch size, channel count, row length (odd and even, the
+    vector and the scalar kernel), ragged cycles, label mix, recording ids, step and method string
+    of the grammar the reference parses; partner indices and targets exact, the splice bit-exact,
+    the warped waveform within the north_star tolerance; a rejected gate returns the input object."""
+    rs = np.random.RandomState(1000 + case)
+    B = int(rs.choice([1, 2, 3, 5, 8, 13, 32, 57]))
+    C = int(rs.choice([1, 2, 4]))
+    T = int(rs.choice([64, 130, 333, 512, 1001, 1400, 2500]))
+    method = _FUZZ_METHODS[case % len(_FUZZ_METHODS)]
+    step = int(rs.randint(0, 5000))
+    x = rs.standard_normal((B, C, T)).astype(np.float32)
+    frames = _random_frames(rs, B, T)
+    labels = rs.randint(0, 2, B).astype(np.int64)
+    wav = tuple(f"{'abcdef'[rs.randint(0, 6)]}{rs.randint(0, 4):04d}" for _ in range(B))
+    ref = O.augment(method, x, labels, frames, wav, step)
+    g = dict(x=x, labels=labels, frames=frames, wav=wav, step=step, method=method)
+    data, tgt, (y, t_out, mix, _) = run(augmentations, g, device)
+    if not ref["fired"]:
+        assert y is data and t_out is tgt and len(mix) == 0
+        return
+    assert np.array_equal(np.asarray(mix), ref["mix"])
+    assert np.array_equal(t_out.cpu().numpy().astype(np.float64), ref["target"].astype(np.float64)) \
+        if "(mixAll)" not in method else np.allclose(t_out.cpu().numpy(), ref["target"], rtol=0, atol=1e-7)
+    err = np.abs(y.cpu().numpy() - ref["y"]).max() if B else 0.0
+    assert err <= (WAVE_TOL if "magwarp" in method else 0.0), (method, (B, C, T), err)

@@ -208,3 +208,36 @@ def test_forward_fills_dropout_bytes(key_on_device, device):
     assert (_counter_hash(4096, 1) != _counter_hash(4096, 2)).mean() > 0.99
     with pytest.raises(RuntimeError):                       # not a multiple of 16 bytes
         forward(torch.zeros(24, dtype=torch.uint8, device=device), 1)
+
+
+@pytest.mark.parametrize("T", [5000, 1036])
+def test_forward_staging_paths_agree(T, device):
+    """The matrix-core forward stages a tile with aligned 16-byte loads when the rows are 16-byte
+    aligned (T % 4 == 0 and an aligned base) and with 4-byte loads otherwise: the same rows at a
+    base shifted by one float must give bit-identical activations and routing bytes (m2, s1)."""
+    import ctypes
+    from pcgmix_amd import _lib
+    lib = _lib.load()
+    N = 24
+    m = make(T, device, seed=6).eval()
+    c1, c2 = m.cnn1[0][0], m.cnn1[1][0]
+    buf = torch.randn(N * T + 1, device=device)
+    x_al = buf[:N * T].clone()                       # 16-byte aligned base (fresh allocation)
+    x_un = buf[1:]                                   # the same layout 4 bytes off an aligned base
+    x_un.copy_(x_al)
+    assert x_al.data_ptr() % 16 == 0 and x_un.data_ptr() % 16 == 4
+    P2 = lib.pcgmix_potes_out_len(T)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    out = []
+    for x in (x_al, x_un):
+        h2 = torch.empty(N, 4, P2, device=device)
+        m2 = torch.zeros(lib.pcgmix_potes_mask_bytes(N, T, 2), dtype=torch.uint8, device=device)
+        s1 = torch.zeros(lib.pcgmix_potes_mask_bytes(N, T, 1), dtype=torch.uint8, device=device)
+        _lib.check(lib.pcgmix_potes_stack_fwd_save_f32(
+            x.data_ptr(), c1.weight.data_ptr(), c1.bias.data_ptr(), c2.weight.data_ptr(),
+            c2.bias.data_ptr(), h2.data_ptr(), m2.data_ptr(), s1.data_ptr(), N, T, None, 0, None, 0, st), "fwd")
+        out.append((h2, m2, s1))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    ref = m.cnn1(x_al.reshape(N, 1, T))
+    assert torch.allclose(out[0][0], ref, rtol=1e-4, atol=1e-5)
