@@ -350,3 +350,32 @@ def test_random_cases_against_oracle(case, device):
         if "(mixAll)" not in method else np.allclose(t_out.cpu().numpy(), ref["target"], rtol=0, atol=1e-7)
     err = np.abs(y.cpu().numpy() - ref["y"]).max() if B else 0.0
     assert err <= (WAVE_TOL if "magwarp" in method else 0.0), (method, (B, C, T), err)
+
+
+_FUZZ_METHODS_2D = ["durratiomixup", "durratiomixup+0.6", "durmixcutout(0.4,0.3)", "durmixcutout(0.9,1.0)+0.9",
+                    "durmixtimemask(0.5)", "durmixtimemask", "durmixfreqmask(0.25)", "durmixfreqmask"]
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_random_2d_cases_against_oracle(case, device):
+    """The same differential test for the spectrogram path (augmentations2d.py:286-427): random
+    (B,1,F,W) images — W a multiple of four or not —, ragged column boundaries, mask variants with
+    and without parameters and gates; everything bit-exact (splice and zeroed rectangles)."""
+    rs = np.random.RandomState(2000 + case)
+    B = int(rs.choice([1, 2, 5, 16, 37]))
+    F = int(rs.choice([16, 40, 128]))
+    W = int(rs.choice([32, 75, 128, 130]))
+    method = _FUZZ_METHODS_2D[case % len(_FUZZ_METHODS_2D)]
+    step = int(rs.randint(0, 5000))
+    x = rs.standard_normal((B, 1, F, W)).astype(np.float32)
+    frames = _random_frames(rs, B, W)
+    labels = rs.randint(0, 2, B).astype(np.int64)
+    wav = tuple(f"a{rs.randint(0, 9):04d}" for _ in range(B))
+    ref = O.augment(method, x, labels, frames, wav, step)
+    g = dict(x=x, labels=labels, frames=frames, wav=wav, step=step, method=method)
+    data, tgt, (y, t_out, mix, _) = run(augmentations2d, g, device)
+    if not ref["fired"]:
+        assert y is data and t_out is tgt and len(mix) == 0
+        return
+    assert np.array_equal(np.asarray(mix), ref["mix"])
+    assert np.array_equal(y.cpu().numpy(), ref["y"]), (method, (B, F, W))
