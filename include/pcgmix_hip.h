@@ -283,7 +283,10 @@ int pcgmix_logmel_recordings_f32(const float* y, const int64_t* rec_off, const i
  *   pcgmix_potes_stack_input_grad_f32   x, dL/dh2 -> dL/dx (N,T): what saliency.py:52-61 needs
  *                                  (the class score differentiated w.r.t. the input); also
  *                                  recomputes the forward, keeps nothing from it.
- * All pointers device; float32.
+ * All pointers device; float32.  Both forwards run on the f32 matrix cores
+ * (v_mfma_f32_4x4x1_16b_f32: every output is an in-order fmaf chain from the bias over (input
+ * channel, tap) — exact f32); the recomputing backward kernels and the layer-1 recompute of the
+ * mask-based weight gradient use a VALU summation order and agree with it to float rounding.
  */
 int pcgmix_potes_out_len(int T);
 int pcgmix_potes_bwd_blocks(int N, int T);
