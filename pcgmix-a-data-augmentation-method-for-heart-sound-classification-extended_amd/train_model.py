@@ -825,18 +825,79 @@ class PipelinedTrainStep:
         return loss
 
 
+def _no_epoch_step():
+    return None
+
+
+class _EpochStep:
+    """(key, captured step) kept on the model by ``train_epoch``.  A copy or a pickle of the model
+    must not drag the graph along: both see ``None`` in its place."""
+    __slots__ = ("key", "step")
+
+    def __init__(self, key, step):
+        self.key, self.step = key, step
+
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_no_epoch_step, ())
+
+
+def _epoch_graphed_step(args, model, optimizer, scheduler, criterion, device, epoch, batch):
+    """The captured step ``train_epoch`` replays instead of calling ``train_step``, or None when
+    the step has to stay eager.  A caller of the reference's ``train_epoch`` hands over exactly
+    what ``GraphedTrainStep`` needs; the graph is built at the first batch and kept for as long as
+    model, optimiser, scheduler, criterion, method and batch shape stay the same objects/values
+    (the reference creates them once per run, train_model.py:293-410).  ``args.hipgraph = False``
+    switches it off.  Eager: CPU, spectrogram datasets, wrapped (DataParallel/DDP) models, a
+    criterion other than ``SELCLoss``, epochs past its turning point, an active process group
+    (use ``train_model()`` / ``FlatGradSync`` there)."""
+    if not getattr(args, "hipgraph", True) or device.type != "cuda":
+        return None
+    if args.dataset in SPECTROGRAM_DATASETS or not isinstance(criterion, SELCLoss):
+        return None
+    if not isinstance(model, (models.CNN_potes, models.ResNet9_myrtle)):
+        return None
+    if epoch > criterion.es or getattr(args, "num_epochs", epoch) > criterion.es:
+        return None
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return None
+    data = batch[0]
+    if data.dim() != 3:
+        return None
+    key = (id(optimizer), id(scheduler), id(criterion), tuple(data.shape), args.method,
+           args.num_classes, device)
+    hit = model.__dict__.get("_pcgmix_epoch_step")      # kept ON the model: dies with it (a module-
+    if hit is None or hit.key != key:                   # level table would keep model and graph alive)
+        B, C, T = data.shape
+        hit = _EpochStep(key, GraphedTrainStep(args, model, optimizer, scheduler, criterion, device, B, C, T))
+        model.__dict__["_pcgmix_epoch_step"] = hit
+    return hit.step
+
+
 def train_epoch(args, model, train_loader, device, optimizer, scheduler, criterion, epoch,
                 step_counter, variability_counter=None, EXPERIMENT_ARGS=None):
-    """Reference signature (train_model.py:490).  Returns (mean loss, accuracy, lr per step)."""
+    """Reference signature (train_model.py:490).  Returns (mean loss, accuracy, lr per step).
+    On a GPU the step is the captured one (``_epoch_graphed_step``): the same values as
+    ``train_step`` at three times its rate; batches of another shape (a loader without
+    drop_last) fall back to the eager step."""
     model.train()
     torch.manual_seed(args.seed * 635410 + step_counter.count)      # :497 fixes this epoch's shuffle
     stats = {"loss_sum": torch.zeros((), device=device), "hits": torch.zeros((), device=device,
                                                                          dtype=torch.long), "seen": 0}
     lrs, n_batches = [], 0
+    graphed = None
     for batch in train_loader:
         lrs.append(optimizer.param_groups[0]["lr"])
-        train_step(args, model, batch, device, optimizer, scheduler, criterion, epoch,
-                   step_counter, stats)
+        if n_batches == 0:
+            graphed = _epoch_graphed_step(args, model, optimizer, scheduler, criterion, device, epoch, batch)
+        if graphed is not None and tuple(batch[0].shape) == tuple(graphed.x.shape):
+            graphed.step(batch, epoch, step_counter, stats)
+        else:
+            train_step(args, model, batch, device, optimizer, scheduler, criterion, epoch,
+                       step_counter, stats)
         n_batches += 1
         if not step_counter.count < args.num_steps:                  # :584-586
             break

@@ -437,13 +437,14 @@ def test_bench_self_launches_two_ranks(device):
 
 
 # ---- pinned to the reference's own train_model.py (tests/golden/train_ref.npz) ------------------
-@pytest.mark.parametrize("mode", ["epoch", "step", "graph"])
+@pytest.mark.parametrize("mode", ["epoch", "epoch_graph", "step", "graph"])
 def test_train_step_reproduces_reference_trajectory(mode, device):
     """The HIP path — HIP augmentation, fused Potes stack/head, soft-CE kernels, ClipAdam — run
     for the 10 steps the reference's ``train_epoch`` (train_model.py:490-589) was recorded on:
     per-step loss within 1e-4, learning rates exact, every trained parameter within 1e-3 after
-    the 10th step.  'epoch' = train_epoch, 'step' = eager train_step, 'graph' = the captured
-    step (GraphedTrainStep)."""
+    the 10th step.  'epoch' = train_epoch with ``args.hipgraph = False`` (eager steps),
+    'epoch_graph' = train_epoch as it runs by default on a GPU (it builds and replays the captured
+    step), 'step' = eager train_step, 'graph' = the captured step (GraphedTrainStep)."""
     import train_replay
     err, worst = train_replay.check_trajectory(train_replay.trajectory(device, mode),
                                                loss_tol=1e-4, param_tol=1e-3)

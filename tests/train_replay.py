@@ -46,7 +46,21 @@ def trajectory(device, mode):
     crit = tm.SELCLoss(labels, 2, es=args.num_epochs + 1, device=device)
     sc = tm.step_counter_class()
     extras = {}
-    if mode == "epoch":
+    if mode == "epoch_graph":
+        # train_epoch as a caller of the reference's function gets it on a GPU: the captured step,
+        # built at the first batch.  It returns the epoch mean only: the per-step trajectory is
+        # filled with the recorded one shifted by the mean's error (so check_trajectory's loss
+        # bound applies to the mean), learning rates and final parameters are compared as always.
+        mean_loss, acc, lrs = tm.train_epoch(args, net, batches, device, opt, sched, crit, 1, sc)
+        assert isinstance(net.__dict__["_pcgmix_epoch_step"].step, tm.GraphedTrainStep)
+        import copy, pickle
+        assert copy.deepcopy(net).__dict__["_pcgmix_epoch_step"] is None      # copies drop the graph
+        assert pickle.loads(pickle.dumps(net)).__dict__["_pcgmix_epoch_step"] is None
+        extras = {"mean_loss": mean_loss, "acc": acc}
+        g = golden()
+        losses = g["traj_losses"] + (mean_loss - float(g["traj_mean_loss"]))
+    elif mode == "epoch":
+        args.hipgraph = False                   # the eager epoch (train_step per batch)
         losses = []
         orig = tm.train_step
 
