@@ -781,6 +781,10 @@ class PipelinedTrainStep:
     def loss(self):
         return self.slots[self.cur ^ 1].loss          # the step that ran last
 
+    @property
+    def x(self):
+        return self.slots[0].x                        # (shape of the static input)
+
     @staticmethod
     def pairs(loader):
         """(batch, next batch or None) over ``loader`` — the one-batch lookahead ``step`` wants."""
@@ -872,7 +876,10 @@ def _epoch_graphed_step(args, model, optimizer, scheduler, criterion, device, ep
     hit = model.__dict__.get("_pcgmix_epoch_step")      # kept ON the model: dies with it (a module-
     if hit is None or hit.key != key:                   # level table would keep model and graph alive)
         B, C, T = data.shape
-        hit = _EpochStep(key, GraphedTrainStep(args, model, optimizer, scheduler, criterion, device, B, C, T))
+        # saliency-guided methods: two captured slots, the augmentation of the next batch on a side
+        # stream under the graph of this one (+15 % at BASELINE config 3); one slot otherwise
+        cls = PipelinedTrainStep if "(salopt" in args.method else GraphedTrainStep
+        hit = _EpochStep(key, cls(args, model, optimizer, scheduler, criterion, device, B, C, T))
         model.__dict__["_pcgmix_epoch_step"] = hit
     return hit.step
 
@@ -889,12 +896,18 @@ def train_epoch(args, model, train_loader, device, optimizer, scheduler, criteri
                                                                          dtype=torch.long), "seen": 0}
     lrs, n_batches = [], 0
     graphed = None
-    for batch in train_loader:
+    for batch, nxt in PipelinedTrainStep.pairs(train_loader):          # one batch of lookahead
         lrs.append(optimizer.param_groups[0]["lr"])
         if n_batches == 0:
             graphed = _epoch_graphed_step(args, model, optimizer, scheduler, criterion, device, epoch, batch)
         if graphed is not None and tuple(batch[0].shape) == tuple(graphed.x.shape):
-            graphed.step(batch, epoch, step_counter, stats)
+            if isinstance(graphed, PipelinedTrainStep):
+                last = not step_counter.count + 1 < getattr(args, "num_steps", float("inf"))   # :584-586
+                ahead = nxt if (not last and nxt is not None
+                                and tuple(nxt[0].shape) == tuple(graphed.x.shape)) else None
+                graphed.step(batch, epoch, step_counter, stats, next_batch=ahead)
+            else:
+                graphed.step(batch, epoch, step_counter, stats)
         else:
             train_step(args, model, batch, device, optimizer, scheduler, criterion, epoch,
                        step_counter, stats)

@@ -447,3 +447,40 @@ def test_train_model_driver_salopt_with_its_own_base_checkpoint(device, tmp_path
         finals.append([p.detach().cpu().clone() for p in perf["model"].parameters()])
     for a, b in zip(*finals):
         assert torch.equal(a, b)
+
+
+def test_train_epoch_pipelines_the_saliency_guided_step(device, tmp_path):
+    """``train_epoch`` — the reference's signature — on a GPU with a saliency-guided method: it
+    builds the two-slot pipelined captured step by itself (one batch of lookahead over the loader)
+    and returns what the eager epoch (``args.hipgraph = False``) returns: mean loss to 1e-4,
+    accuracy and learning rates exactly, parameters to 1e-3; a second epoch re-uses the graph."""
+    B, T = 32, 2500
+    batches = []
+    for i in range(6):
+        x, frames, labels, wav = synthetic.make_batch(B, 4, T, sample_rate=1000, seed=740 + i)
+        batches.append((torch.from_numpy(x), torch.from_numpy(labels), torch.from_numpy(frames), wav,
+                        torch.ones(B, dtype=torch.long), torch.arange(B)))
+    out = {}
+    for mode in ("eager", "captured"):
+        args = TC.salopt_traj_args(str(tmp_path / mode))
+        args.batch_size, args.num_steps, args.num_epochs = B, 12, 2
+        args.hipgraph = mode == "captured"
+        _write_base_checkpoint(args)
+        saliency._LOADED.clear()
+        net = _potes(args, device)
+        opt, sched = tm.make_optimizer(args, net)
+        crit = tm.SELCLoss(np.concatenate([b[1].numpy() for b in batches]), 2, es=args.num_epochs + 1,
+                           device=device)
+        sc = tm.step_counter_class()
+        res = [tm.train_epoch(args, net, batches, device, opt, sched, crit, e, sc) for e in (1, 2)]
+        step = net.__dict__.get("_pcgmix_epoch_step")
+        if mode == "captured":
+            assert isinstance(step.step, tm.PipelinedTrainStep)
+        else:
+            assert step is None
+        assert sc.count == 12
+        out[mode] = (res, [p.detach().cpu().numpy() for p in net.parameters() if p.requires_grad])
+    for (la, aa, lra), (lb, ab, lrb) in zip(out["eager"][0], out["captured"][0]):
+        assert abs(la - lb) <= 1e-4 * max(1.0, abs(la)) and aa == ab and lra == lrb
+    for a, b in zip(out["eager"][1], out["captured"][1]):
+        assert np.allclose(a, b, rtol=1e-3, atol=1e-4)
