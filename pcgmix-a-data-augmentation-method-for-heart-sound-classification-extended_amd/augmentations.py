@@ -304,7 +304,7 @@ def splice_plain(recipe, data: torch.Tensor, labels, frames, step: int,
     idx = data.device.index
     ohe_ptr, n_cls, lab_ptr = None, 0, None
     if labels is None:
-        ohe = target_ohe.detach()
+        ohe = target_ohe                          # (only its metadata and address are read)
         if ohe.is_cuda and ohe.dtype == torch.int64 and ohe.dim() == 2 and ohe.is_contiguous():
             if ohe.shape[0] != B:
                 raise ValueError("labels/frames do not match the batch size")
