@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 12
+#define PCGMIX_ABI_VERSION 13
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -379,6 +379,18 @@ int pcgmix_adam_hyper(float clip, float lr, float beta1, float beta2, float eps,
 int pcgmix_adam_clip_multi_dev_f32(int n_tensors, float* const* p, const float* const* g,
                                    float* const* m, float* const* v, const long long* n,
                                    const float* hyper_dev, pcgmix_stream_t stream);
+/* The same update with the Potes conv stack's gradient reduction folded in (one launch less at
+ * the end of a captured training step): pcgmix_potes_stack_bwd_mask_f32 called with grads = NULL
+ * leaves its G x 212 partial rows un-reduced; this launch carries 212 extra blocks, each of which
+ * sums one column in pcgmix_potes_reduce_f32's order (same bits), stores it at grads[e] and updates
+ * the element of the tensor whose gradient pointer g[i] lies inside grads[0 .. 212) (such tensors
+ * are updated by those blocks only).  n_tensors <= 32.  pcgmix_potes_reduce_f32 is the reduction
+ * alone (what pcgmix_potes_stack_bwd_mask_f32 launches when grads != NULL).                      */
+int pcgmix_adam_clip_multi_reduce_dev_f32(int n_tensors, float* const* p, const float* const* g,
+                                          float* const* m, float* const* v, const long long* n,
+                                          const float* hyper_dev, const float* partial, float* grads,
+                                          int G, pcgmix_stream_t stream);
+int pcgmix_potes_reduce_f32(const float* partial, float* grads, int G, pcgmix_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Potes classifier head, forward and backward.                                       [device]

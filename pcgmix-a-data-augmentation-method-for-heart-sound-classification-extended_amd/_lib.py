@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -66,6 +66,9 @@ SIGNATURES = {
                                             ctypes.c_longlong, _ptr]),
     "pcgmix_adam_hyper": (_c_int, [_c_float] * 6 + [ctypes.c_longlong, _ptr]),
     "pcgmix_adam_clip_multi_dev_f32": (_c_int, [_c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "pcgmix_adam_clip_multi_reduce_dev_f32": (_c_int, [_c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                                       _c_int, _ptr]),
+    "pcgmix_potes_reduce_f32": (_c_int, [_ptr, _ptr, _c_int, _ptr]),
     "pcgmix_potes_head_fwd_f32": (_c_int, [_ptr, _ptr, _c_float, _c_int, _c_int, _ptr, _ptr, _ptr, _c_float,
                                            _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int,
                                            _ptr]),

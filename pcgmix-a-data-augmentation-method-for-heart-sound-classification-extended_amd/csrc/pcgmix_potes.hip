@@ -1587,11 +1587,10 @@ __global__ void skinny_linear_reduce_kernel(const float* __restrict__ partial,
 }
 
 // Sum the per-block partial vectors in a fixed order: grads[e] = sum_g partial[g][e].
-__global__ __launch_bounds__(kPotThreads) void potes_reduce_kernel(const float* __restrict__ partial,
-                                                                   float* __restrict__ grads,
-                                                                   int G) {
-  __shared__ float red[kPotThreads];
-  const int e = blockIdx.x;
+// Column e of the G partial rows, summed by one 256-thread block in a fixed order (thread t takes
+// rows t, t + 256, ...; then a tree over the threads): the value is in red[0] for thread 0.
+__device__ __forceinline__ float potes_reduce_column(const float* __restrict__ partial, int G, int e,
+                                                     float* red) {
   float a = 0.f;
   for (int g = threadIdx.x; g < G; g += kPotThreads) a += partial[(size_t)g * kNGrad + e];
   red[threadIdx.x] = a;
@@ -1600,7 +1599,15 @@ __global__ __launch_bounds__(kPotThreads) void potes_reduce_kernel(const float* 
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) grads[e] = red[0];
+  return red[0];
+}
+
+__global__ __launch_bounds__(kPotThreads) void potes_reduce_kernel(const float* __restrict__ partial,
+                                                                   float* __restrict__ grads,
+                                                                   int G) {
+  __shared__ float red[kPotThreads];
+  const float v = potes_reduce_column(partial, G, blockIdx.x, red);
+  if (threadIdx.x == 0) grads[blockIdx.x] = v;
 }
 
 // ---------------------------------------------------------------------------------- optimiser
@@ -1651,14 +1658,48 @@ struct AdamTable {
 // hyper != nullptr: the eight scalars are read from device memory instead (clip, wd, 1-b1, b2,
 // 1-b2, step_size, 1/sqrt(bc2), eps — pcgmix_adam_hyper's layout): a launch captured in a
 // hipGraph then follows OneCycleLR's lr/beta1 and the bias corrections from replay to replay.
+// partial != nullptr: the launch carries kNGrad EXTRA blocks behind the table's own — block
+// red_first + e sums column e of the conv stack's per-block gradient partials exactly as
+// potes_reduce_kernel does (same order, same bits), stores it at grads[e] (what the parameters'
+// .grad tensors alias) and applies the update to the one element it belongs to: the tensor of the
+// table whose gradient pointer lies inside grads[0 .. kNGrad) (such tensors own no blocks of the
+// table).  One launch instead of two at the end of a captured training step.
 __global__ __launch_bounds__(256) void adam_clip_multi_kernel(AdamTable tab, float clip, float wd,
                                                               float one_m_b1, float b2,
                                                               float one_m_b2, float step_size,
                                                               float inv_bc2_sqrt, float eps,
-                                                              const float* __restrict__ hyper) {
+                                                              const float* __restrict__ hyper,
+                                                              const float* __restrict__ partial,
+                                                              float* __restrict__ grads, int G,
+                                                              int red_first) {
   if (hyper) {
     clip = hyper[0]; wd = hyper[1]; one_m_b1 = hyper[2]; b2 = hyper[3];
     one_m_b2 = hyper[4]; step_size = hyper[5]; inv_bc2_sqrt = hyper[6]; eps = hyper[7];
+  }
+  if (partial && (int)blockIdx.x >= red_first) {
+    __shared__ float red[kPotThreads];
+    const int e = (int)blockIdx.x - red_first;
+    float gi = potes_reduce_column(partial, G, e, red);
+    if (threadIdx.x != 0) return;
+    grads[e] = gi;
+    const float* ge = grads + e;
+    for (int t = 0; t < tab.count; ++t) {
+      if (ge >= tab.g[t] && ge < tab.g[t] + tab.n[t]) {
+        const long long i = ge - tab.g[t];
+        if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+        const float pi = tab.p[t][i];
+        gi = fmaf(wd, pi, gi);
+        float mi = tab.m[t][i], vi = tab.v[t][i];
+        mi = fmaf(one_m_b1, gi - mi, mi);
+        vi = fmaf(one_m_b2 * gi, gi, b2 * vi);
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        tab.p[t][i] = pi - step_size * (mi / denom);
+        tab.m[t][i] = mi;
+        tab.v[t][i] = vi;
+        return;
+      }
+    }
+    return;
   }
   int t = 0;
   while (t + 1 < tab.count && (int)blockIdx.x >= tab.blk_start[t + 1]) ++t;
@@ -1707,7 +1748,8 @@ extern "C" int pcgmix_adam_hyper(float clip, float lr, float beta1, float beta2,
 
 static int adam_multi_launch(int n_tensors, float* const* p, const float* const* g, float* const* m,
                              float* const* v, const long long* n, const float* h8,
-                             const float* hyper_dev, hipStream_t stream);
+                             const float* hyper_dev, hipStream_t stream,
+                             const float* partial = nullptr, float* grads = nullptr, int G = 0);
 
 extern "C" int pcgmix_adam_clip_multi_dev_f32(int n_tensors, float* const* p, const float* const* g,
                                               float* const* m, float* const* v, const long long* n,
@@ -1717,6 +1759,25 @@ extern "C" int pcgmix_adam_clip_multi_dev_f32(int n_tensors, float* const* p, co
   const float zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   return adam_multi_launch(n_tensors, p, g, m, v, n, zero8, hyper_dev,
                            reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int pcgmix_adam_clip_multi_reduce_dev_f32(int n_tensors, float* const* p,
+                                                     const float* const* g, float* const* m,
+                                                     float* const* v, const long long* n,
+                                                     const float* hyper_dev, const float* partial,
+                                                     float* grads, int G, pcgmix_stream_t stream) {
+  if (n_tensors <= 0 || !hyper_dev || !p || !g || !m || !v || !n || !partial || !grads || G <= 0)
+    return hipErrorInvalidValue;
+  const float zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return adam_multi_launch(n_tensors, p, g, m, v, n, zero8, hyper_dev,
+                           reinterpret_cast<hipStream_t>(stream), partial, grads, G);
+}
+
+extern "C" int pcgmix_potes_reduce_f32(const float* partial, float* grads, int G, pcgmix_stream_t stream) {
+  if (!partial || !grads || G <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pcgmix::potes_reduce_kernel, dim3(pcgmix::kNGrad), dim3(pcgmix::kPotThreads), 0,
+                     reinterpret_cast<hipStream_t>(stream), partial, grads, G);
+  return (int)hipGetLastError();
 }
 
 extern "C" int pcgmix_adam_clip_multi_f32(int n_tensors, float* const* p, const float* const* g,
@@ -1734,8 +1795,10 @@ extern "C" int pcgmix_adam_clip_multi_f32(int n_tensors, float* const* p, const 
 
 static int adam_multi_launch(int n_tensors, float* const* p, const float* const* g, float* const* m,
                              float* const* v, const long long* n, const float* h8,
-                             const float* hyper_dev, hipStream_t stream) {
+                             const float* hyper_dev, hipStream_t stream, const float* partial,
+                             float* grads, int G) {
   using namespace pcgmix;
+  if (partial && n_tensors > kAdamMaxTensors) return hipErrorInvalidValue;   // one table, one launch
   for (int first = 0; first < n_tensors; first += kAdamMaxTensors) {
     AdamTable tab;
     tab.count = 0;
@@ -1744,7 +1807,9 @@ static int adam_multi_launch(int n_tensors, float* const* p, const float* const*
     for (int i = first; i < last; ++i) {
       if (n[i] < 0 || (n[i] > 0 && (!p[i] || !g[i] || !m[i] || !v[i]))) return hipErrorInvalidValue;
       if (n[i] == 0) continue;
-      const long long nb = (n[i] + kAdamEPB - 1) / kAdamEPB;
+      // tensors whose gradient lives in grads[0 .. kNGrad) are updated by the reduction blocks
+      const bool deferred = partial && g[i] >= grads && g[i] < grads + kNGrad;
+      const long long nb = deferred ? 0 : (n[i] + kAdamEPB - 1) / kAdamEPB;
       if (nb > (1ll << 30) - blocks) return hipErrorInvalidValue;
       const int k = tab.count++;
       tab.p[k] = p[i]; tab.g[k] = g[i]; tab.m[k] = m[i]; tab.v[k] = v[i]; tab.n[k] = n[i];
@@ -1753,8 +1818,11 @@ static int adam_multi_launch(int n_tensors, float* const* p, const float* const*
     }
     if (tab.count == 0) continue;
     tab.blk_start[tab.count] = blocks;
+    const int red_first = blocks;
+    if (partial) blocks += kNGrad;
     hipLaunchKernelGGL(adam_clip_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, tab,
-                       h8[0], h8[1], h8[2], h8[3], h8[4], h8[5], h8[6], h8[7], hyper_dev);
+                       h8[0], h8[1], h8[2], h8[3], h8[4], h8[5], h8[6], h8[7], hyper_dev, partial, grads, G,
+                       red_first);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return (int)err;
   }
@@ -1902,7 +1970,7 @@ extern "C" int pcgmix_potes_stack_bwd_mask_f32(const float* x, const float* grad
                                                const float* w2, const float* b2, float* partial,
                                                float* grads, int N, int T, pcgmix_stream_t stream) {
   using namespace pcgmix;
-  if (!x || !grad_h2 || !m2 || !w1 || !b1 || !w2 || !b2 || !partial || !grads || N <= 0 || N > 65535 || T < 14)
+  if (!x || !grad_h2 || !m2 || !w1 || !b1 || !w2 || !b2 || !partial || N <= 0 || N > 65535 || T < 14)
     return hipErrorInvalidValue;
   const int G = pcgmix_potes_bwd_blocks(N, T);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1913,7 +1981,8 @@ extern "C" int pcgmix_potes_stack_bwd_mask_f32(const float* x, const float* grad
   else
     hipLaunchKernelGGL(potes_bwd_kernel<true>, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2,
                        m2, w1, b1, w2, b2, partial, N, T);
-  hipLaunchKernelGGL(potes_reduce_kernel, dim3(kNGrad), dim3(kPotThreads), 0, s, partial, grads, G);
+  if (grads)      // NULL: the caller reduces later (pcgmix_adam_clip_multi_reduce_dev_f32 / pcgmix_potes_reduce_f32)
+    hipLaunchKernelGGL(potes_reduce_kernel, dim3(kNGrad), dim3(kPotThreads), 0, s, partial, grads, G);
   return (int)hipGetLastError();
 }
 

@@ -43,6 +43,13 @@ class PotesStackFunction(torch.autograd.Function):
     but the input row (``pcgmix_potes_stack_{bwd,input_grad}_f32``)."""
 
     use_masks = True
+    # A dict while a captured training step records its backward and the optimiser update is the
+    # next node (``GraphedTrainStep`` with ``ClipAdam``, one rank): the mask-based weight-gradient
+    # backward then leaves its per-block partials un-reduced and reports them here ("partial",
+    # "grads", "G") — ``ClipAdam.capture_update`` reduces them inside its own launch
+    # (``pcgmix_adam_clip_multi_reduce_dev_f32``: one launch less per replay), or, if it cannot,
+    # with ``pcgmix_potes_reduce_f32``.  None everywhere else.
+    defer_reduce = None
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, rnd=None, key=None):
@@ -104,10 +111,16 @@ class PotesStackFunction(torch.autograd.Function):
             partial = torch.empty((G, 212), dtype=torch.float32, device=x.device)
             grads = torch.empty(212, dtype=torch.float32, device=x.device)
             if m2 is not None:
+                defer = PotesStackFunction.defer_reduce
+                if defer is not None and "partial" in defer:
+                    defer = None                       # a second stack in the same step: reduce here
                 _lib.check(lib.pcgmix_potes_stack_bwd_mask_f32(
                     x.data_ptr(), g.data_ptr(), m2.data_ptr(), w1.data_ptr(), b1.data_ptr(),
-                    w2.data_ptr(), b2.data_ptr(), partial.data_ptr(), grads.data_ptr(), N, T, stream),
+                    w2.data_ptr(), b2.data_ptr(), partial.data_ptr(),
+                    grads.data_ptr() if defer is None else None, N, T, stream),
                     "pcgmix_potes_stack_bwd_mask_f32")
+                if defer is not None:
+                    defer.update(partial=partial, grads=grads, G=G)
             else:
                 _lib.check(lib.pcgmix_potes_stack_bwd_f32(
                     x.data_ptr(), g.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),

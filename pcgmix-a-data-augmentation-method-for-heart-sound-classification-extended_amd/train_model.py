@@ -208,17 +208,37 @@ class ClipAdam(torch.optim.Adam):
         self._cap_step = steps.pop()
 
     @torch.no_grad()
-    def capture_update(self, hyper_dev: torch.Tensor):
-        """Inside the capture, after backward: the update of all ``prepare_capture`` tensors."""
+    def capture_update(self, hyper_dev: torch.Tensor, deferred: Optional[dict] = None):
+        """Inside the capture, after backward: the update of all ``prepare_capture`` tensors.
+
+        ``deferred`` (``models.PotesStackFunction.defer_reduce`` after the backward): the Potes conv
+        stack left its 212 gradient columns as G un-reduced partial rows.  When the stack's four
+        parameter gradients are views of ``deferred["grads"]`` (autograd keeps the tensors the
+        backward returned) the reduction runs as 212 extra blocks of this launch, each of which also
+        updates its element; otherwise it is launched on its own first."""
         import ctypes
         from . import _lib
+        lib = _lib.load()
         live = self._cap_params
         if any(p.grad is None for p in live):
             raise RuntimeError("ClipAdam.capture_update: a prepared parameter has no gradient")
         self._cap_grads = self._dense_grads(live)            # keep graph memory referenced
         tab = self._table(0, live, self._cap_grads)
         stream = ctypes.c_void_p(torch.cuda.current_stream(live[0].device).cuda_stream)
-        _lib.check(_lib.load().pcgmix_adam_clip_multi_dev_f32(
+        if deferred and "partial" in deferred:
+            grads, partial, G = deferred["grads"], deferred["partial"], int(deferred["G"])
+            lo, hi = grads.data_ptr(), grads.data_ptr() + grads.numel() * 4
+            covered = sum(g.numel() for g in self._cap_grads if lo <= g.data_ptr() < hi)
+            self._cap_deferred = (partial, grads)            # referenced by the graph
+            if covered == grads.numel() and len(live) <= 32:
+                _lib.check(lib.pcgmix_adam_clip_multi_reduce_dev_f32(
+                    len(live), tab[1], tab[5], tab[2], tab[3], tab[4], hyper_dev.data_ptr(),
+                    partial.data_ptr(), grads.data_ptr(), G, stream),
+                    "pcgmix_adam_clip_multi_reduce_dev_f32")
+                return
+            _lib.check(lib.pcgmix_potes_reduce_f32(partial.data_ptr(), grads.data_ptr(), G, stream),
+                       "pcgmix_potes_reduce_f32")
+        _lib.check(lib.pcgmix_adam_clip_multi_dev_f32(
             len(live), tab[1], tab[5], tab[2], tab[3], tab[4], hyper_dev.data_ptr(), stream),
             "pcgmix_adam_clip_multi_dev_f32")
 
@@ -600,10 +620,18 @@ class GraphedTrainStep:
             sync.dist.barrier()
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: HIP calls of other threads (RCCL's watchdog) must not abort the capture
+        # One rank, ClipAdam as the graph's last node: the conv stack's gradient reduction moves
+        # into the optimiser launch (models.PotesStackFunction.defer_reduce).
+        fold = {} if (self.adam_in_graph and sync is None
+                      and os.environ.get("PCGMIX_NO_REDUCE_FOLD") is None) else None
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.loss, self.out = self._fwd_bwd()
+            models.PotesStackFunction.defer_reduce = fold
+            try:
+                self.loss, self.out = self._fwd_bwd()
+            finally:
+                models.PotesStackFunction.defer_reduce = None
             if self.adam_in_graph and sync is None:
-                self.opt.capture_update(self.aux[4:12])
+                self.opt.capture_update(self.aux[4:12], deferred=fold)
         if self.adam_in_graph and sync is not None:
             # N > 1: [forward + backward + pack] | one eager all-reduce | [clip + Adam].  The update
             # reads the averaged gradients through views of the flat buffer and its eight scalars
