@@ -126,11 +126,31 @@ class PcgmixLibraryError(RuntimeError):
     pass
 
 
+TAPE = None      # a list while a captured step records its library launches (train_model.GraphedTrainStep)
+
+
+class _Recorder:
+    """``load()``'s return value while ``TAPE`` is a list: every call whose last argument is a stream
+    handle is appended as (name, function, arguments) and then made."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+
+        def call(*a):
+            if TAPE is not None and a and isinstance(a[-1], ctypes.c_void_p):
+                TAPE.append((name, fn, a))
+            return fn(*a)
+        return call
+
+
 def load() -> ctypes.CDLL:
     """Load (once) and type the library.  Raises PcgmixLibraryError when it is absent."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _lib if TAPE is None else _Recorder(_lib)
     with _lock:
         if _lib is not None:
             return _lib

@@ -505,6 +505,11 @@ class GraphedTrainStep:
     (``FlatGradSync``) — DDP's hooks cannot be captured — and the update is a SECOND small graph
     replayed behind the collective.  Needs static shapes (the loaders use drop_last=True)."""
 
+    use_tape = True      # direct launches instead of the graph replay where the step allows it
+    _TAPE_LAUNCHES = ("pcgmix_potes_stack_fwd_save_f32", "pcgmix_potes_head_loss_fwd_f32",
+                      "pcgmix_potes_head_loss_bwd_f32", "pcgmix_potes_stack_bwd_mask_f32",
+                      "pcgmix_adam_clip_multi_reduce_dev_f32")
+
     def __init__(self, args, model, optimizer, scheduler, criterion, device, batch_size, channels,
                  sig_len, sync: Optional[FlatGradSync] = None):
         if args.dataset in SPECTROGRAM_DATASETS:
@@ -624,14 +629,33 @@ class GraphedTrainStep:
         # into the optimiser launch (models.PotesStackFunction.defer_reduce).
         fold = {} if (self.adam_in_graph and sync is None
                       and os.environ.get("PCGMIX_NO_REDUCE_FOLD") is None) else None
+        # The fused Potes step is five library launches and nothing else (forward, head + loss,
+        # feature pass, weight gradients, reduction + update: profiles/r3_train_step_timeline.txt).
+        # They are recorded while the capture makes them; ``launch`` then issues them DIRECTLY on the
+        # current stream instead of replaying the hipGraph — the graph's launch leaves ~5 us of idle
+        # GPU per step that back-to-back kernel launches do not (130.8 -> 125.7 us,
+        # profiles/probes/tape_vs_graph.py).  The graph object stays: it owns the buffers.
+        from . import _lib
+        want_tape = (self.use_tape and fold is not None and self.labels_mode
+                     and isinstance(model, models.CNN_potes) and os.environ.get("PCGMIX_NO_TAPE") is None)
+        tape = [] if want_tape else None
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             models.PotesStackFunction.defer_reduce = fold
+            _lib.TAPE = tape
             try:
                 self.loss, self.out = self._fwd_bwd()
+                if self.adam_in_graph and sync is None:
+                    self.opt.capture_update(self.aux[4:12], deferred=fold)
             finally:
                 models.PotesStackFunction.defer_reduce = None
-            if self.adam_in_graph and sync is None:
-                self.opt.capture_update(self.aux[4:12], deferred=fold)
+                _lib.TAPE = None
+        self.tape = None
+        if tape is not None and [t[0] for t in tape] == list(self._TAPE_LAUNCHES):
+            import ctypes
+            # pointer tables are snapshotted: ClipAdam re-uses its ctypes arrays for the next capture
+            # (a second slot of PipelinedTrainStep), a graph node would have copied them too
+            snap = lambda v: type(v)(*v) if isinstance(v, ctypes.Array) else v      # noqa: E731
+            self.tape = [(name, fn, tuple(snap(v) for v in a[:-1])) for name, fn, a in tape]
         if self.adam_in_graph and sync is not None:
             # N > 1: [forward + backward + pack] | one eager all-reduce | [clip + Adam].  The update
             # reads the averaged gradients through views of the flat buffer and its eight scalars
@@ -745,7 +769,16 @@ class GraphedTrainStep:
         """Second half: replay the captured forward + backward (+ update), the gradient all-reduce
         and update graph under torch.distributed, scheduler, step counter, statistics."""
         B = self._batch_size
-        self.graph.replay()
+        if self.tape is not None:
+            import ctypes
+            st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            for name, fn, a in self.tape:
+                err = fn(*a, st)
+                if err:
+                    from . import _lib
+                    _lib.check(err, name)
+        else:
+            self.graph.replay()
         reseed_device_rng(self.args, self.device)
         if self.graph_update is not None:
             self.sync.reduce_and_bind()

@@ -484,3 +484,48 @@ def test_train_epoch_pipelines_the_saliency_guided_step(device, tmp_path):
         assert abs(la - lb) <= 1e-4 * max(1.0, abs(la)) and aa == ab and lra == lrb
     for a, b in zip(out["eager"][1], out["captured"][1]):
         assert np.allclose(a, b, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("method", ["durratiomixup", "durmixmagwarp(0.2,4)+0.8"])
+def test_direct_launches_equal_the_graph_replay(method, device, tmp_path):
+    """The fused Potes step issued as its five recorded library launches (the default) == the same
+    step replayed as a hipGraph (``GraphedTrainStep.use_tape = False``): every loss and every
+    parameter bit for bit over 8 steps, dropout on.  Another model keeps the graph."""
+    B, T = 32, 2500
+    batches = []
+    for i in range(8):
+        x, frames, labels, wav = synthetic.make_batch(B, 4, T, sample_rate=1000, seed=820 + i)
+        batches.append((torch.from_numpy(x).to(device), torch.from_numpy(labels), torch.from_numpy(frames),
+                        wav, torch.ones(B, dtype=torch.long), torch.arange(B)))
+    res = {}
+    old = tm.GraphedTrainStep.use_tape
+    try:
+        for use_tape in (True, False):
+            tm.GraphedTrainStep.use_tape = use_tape
+            args = TC.salopt_traj_args(str(tmp_path / str(use_tape)))
+            args.method, args.batch_size, args.seed_fix, args.num_steps = method, B, 4, 8
+            torch.manual_seed(7)
+            net = tm.build_model(args).to(device).train()
+            opt, sched = tm.make_optimizer(args, net)
+            crit = tm.SELCLoss(np.zeros(B * 8, int), 2, es=args.num_epochs + 1, device=device)
+            sc = tm.step_counter_class()
+            torch.cuda.manual_seed(4)
+            g = tm.GraphedTrainStep(args, net, opt, sched, crit, device, B, 4, T)
+            assert (g.tape is not None) == use_tape
+            if use_tape:
+                assert [t[0] for t in g.tape] == list(tm.GraphedTrainStep._TAPE_LAUNCHES)
+            losses = [g.step(b, 1, sc).clone() for b in batches]
+            torch.cuda.synchronize()
+            res[use_tape] = (torch.stack(losses).cpu(), [p.detach().cpu().clone() for p in net.parameters()])
+    finally:
+        tm.GraphedTrainStep.use_tape = old
+    assert torch.equal(res[True][0], res[False][0]), (res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)
+    # ResNet9: torch/MIOpen kernels inside the capture — the graph is replayed
+    args = TC.salopt_traj_args(str(tmp_path / "r9"))
+    args.method, args.model, args.batch_size = "durratiomixup", "resnet9", 4
+    net = tm.build_model(args).to(device).train()
+    opt, sched = tm.make_optimizer(args, net)
+    crit = tm.SELCLoss(np.zeros(8, int), 2, es=args.num_epochs + 1, device=device)
+    assert tm.GraphedTrainStep(args, net, opt, sched, crit, device, 4, 4, T).tape is None
