@@ -356,8 +356,12 @@ def build_train_step(method, model_name, B, C, T, rate, device, total_steps, ran
             step = lambda: g.step(batch, 0, sc, None, next_batch=batch)      # noqa: E731
     else:
         step = lambda: tm.train_step(args, model, batch, device, opt, sched, crit, 0, sc)  # noqa: E731
+    slots = getattr(g, "slots", [g]) if graphed else []
     return step, {"model": model_name, "method": method, "batch_per_gpu": B, "shape": [B, C, T],
                   "hipgraph": bool(graphed),
+                  # the captured step issued as its recorded library launches instead of a graph
+                  # replay (fused Potes step, one rank; train_model.GraphedTrainStep)
+                  "direct_launches": bool(slots) and all(s_.tape is not None for s_ in slots),
                   "pipelined": bool(graphed) and "(salopt" in method
                   and not os.environ.get("PCGMIX_BENCH_NO_PIPELINE")}
 
