@@ -980,18 +980,40 @@ def train_epoch(args, model, train_loader, device, optimizer, scheduler, criteri
     return loss, acc, lrs
 
 
-@torch.no_grad()
-def test_data_accuracy(args, model, test_loader, device, criterion=None):
-    """Evaluation as train_model.py:591-670: per recording, average the softmax of its heart
-    cycles and take the argmax (:623-633); with '(class_majority)' in ``args.method`` the
-    recording's class is the majority of its cycles' arg-max votes, a 0/1 tie going to class 1
-    (:634-647).  Accuracy / sensitivity / specificity / precision / recall / F1 over recordings,
-    ROC-AUC of the mean class-1 probability.  The per-recording sums are segmented sums on the
-    device (index_add), not a Python dict of ``.item()`` values.
+class performance_metrics_class:
+    """The reference's result collector (train_model.py:178-195): a dict of lists with the same
+    thirteen keys and the same ``add(key, value)``."""
 
-    Returns a dict (the reference appends the same numbers to its ``performance`` object).
-    Under '(class_majority)' the reference never collects the mean probabilities and its own
-    ``roc_auc_score`` line (:667) raises IndexError; here ``rocauc`` is None on that branch."""
+    def __init__(self):
+        self.dict = {k: [] for k in ("steps", "epochs", "times", "train_loss", "train_accuracy",
+                                     "test_loss", "test_accuracy", "test_specificity",
+                                     "test_sensitivity", "test_precision", "test_recall", "test_f1",
+                                     "test_rocauc")}
+
+    def add(self, string, value):
+        self.dict[string].append(value)
+
+
+@torch.no_grad()
+def test_data_accuracy(args, model, test_loader, device, criterion=None, epoch=None,
+                       performance=None):
+    """Evaluation as train_model.py:591-670, reference signature ``(args, model, test_loader,
+    device, criterion, epoch, performance)`` (called that way at :455): per recording, average
+    the softmax of its heart cycles and take the argmax (:623-633); with '(class_majority)' in
+    ``args.method`` the recording's class is the majority of its cycles' arg-max votes, a 0/1 tie
+    going to class 1 (:634-647).  Accuracy / sensitivity / specificity / precision / recall / F1
+    over recordings, ROC-AUC of the mean class-1 probability.  The per-recording sums are
+    segmented sums on the device (index_add), not a Python dict of ``.item()`` values.
+
+    With a ``performance`` object (anything with the reference's ``add(key, value)``,
+    :194-195) the eight ``test_*`` values are appended to it in the reference's order
+    (:651-669) and the function returns None, as the reference does.  Without one it returns
+    the same numbers as a dict.  ``epoch`` is accepted and unused, as in the reference.
+
+    Under '(class_majority)' the reference never collects the mean probabilities, so its own
+    ``roc_auc_score`` line (:667) raises IndexError after the other seven values have been
+    appended: with ``performance`` this function does exactly that; the dict form carries
+    ``rocauc = None`` on that branch."""
     model.eval()
     rec_ids: dict = {}
     rec_label: dict = {}
@@ -1045,10 +1067,20 @@ def test_data_accuracy(args, model, test_loader, device, criterion=None):
             ranks[tie] = ranks[tie].mean()
         n1 = int(lab.sum())
         auc = float((ranks[lab == 1].sum() - n1 * (n1 + 1) / 2) / (n1 * (R - n1)))
-    return {"accuracy": 100.0 * float((pred == lab).sum()) / max(1, R), "sensitivity": 100.0 * rec,
-            "specificity": 100.0 * tn / max(1, tn + fp), "precision": prec, "recall": rec,
-            "f1": 2 * prec * rec / max(1e-12, prec + rec), "rocauc": auc, "recordings": R,
-            "loss": float(loss_sum) / max(1, n) if criterion is not None else None}
+    n_total = len(test_loader.dataset) if hasattr(test_loader, "dataset") else n      # :653
+    ev = {"accuracy": 100.0 * float((pred == lab).sum()) / max(1, R), "sensitivity": 100.0 * rec,
+          "specificity": 100.0 * tn / max(1, tn + fp), "precision": prec, "recall": rec,
+          "f1": 2 * prec * rec / max(1e-12, prec + rec), "rocauc": auc, "recordings": R,
+          "loss": float(loss_sum) / max(1, n_total) if criterion is not None else None}
+    if performance is None:
+        return ev
+    for key in ("accuracy", "loss", "specificity", "sensitivity", "f1", "precision", "recall"):
+        performance.add("test_" + key, ev[key])                                       # :651-666
+    if majority:
+        raise IndexError("'(class_majority)' collects no mean probabilities: the reference's "
+                         "roc_auc_score line (train_model.py:667) fails the same way")
+    performance.add("test_rocauc", auc)                                               # :667-668
+    return None
 
 
 def train_model(args, dataset, device, use_graph: bool = True, log=print, pipeline: bool = True):
@@ -1114,9 +1146,8 @@ def train_model(args, dataset, device, use_graph: bool = True, log=print, pipeli
         graphed = cls(args, model, optimizer, scheduler, criterion, device,
                       args.batch_size // world, args.num_channels, args.sig_len,
                       sync=FlatGradSync(model, device) if distributed else None)
-    perf = {k: [] for k in ("epochs", "steps", "train_loss", "train_accuracy", "test_accuracy",
-                            "test_loss", "test_sensitivity", "test_specificity", "test_f1",
-                            "test_rocauc", "times")}
+    performance = performance_metrics_class()                                           # :421
+    perf = performance.dict
     plot_epochs = set(np.linspace(1, args.num_epochs, 11).astype("int").tolist())       # :424
     args.depth = 0
     t_sum = 0.0
@@ -1143,20 +1174,19 @@ def train_model(args, dataset, device, use_graph: bool = True, log=print, pipeli
                 break
         t_sum += _time.time() - t0
         if epoch in plot_epochs:
-            ev = test_data_accuracy(args, model, test_loader, device, criterion)
-            perf["epochs"].append(epoch)
-            perf["steps"].append(step_counter.count)
-            perf["train_loss"].append(float(stats["loss_sum"]) / max(1, n_batches))
-            perf["train_accuracy"].append(100.0 * float(stats["hits"]) / max(1, stats["seen"]))
-            for k_out, k_in in (("test_accuracy", "accuracy"), ("test_loss", "loss"),
-                                ("test_sensitivity", "sensitivity"), ("test_specificity", "specificity"),
-                                ("test_f1", "f1"), ("test_rocauc", "rocauc")):
-                perf[k_out].append(ev[k_in])
-            perf["times"].append(t_sum)
+            performance.add("epochs", epoch)                                            # :447-455
+            performance.add("steps", step_counter.count)
+            performance.add("train_loss", float(stats["loss_sum"]) / max(1, n_batches))
+            performance.add("train_accuracy", 100.0 * float(stats["hits"]) / max(1, stats["seen"]))
+            try:
+                test_data_accuracy(args, model, test_loader, device, criterion, epoch, performance)
+            except IndexError:                    # '(class_majority)': the reference stops here (:667)
+                performance.add("test_rocauc", None)
+            performance.add("times", t_sum)
             if rank == 0 and log is not None:
                 log(f"epoch {epoch:3d} step {step_counter.count:6d} train loss "
                     f"{perf['train_loss'][-1]:.4f} acc {perf['train_accuracy'][-1]:.1f}%  "
-                    f"test acc {ev['accuracy']:.1f}%")
+                    f"test acc {perf['test_accuracy'][-1]:.1f}%")
     out_dir = getattr(args, "EXPERIMENTS", None)
     if out_dir and rank == 0:
         exp = _sal.experiment_dir(args)

@@ -45,6 +45,12 @@ def eval_pool(seed=EVAL_SEED):
     return x[order], labels[order], [wav[i] for i in order]
 
 
+class ListLoader(list):
+    """A list of batches with the ``.dataset`` attribute test_data_accuracy takes len() of
+    (train_model.py:653)."""
+    dataset = None
+
+
 def eval_loader():
     x, labels, wav = eval_pool()
     return [(torch.from_numpy(x[i:i + 24]), torch.from_numpy(labels[i:i + 24]), None,

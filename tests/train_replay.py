@@ -5,6 +5,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import GOLDEN
@@ -139,6 +140,28 @@ def check_evaluation(device):
             assert ev["rocauc"] is None         # the reference raises IndexError there (:667)
         else:
             assert abs(ev["rocauc"] - float(g[f"eval_{tag}_rocauc"])) <= 1e-12
+        # the reference's own call (train_model.py:455): seven positional arguments, results pushed
+        # into the performance object, nothing returned; the golden holds what the reference's
+        # performance.dict held after that call (make_golden_train.py)
+        perf = tm.performance_metrics_class()
+        ld = train_cases.ListLoader(loader)
+        ld.dataset = range(48)
+        if int(g[f"eval_{tag}_rocauc_raises"]):
+            with pytest.raises(IndexError):
+                tm.test_data_accuracy(A, m, ld, device, crit, 1, perf)
+        else:
+            assert tm.test_data_accuracy(A, m, ld, device, crit, 1, perf) is None
+        assert set(perf.dict) == {"steps", "epochs", "times", "train_loss", "train_accuracy",
+                                  "test_loss", "test_accuracy", "test_specificity",
+                                  "test_sensitivity", "test_precision", "test_recall", "test_f1",
+                                  "test_rocauc"}                        # :180-193
+        for k in ("accuracy", "loss", "specificity", "sensitivity", "f1", "precision", "recall",
+                  "rocauc"):
+            got, want = perf.dict["test_" + k], float(g[f"eval_{tag}_{k}"])
+            if np.isnan(want):
+                assert got == []                # the reference never appended it (:667 raised)
+            else:
+                assert len(got) == 1 and abs(got[0] - want) <= (1e-5 if k == "loss" else 1e-9), (tag, k)
     assert float(g["eval_mean_accuracy"]) != float(g["eval_cm_accuracy"])      # the rules differ here
 
 
