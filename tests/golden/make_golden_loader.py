@@ -52,6 +52,43 @@ CONFIGS = [dict(train_balance=True, n_fraction=1.0, valid=False, seed=4, seed_da
            dict(train_balance=True, n_fraction=0.5, valid=True, seed=3, seed_data=11)]
 
 
+RUN_ARGS = dict(dataset="PhysioNet", seed_data=1100001, n_fraction=1.0, batch_size=16, num_classes=2,
+                sample_rate=1000, num_channels=4, seed=4, train_balance=True, method="durratiomixup",
+                valid=False, classical_space=False)
+RUN_EPOCHS = 2
+
+
+def record_run(dl, ds):
+    """What the reference's ``physionet_dataloader(args, ds).run('train', 4)`` (a real
+    ``DataLoader(shuffle=True, drop_last=True)``, dataloader_physionet.py:204-229) yields over two
+    epochs seeded as ``train_epoch`` seeds them (train_model.py:497): per batch the dataset indices,
+    labels, frames, recording ids and the cycles themselves.  ``torch_audiomentations`` is not
+    installed; the loader's only use of it is ``Compose([Identity()])`` (:191-194), served here as
+    the identity function it is."""
+    import torch
+    dl.torch_audiomentations.Compose = lambda transforms: (lambda x, sample_rate=None: x)
+    a = argparse.Namespace(**RUN_ARGS)
+    loader, labels = dl.physionet_dataloader(a, ds).run("train", 4)
+    out = {"run_labels": np.asarray(labels), "run_len": np.int64(len(loader))}
+    count = 0
+    for e in range(RUN_EPOCHS):
+        torch.manual_seed(a.seed * 635410 + count)                    # train_model.py:497
+        idx, tgt, fr, wav, data = [], [], [], [], []
+        for d, t, f, w, _q, i in loader:
+            idx.append(i.numpy()); tgt.append(t.numpy()); fr.append(f.numpy())
+            wav.append(np.array(w)); data.append(d.numpy())
+            count += 1
+        out[f"run_e{e}_idx"] = np.stack(idx)
+        out[f"run_e{e}_target"] = np.stack(tgt)
+        out[f"run_e{e}_frames"] = np.stack(fr)
+        out[f"run_e{e}_wav"] = np.stack(wav)
+        out[f"run_e{e}_data"] = np.stack(data).astype(np.float32)
+    test = dl.physionet_dataloader(a, ds).run("test", None)
+    out["run_test_wav"] = np.concatenate([np.array(b[3]) for b in test])
+    out["run_test_data_sum"] = np.concatenate([b[0].numpy().reshape(len(b[1]), -1).sum(1) for b in test])
+    return out
+
+
 def main():
     ref = importlib.import_module("_ref_import").import_reference()
     dl = importlib.import_module("dataloader_physionet")        # the reference's module
@@ -81,6 +118,7 @@ def main():
                              method="base", valid=False, classical_space=False)
     out["test_wav"] = np.array(t.test_wav)
     out["test_data_shape"] = np.array(np.array(t.test_data).shape)
+    out.update(record_run(dl, ds))
     np.savez_compressed(os.path.join(HERE, "loader_selection.npz"), **out)
     print("loader_selection.npz:", os.path.getsize(os.path.join(HERE, "loader_selection.npz")) // 1024, "KiB",
           {k: v.shape for k, v in list(out.items())[:4]})

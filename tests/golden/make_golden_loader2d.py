@@ -42,6 +42,33 @@ CONFIGS2D = [dict(n_fraction=1.0, valid=False, seed=4, seed_data=1100001),
              dict(n_fraction=0.6, valid=True, seed=5, seed_data=11)]
 
 
+RUN2D_ARGS = dict(dataset="PhysioNet(spec128)", seed_data=1100001, n_fraction=1.0, batch_size=8,
+                  num_classes=2, num_channels=1, seed=4, method="durratiomixup", valid=False)
+RUN2D_EPOCHS = 2
+
+
+def record_run2d(dl, ds):
+    """The batches of the reference's ``physionet_dataloader(args, ds).run('train', 4)``
+    (dataloader_physionet2d.py:137-157) over two epochs seeded as train_model.py:497 does."""
+    import argparse
+    import torch
+    a = argparse.Namespace(**RUN2D_ARGS)
+    loader, labels = dl.physionet_dataloader(a, ds).run("train", 4)
+    out = {"run_labels": np.asarray(labels), "run_len": np.int64(len(loader))}
+    count = 0
+    for e in range(RUN2D_EPOCHS):
+        torch.manual_seed(a.seed * 635410 + count)
+        idx, tgt, wav, data = [], [], [], []
+        for d, t, _f, w, _q, i in loader:
+            idx.append(i.numpy()); tgt.append(t.numpy()); wav.append(np.array(w)); data.append(d.numpy())
+            count += 1
+        out[f"run_e{e}_idx"] = np.stack(idx)
+        out[f"run_e{e}_target"] = np.stack(tgt)
+        out[f"run_e{e}_wav"] = np.stack(wav)
+        out[f"run_e{e}_data"] = np.stack(data).astype(np.float32)
+    return out
+
+
 def main():
     importlib.import_module("_ref_import").import_reference()
     dl = importlib.import_module("dataloader_physionet2d")        # the reference's module
@@ -63,6 +90,7 @@ def main():
     out["test_wav"] = np.array(t.test_wav)
     item = t[3]
     out["test_item3_shape"] = np.array(item[0].shape)
+    out.update(record_run2d(dl, ds))
     path = os.path.join(HERE, "loader2d_selection.npz")
     np.savez_compressed(path, **out)
     print("loader2d_selection.npz:", os.path.getsize(path) // 1024, "KiB")

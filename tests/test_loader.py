@@ -129,3 +129,84 @@ def test_dataloader2d_run_interface():
     test = dl2.physionet_dataloader(a, ds).run("test", None)
     assert [w for b in test for w in b[3]] == g["test_wav"].tolist()
     assert list(next(iter(test))[0].shape[1:]) == g["test_item3_shape"].tolist()
+
+
+# ---- the loader's batches against the reference's DataLoader (round 4) --------------------------
+from make_golden_loader import RUN_ARGS, RUN_EPOCHS  # noqa: E402
+
+
+def _check_run_against_reference(golden, device):
+    """``physionet_dataloader(args, ds).run('train', 4)`` for two epochs, seeded as train_epoch
+    seeds them (train_model.py:497), against what the reference's own
+    ``DataLoader(shuffle=True, drop_last=True)`` yielded (dataloader_physionet.py:204-229, recorded
+    by make_golden_loader.record_run): same indices, labels, frames, recording ids and cycles,
+    batch by batch; the gathered data lives on ``device``."""
+    a = argparse.Namespace(**RUN_ARGS)
+    if device is not None:
+        a.device = device
+    loader, labels = dl.physionet_dataloader(a, synthetic_dataset()).run("train", 4)
+    assert np.array_equal(labels, golden["run_labels"]) and len(loader) == int(golden["run_len"])
+    count = 0
+    for e in range(RUN_EPOCHS):
+        torch.manual_seed(a.seed * 635410 + count)
+        n = 0
+        for b, (data, target, frames, wav, _q, idx) in enumerate(loader):
+            if device is not None:
+                assert data.device.type == device.type and data.is_contiguous()
+            assert target.dtype == torch.int64 and frames.dtype == torch.int64
+            assert np.array_equal(idx.numpy(), golden[f"run_e{e}_idx"][b])
+            assert np.array_equal(target.numpy(), golden[f"run_e{e}_target"][b])
+            assert np.array_equal(frames.numpy(), golden[f"run_e{e}_frames"][b])
+            assert list(wav) == golden[f"run_e{e}_wav"][b].tolist()
+            assert np.array_equal(data.cpu().numpy(), golden[f"run_e{e}_data"][b])     # bit for bit
+            count += 1
+            n += 1
+        assert n == int(golden["run_len"])
+    test = dl.physionet_dataloader(a, synthetic_dataset()).run("test", None)
+    assert [w for b in test for w in b[3]] == golden["run_test_wav"].tolist()
+    got = np.concatenate([b[0].cpu().numpy().reshape(len(b[1]), -1).sum(1) for b in test])
+    assert np.allclose(got, golden["run_test_data_sum"], rtol=0, atol=1e-4)
+
+
+def test_run_batches_match_reference_dataloader_cpu(golden):
+    _check_run_against_reference(golden, None)
+
+
+@pytest.mark.gpu
+def test_run_batches_match_reference_dataloader_on_device(golden, device):
+    """§8 f2 on the GPU: the device-resident gather yields the reference DataLoader's batches."""
+    _check_run_against_reference(golden, device)
+
+
+from make_golden_loader2d import RUN2D_ARGS, RUN2D_EPOCHS  # noqa: E402
+
+
+def _check_run2d_against_reference(device):
+    from pcgmix_amd import dataloader_physionet2d as dl2
+    g = np.load(os.path.join(GOLDEN, "loader2d_selection.npz"))
+    a = argparse.Namespace(**RUN2D_ARGS)
+    if device is not None:
+        a.device = device
+    loader, labels = dl2.physionet_dataloader(a, synthetic_dataset2d()).run("train", 4)
+    assert np.array_equal(labels, g["run_labels"]) and len(loader) == int(g["run_len"])
+    count = 0
+    for e in range(RUN2D_EPOCHS):
+        torch.manual_seed(a.seed * 635410 + count)
+        for b, (data, target, _f, wav, _q, idx) in enumerate(loader):
+            if device is not None:
+                assert data.device.type == device.type
+            assert np.array_equal(idx.numpy(), g[f"run_e{e}_idx"][b])
+            assert np.array_equal(target.numpy(), g[f"run_e{e}_target"][b])
+            assert list(wav) == g[f"run_e{e}_wav"][b].tolist()
+            assert np.array_equal(data.cpu().numpy(), g[f"run_e{e}_data"][b])
+            count += 1
+    assert count == RUN2D_EPOCHS * int(g["run_len"])
+
+
+def test_run2d_batches_match_reference_dataloader_cpu():
+    _check_run2d_against_reference(None)
+
+
+@pytest.mark.gpu
+def test_run2d_batches_match_reference_dataloader_on_device(device):
+    _check_run2d_against_reference(device)
