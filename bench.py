@@ -195,23 +195,27 @@ def karg_unroll(B, C, T, warp):
     return u.value if _lib.load().pcgmix_mix_karg_variant(B, C, T, ctypes.byref(u)) else 0
 
 
-def mix_kernel_name(B, C, T, warp):
+def mix_kernel_name(B, C, T, n_knots):
     """Name of the instantiation the drop-in step launches for this problem (asked from the
-    library: the choice of lane width and unroll lives there)."""
-    u = karg_unroll(B, C, T, warp)
+    library: the choice of lane width and unroll lives there).  n_knots = 0: no warp."""
+    u = karg_unroll(B, C, T, n_knots)
     if u:
         return f"pcgmix::mix_warp_karg_kernel<false, {u}>"
-    return mix_warp_kernel_name(B, C, T, warp)
+    return mix_warp_kernel_name(B, C, T, n_knots)
 
 
-def mix_warp_kernel_name(B, C, T, warp):
+def mix_warp_kernel_name(B, C, T, n_knots, zero_rect=False):
     """Name of the instantiation pcgmix_mix_warp_f32 launches (index block in device memory)."""
     import ctypes
     from pcgmix_amd import _lib
     buf = ctypes.create_string_buffer(96)
-    _lib.check(_lib.load().pcgmix_mix_kernel_name(B, C, T, int(bool(warp)), 1, buf, 96),
-               "pcgmix_mix_kernel_name")
+    _lib.check(_lib.load().pcgmix_mix_kernel_name(B, C, T, int(n_knots), int(bool(zero_rect)), 1,
+                                                  buf, 96), "pcgmix_mix_kernel_name")
     return buf.value.decode()
+
+
+def _n_knots(plan):
+    return 0 if plan.knots is None else int(plan.knots.shape[1])
 
 
 def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200, per_launch=False, info=None):
@@ -226,7 +230,7 @@ def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200, per_launch=
     plan = hostprep.make_plan(method, labels, frames, wav, 1, B, C)
     if info is not None:
         info["exact_bytes"] = exact_mix_bytes(frames, plan.mix, C, T)
-        info["kernel"] = mix_kernel_name(B, C, T, plan.knots is not None)
+        info["kernel"] = mix_kernel_name(B, C, T, _n_knots(plan))
     with torch.cuda.device(device):
         dev, offs = augmentations.upload_plan(plan, frames, device)
     base = dev.data_ptr()

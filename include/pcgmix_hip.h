@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 13
+#define PCGMIX_ABI_VERSION 14
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -627,8 +627,11 @@ long long pcgmix_ctx_phase_times(pcgmix_ctx* ctx, double* out8);
  * lane (1, 2, 4).  For reporting: the kernel's name is mix_warp_kernel<vec, warp, unroll>. */
 int pcgmix_mix_variant(int B, int C, int T, int warp, int aligned16, int* vec, int* unroll);
 /* Name of the kernel instantiation pcgmix_mix_warp_f32 launches for this problem, as rocprofv3
- * lists it (e.g. "pcgmix::mix_warp_tq_kernel<2, 1>"), written NUL-terminated into buf. */
-int pcgmix_mix_kernel_name(int B, int C, int T, int warp, int aligned16, char* buf, int buf_len);
+ * lists it (e.g. "pcgmix::mix_warp_tq_kernel<2, 1>"), written NUL-terminated into buf.  n_knots = 0:
+ * no warp; zero_rect != 0: the call carries 2D mask rectangles.  Asks the same selection routine
+ * the launcher uses. */
+int pcgmix_mix_kernel_name(int B, int C, int T, int n_knots, int zero_rect, int aligned16, char* buf,
+                           int buf_len);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm (training mode) + ReLU + MaxPool of a ResNet9 block, channels innermost.  [device]

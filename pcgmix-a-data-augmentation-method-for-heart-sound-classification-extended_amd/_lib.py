@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -108,7 +108,8 @@ SIGNATURES = {
     "pcgmix_ctx_labels_wait": (_c_int, [_ptr, _ptr, _c_int, _ptr]),
     "pcgmix_augment_plain_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _ptr, ctypes.c_uint64,
                                           _c_float, _ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr]),
-    "pcgmix_mix_kernel_name": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_char_p, _c_int]),
+    "pcgmix_mix_kernel_name": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_char_p,
+                                        _c_int]),
     "pcgmix_mix_variant": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_int),
                                     ctypes.POINTER(_c_int)]),
     "pcgmix_bnrp_workspace_floats": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int]),

@@ -556,26 +556,59 @@ extern "C" int pcgmix_mix_variant(int B, int C, int T, int warp, int aligned16, 
   return hipSuccess;
 }
 
-// Name of the kernel instantiation pcgmix_mix_warp_f32 launches for this problem (what rocprofv3
-// lists), so that a benchmark can match its own timing with the profiler's rows.
-extern "C" int pcgmix_mix_kernel_name(int B, int C, int T, int warp, int aligned16, char* buf,
-                                      int buf_len) {
-  if (B < 0 || C <= 0 || T <= 0 || !buf || buf_len <= 0) return hipErrorInvalidValue;
-  const bool vec4 = (T % 4 == 0) && aligned16;
+// Which instantiation launch_mix_warp launches — the ONE place that decides it (the launcher and the
+// name query below both ask here, so a benchmark cannot pair its timing with the wrong rocprofv3 row).
+namespace pcgmix {
+struct MixVariant {
+  bool tq;         // mix_warp_tq_kernel<CG, UT> (one lane = one position quad for all channels)
+  int CG, UT;      // tq: channels whose loads a lane keeps in flight; quads per lane
+  int vec, U;      // otherwise mix_warp_kernel<vec, warp, U>
+  size_t lds_tq;   // tq: records | thresholds (padded to 8 bytes) | staged operator | staged knots
+};
+static MixVariant choose_mix_variant(long long B, int C, int T, bool vec4, int n_knots,
+                                     bool zero_rect) {
+  MixVariant v{};
+  const bool warp = n_knots > 0;
   const long long plane = (long long)C * T;
-  if (vec4 && warp && getenv("PCGMIX_NO_WARP_TQ") == nullptr && C <= 64) {
-    int UT = (C % 4 != 0 && T >= 4096 && (long long)B * plane >= (64LL << 20)) ? 2 : 1;
-    if (const char* env = getenv("PCGMIX_WARP_TQ_UT")) UT = atoi(env) == 2 ? 2 : 1;
-    int CG = (C % 2 == 0 && (long long)B * plane < (64LL << 20)) ? 2 : 1;
-    if (const char* env = getenv("PCGMIX_WARP_TQ_CG")) {
-      const int v = atoi(env);
-      if ((v == 1 || v == 2 || v == 4) && C % v == 0) CG = v;
-    }
-    snprintf(buf, (size_t)buf_len, "pcgmix::mix_warp_tq_kernel<%d, %d>", CG, UT);
-    return hipSuccess;
+  v.vec = vec4 ? 4 : 1;
+  v.U = vec4 ? choose_unroll(B, plane, warp) : 1;
+  static const bool tq_ok = getenv("PCGMIX_NO_WARP_TQ") == nullptr;     // tuning / A-B runs
+  if (!(vec4 && warp && !zero_rect && tq_ok && C <= 64)) return v;
+  v.lds_tq = sizeof(double) * ((size_t)C * (n_knots - 1) * kRec + (size_t)n_knots +
+                               4 * (size_t)(n_knots - 1) * n_knots + (size_t)n_knots * C) +
+             sizeof(int) * (size_t)((n_knots + 1) & ~1);
+  if (v.lds_tq > 64 * 1024) return v;
+  v.tq = true;
+  // two quads per lane only where the registers allow it (CG = 4, UT = 2 needs 256 VGPRs)
+  v.UT = (C % 4 != 0 && T >= 4096 && B * plane >= (64LL << 20)) ? 2 : 1;
+  if (const char* env = getenv("PCGMIX_WARP_TQ_UT")) v.UT = atoi(env) == 2 ? 2 : 1;     // tuning runs
+  // channels whose loads a lane keeps in flight.  Measured at C = 4 (MI355X, back to back):
+  // (256,4,5000) 14.2 / 11.9 / 12.1 us for 4 / 2 / 1, saturating 16384x4x5000 672 / 596 / 573 us
+  // (fewer registers, more waves: 144 / 94 / 76 VGPRs)
+  v.CG = (C % 2 == 0 && B * plane < (64LL << 20)) ? 2 : 1;
+  if (const char* env = getenv("PCGMIX_WARP_TQ_CG")) {  // tuning runs
+    const int e = atoi(env);
+    if ((e == 1 || e == 2 || e == 4) && C % e == 0) v.CG = e;
   }
-  snprintf(buf, (size_t)buf_len, "pcgmix::mix_warp_kernel<%d, %s, %d>", vec4 ? 4 : 1,
-           warp ? "true" : "false", vec4 ? pcgmix::choose_unroll(B, plane, warp != 0) : 1);
+  return v;
+}
+}  // namespace pcgmix
+
+// Name of the kernel instantiation pcgmix_mix_warp_f32 launches for this problem (what rocprofv3
+// lists), so that a benchmark can match its own timing with the profiler's rows.  n_knots = 0: no
+// warp; zero_rect: the call carries 2D mask rectangles.
+extern "C" int pcgmix_mix_kernel_name(int B, int C, int T, int n_knots, int zero_rect,
+                                      int aligned16, char* buf, int buf_len) {
+  if (B < 0 || C <= 0 || T <= 0 || n_knots < 0 || n_knots == 1 || n_knots > 64 || !buf ||
+      buf_len <= 0)
+    return hipErrorInvalidValue;
+  const bool vec4 = (T % 4 == 0) && aligned16;
+  const pcgmix::MixVariant v = pcgmix::choose_mix_variant(B, C, T, vec4, n_knots, zero_rect != 0);
+  if (v.tq)
+    snprintf(buf, (size_t)buf_len, "pcgmix::mix_warp_tq_kernel<%d, %d>", v.CG, v.UT);
+  else
+    snprintf(buf, (size_t)buf_len, "pcgmix::mix_warp_kernel<%d, %s, %d>", v.vec,
+             n_knots ? "true" : "false", v.U);
   return hipSuccess;
 }
 
@@ -686,36 +719,21 @@ int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, con
     else if (U == 2) PCGMIX_LAUNCH(4, W, 2);              \
     else PCGMIX_LAUNCH(4, W, 1);                          \
   } while (0)
-  static const bool tq_ok = getenv("PCGMIX_NO_WARP_TQ") == nullptr;     // tuning / A-B runs
-  if (vec4 && warp && !zero_rect && tq_ok && C <= 64) {
+  const MixVariant mv = choose_mix_variant(B, C, T, vec4, warp ? n_knots : 0, zero_rect != nullptr);
+  if (mv.tq) {
     // one lane = one position quad for all channels (mix_warp_tq_kernel)
-    // two quads per lane only where the registers allow it (CG = 4, UT = 2 needs 256 VGPRs)
-    int UT = (C % 4 != 0 && T >= 4096 && (long long)B * plane >= (64LL << 20)) ? 2 : 1;
-    if (const char* env = getenv("PCGMIX_WARP_TQ_UT")) UT = atoi(env) == 2 ? 2 : 1;     // tuning runs
-    // records | thresholds (padded to 8 bytes) | staged operator | staged knots of the sample
-    const size_t lds_tq = sizeof(double) * ((size_t)C * (n_knots - 1) * kRec + (size_t)n_knots +
-                                            4 * (size_t)(n_knots - 1) * n_knots + (size_t)n_knots * C) +
-                          sizeof(int) * (size_t)((n_knots + 1) & ~1);
-    if (lds_tq <= 64 * 1024) {
-      dim3 grid_tq((unsigned)((T + kThreads * 4 * UT - 1) / (kThreads * 4 * UT)), gy, gz);
+    const int UT = mv.UT, CG = mv.CG;
+    const size_t lds_tq = mv.lds_tq;
+    dim3 grid_tq((unsigned)((T + kThreads * 4 * UT - 1) / (kThreads * 4 * UT)), gy, gz);
 #define PCGMIX_LAUNCH_TQ(CGV, UTV)                                                                  \
   hipLaunchKernelGGL((mix_warp_tq_kernel<CGV, UTV>), grid_tq, block, lds_tq, s, x, y, frames,        \
                      mix_idx, off, lam, oml, knots, spline_op, n_knots, B, C, T, pay_src, pay_dst,  \
                      pay_n16, disp_part, pk)
-      // channels whose loads a lane keeps in flight.  Measured at C = 4 (MI355X, back to back):
-      // (256,4,5000) 14.2 / 11.9 / 12.1 us for 4 / 2 / 1, saturating 16384x4x5000 672 / 596 / 573 us
-      // (fewer registers, more waves: 144 / 94 / 76 VGPRs)
-      int CG = (C % 2 == 0 && (long long)B * plane < (64LL << 20)) ? 2 : 1;
-      if (const char* env = getenv("PCGMIX_WARP_TQ_CG")) {  // tuning runs
-        const int v = atoi(env);
-        if ((v == 1 || v == 2 || v == 4) && C % v == 0) CG = v;
-      }
-      if (CG == 4) { if (UT == 2) PCGMIX_LAUNCH_TQ(4, 2); else PCGMIX_LAUNCH_TQ(4, 1); }
-      else if (CG == 2) { if (UT == 2) PCGMIX_LAUNCH_TQ(2, 2); else PCGMIX_LAUNCH_TQ(2, 1); }
-      else { if (UT == 2) PCGMIX_LAUNCH_TQ(1, 2); else PCGMIX_LAUNCH_TQ(1, 1); }
+    if (CG == 4) { if (UT == 2) PCGMIX_LAUNCH_TQ(4, 2); else PCGMIX_LAUNCH_TQ(4, 1); }
+    else if (CG == 2) { if (UT == 2) PCGMIX_LAUNCH_TQ(2, 2); else PCGMIX_LAUNCH_TQ(2, 1); }
+    else { if (UT == 2) PCGMIX_LAUNCH_TQ(1, 2); else PCGMIX_LAUNCH_TQ(1, 1); }
 #undef PCGMIX_LAUNCH_TQ
-      return (int)hipGetLastError();
-    }
+    return (int)hipGetLastError();
   }
   if (vec4) {
     if (warp) PCGMIX_LAUNCH_U(true); else PCGMIX_LAUNCH_U(false);

@@ -179,6 +179,10 @@ class ClipAdam(torch.optim.Adam):
             steps = {int(self.state[p]["step"]) for p in live}
             if len(steps) != 1:
                 raise RuntimeError("ClipAdam: parameters of one group must share the step count")
+            if self._cap_params:
+                # an eager step between captured ones (train_epoch: a batch of another shape) counts
+                # for the captured launches too: their bias corrections continue from here
+                self._cap_step = next(iter(steps))
             tab = self._table(gi, live, self._dense_grads(live))
             dev = live[0].device
             stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -200,6 +204,7 @@ class ClipAdam(torch.optim.Adam):
     def prepare_capture(self, params):
         """Before the capture: allocate the moments of ``params`` (the tensors that will carry a
         gradient) — an allocation inside the capture would be re-zeroed by every replay."""
+        self._flush_captured_steps()                 # re-capture: the state carries the live count
         self._init_state(params)
         steps = {int(self.state[p]["step"]) for p in params}
         if len(steps) != 1:
@@ -650,7 +655,8 @@ class GraphedTrainStep:
                 models.PotesStackFunction.defer_reduce = None
                 _lib.TAPE = None
         self.tape = None
-        if tape is not None and [t[0] for t in tape] == list(self._TAPE_LAUNCHES):
+        if tape is not None and [t[0] for t in tape] == list(self._TAPE_LAUNCHES) \
+                and self._tape_covers_capture(tape, fold):
             import ctypes
             # pointer tables are snapshotted: ClipAdam re-uses its ctypes arrays for the next capture
             # (a second slot of PipelinedTrainStep), a graph node would have copied them too
@@ -666,6 +672,33 @@ class GraphedTrainStep:
             self.graph_update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_update, capture_error_mode="thread_local"):
                 self.opt.capture_update(self.aux[4:12])
+
+    def _tape_covers_capture(self, tape, fold) -> bool:
+        """The tape replaces the graph only if the five recorded launches ARE the capture: no
+        torch-side kernel may sit between them (an AccumulateGrad clone of a head gradient, a
+        dense copy of a stride-mismatched gradient — the tape would skip it and the update would
+        read stale memory).  Checked at build time: every gradient the captured update reads must
+        be (a view of) the very buffer one of the recorded launches was handed — the backward
+        launches' outputs, or the deferred-reduction block the update launch fills."""
+        import ctypes
+        import warnings
+        written = set()
+        for _name, _fn, a in tape:
+            for v in a[:-1]:
+                if isinstance(v, int) and v > 4096:
+                    written.add(v)
+                elif isinstance(v, ctypes.c_void_p) and v.value:
+                    written.add(v.value)
+        for p, g in zip(self.opt._cap_params, self.opt._cap_grads):
+            # (gradients are views: the head's small ones of one block, the stack's of the deferred
+            # block — compare the storage a launch was handed, not the view's own address)
+            if g is not p.grad or g.untyped_storage().data_ptr() not in written:
+                warnings.warn("GraphedTrainStep: the capture holds work besides the five library "
+                              "launches (a gradient of %s is not written by them directly); "
+                              "replaying the hipGraph instead of launching directly"
+                              % (tuple(p.shape),))
+                return False
+        return True
 
     def _fwd_bwd(self):
         fused = fused_loss_model(self.model, self.ce, self.x, self.t, None) \
@@ -871,15 +904,20 @@ class PipelinedTrainStep:
     def step(self, batch, epoch, step_counter, stats: Optional[dict] = None, next_batch=None):
         main = torch.cuda.current_stream(self.device)
         s = self.cur
-        if next_batch is not None:
-            # next_batch exists already (the caller's lookahead fetched it before this call): mark the
-            # point on the main stream BEFORE this step's graph, so that the side stream waits for
-            # the batch and not for the graph it is meant to overlap
-            self._fetched.record(main)
         if self.prepared != id(batch):                  # first step, or the caller gave no lookahead
+            # inline, on the main stream.  Both slots' prepares share the cached saliency graph
+            # (seed, boundaries, activations, map) and the per-device step context (search
+            # workspace): the side stream's prepare(k+1) must not start before THIS prepare's last
+            # kernel has read them, so the hand-over point below is recorded behind it.
             self.slots[s].prepare(batch, epoch, step_counter)
         else:
             main.wait_event(self.ready[s])
+        if next_batch is not None:
+            # next_batch exists already (the caller's lookahead fetched it before this call): mark the
+            # point on the main stream BEFORE this step's graph — and behind an inline prepare — so
+            # that the side stream waits for the batch (and the shared saliency buffers) and not for
+            # the graph it is meant to overlap
+            self._fetched.record(main)
         self.prepared = None
         loss = self.slots[s].launch(step_counter, stats)
         self.done[s].record(main)

@@ -62,8 +62,8 @@ else:
                                  float(plan.lam32), knots_ptr, op_ptr, plan.n_knots, B, C, T)
 torch.cuda.synchronize()
 info = {"mode": mode, "method": method, "B": B, "C": C, "T": T, "iters": iters,
-        "kernel": bench.mix_kernel_name(B, C, T, plan.knots is not None) if mode == "karg" else
-        bench.mix_warp_kernel_name(B, C, T, plan.knots is not None),
+        "kernel": bench.mix_kernel_name(B, C, T, bench._n_knots(plan)) if mode == "karg" else
+        bench.mix_warp_kernel_name(B, C, T, bench._n_knots(plan)),
         "exact_bytes": bench.exact_mix_bytes(frames, plan.mix, C, T),
         "contract_12CT_bytes": 12.0 * B * C * T, "own_plus_write_bytes": 8.0 * B * C * T}
 os.makedirs(out_dir, exist_ok=True)

@@ -556,3 +556,45 @@ def test_clip_adam_captured_update_matches_eager(device):
     assert all(float(v["step"]) == 10.0 for v in sd["state"].values())
     with pytest.raises(RuntimeError):
         oa.load_state_dict(sd)                               # the graph holds the old moments
+
+
+def test_clip_adam_interleaved_captured_and_eager_steps(device):
+    """train_epoch mixes captured steps with eager ones for batches of another shape: the step
+    count (bias corrections) must run through both kinds — captured, captured, EAGER, captured,
+    captured, then a re-capture on the same optimiser — exactly as nine eager steps."""
+    torch.manual_seed(1)
+    shapes = [(20, 1000), (8, 1, 5), (20,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=device)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = tm.ClipAdam(pa, lr=0.01, weight_decay=1e-4, clip_value=0.1)
+    ob = tm.ClipAdam(pb, lr=0.01, weight_decay=1e-4, clip_value=0.1)
+    grads = [torch.zeros_like(p) for p in pa]
+    for p, g in zip(pa, grads):
+        p.grad = g
+    hyper, host = torch.zeros(8, device=device), np.zeros(8, dtype=np.float32)
+
+    def capture():
+        oa.prepare_capture(pa)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            oa.capture_update(hyper)
+        return g
+    graph = capture()
+    for it, kind in enumerate("ccecc" + "R" + "cec"):
+        if kind == "R":
+            graph = capture()                          # key change: a new capture, same optimiser
+            continue
+        for g, y in zip(grads, pb):
+            g.copy_(torch.randn_like(g) * 0.2)
+            y.grad = g.clone()
+        if kind == "c":
+            oa.next_hyper(host)
+            hyper.copy_(torch.from_numpy(host))
+            graph.replay()
+        else:
+            oa.step()
+        ob.step()
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)
+        assert torch.equal(oa.state[x]["exp_avg_sq"], ob.state[y]["exp_avg_sq"])
+    assert all(float(v["step"]) == 8.0 for v in oa.state_dict()["state"].values())

@@ -383,12 +383,18 @@ def test_train_model_driver_on_spectrograms(device, tmp_path):
     assert len(glob.glob(str(tmp_path / "*" / "model.pth"))) == 1
 
 
+@pytest.mark.parametrize("busy", [False, True])
 @pytest.mark.parametrize("method", ["durmixmagwarp(0.2,4)+0.8", "(saloptenv)durmixmagwarp(0.2,4)"])
-def test_pipelined_step_is_bit_identical_to_the_sequential_one(method, device, tmp_path):
+def test_pipelined_step_is_bit_identical_to_the_sequential_one(method, busy, device, tmp_path):
     """PipelinedTrainStep (augmentation of batch k+1 on a side stream while the captured graph of
     batch k replays; two slots) == GraphedTrainStep called batch after batch: same kernels, same
     values, only the stream of the augmentation launches differs — every loss and every parameter
-    bit for bit over 7 steps (dropout ON: the keys advance in the same host order)."""
+    bit for bit over 7 steps (dropout ON: the keys advance in the same host order).
+
+    ``busy``: ~30 ms of GPU work is queued on the main stream in front of the first pipelined
+    step, so the host runs far ahead of the GPU and the first (inline, main-stream) prepare is
+    still pending when the side stream's prepare of batch 1 is issued — both use the shared
+    saliency graph and step context, the hand-over event has to order them."""
     B, T = 32, 2500
     batches = []
     for i in range(7):
@@ -410,6 +416,10 @@ def test_pipelined_step_is_bit_identical_to_the_sequential_one(method, device, t
         g = cls(args, net, opt, sched, crit, device, B, 4, T)
         losses = []
         if mode == "pipelined":
+            if busy:
+                w = torch.randn(4096, 4096, device=device)
+                for _ in range(60):
+                    w = (w @ w).clamp_(-1, 1)
             for b, nxt in tm.PipelinedTrainStep.pairs(batches):
                 losses.append(g.step(b, 1, sc, None, next_batch=nxt).clone())
         else:
