@@ -82,6 +82,42 @@ double pcgmix_py_uniform01(uint64_t seed);
 /* random.Random(seed).randint(0, hi) — the '(rand)' placement offset (augmentations.py:307). */
 int64_t pcgmix_py_randint0(uint64_t seed, int64_t hi);
 
+/* ------------------------------------------------------------------------------------------
+ * numpy's legacy global random stream, restated (host).  csrc/pcgmix_nprand.hip.
+ *
+ * Replaces, bit for bit, the draws the reference takes from it in every step:
+ *     np.random.seed(seed); lam = np.random.beta(alpha, alpha)        augmentations.py:659-666
+ *     np.random.normal(loc=1.0, scale=sigma, size=(B, knot+2, C))     augmentations.py:677
+ * `mt_state` is numpy's own generator state — struct { uint32_t key[624]; int pos; }, the address
+ * np.random.get_bit_generator().ctypes.state_address — or a private copy of that layout; the
+ * functions advance it in place, so the global stream ends where the reference leaves it.
+ * numpy's Gaussian cache flag lives outside that struct: counts of normals must be even (the
+ * cache is then empty before and after, as it is behind np.random.seed).  All return 0, or 1
+ * for arguments outside that contract (the caller then draws with numpy).
+ */
+/* RandomState.seed(int): mt19937_seed / init_genrand. */
+int pcgmix_np_seed(void* mt_state, uint32_t seed);
+/* RandomState.beta(a, b) for a <= 1 and b <= 1 (Johnk's algorithm, legacy_beta). */
+int pcgmix_np_beta(void* mt_state, double a, double b, double* out);
+/* RandomState.normal(loc, scale, n) into out (host, n doubles), n even (legacy_gauss pairs). */
+int pcgmix_np_normal_fill(void* mt_state, double loc, double scale, long long n, double* out);
+
+/* One step's (lambda, knots), drawn one step ahead.  pcgmix_npdraw_step returns what
+ * seed(seed) -> beta(alpha, alpha) -> normal(1, sigma, n) yield: *lam, and *knots -> n doubles in
+ * memory the object owns (valid until the next call on it); `np_state` (numpy's state address, or
+ * NULL) receives the generator state behind the draws.  With `lookahead` = L in 1..3 the object
+ * owns L + 1 worker threads that draw the blocks of seed + 1 .. seed + L (same alpha, sigma, n)
+ * while the caller works on this step; *hit (optional) says whether this call found its block
+ * ready.  Contract: 0 < alpha <= 1, n even.  One caller thread per object; a forked child draws
+ * inline. */
+typedef struct pcgmix_npdraw pcgmix_npdraw;
+int pcgmix_npdraw_create(pcgmix_npdraw** out, int lookahead);
+void pcgmix_npdraw_destroy(pcgmix_npdraw* d);
+int pcgmix_npdraw_step(pcgmix_npdraw* d, uint32_t seed, double alpha, double sigma, long long n,
+                       void* np_state, double* lam, const double** knots, int* hit);
+/* Blocks found ready / drawn inline so far. */
+long long pcgmix_npdraw_stats(pcgmix_npdraw* d, long long* misses);
+
 /* Validate `frames` (int64 (B,5), as the reference's loader yields them) against the signal
  * length and pack the per-step index block read by pcgmix_mix_warp_f32 into `out` (host, e.g.
  * pinned staging): int32 frames[B][5] | mix[B] | rand_off[B][4] (if given) | rect[B][4] (if

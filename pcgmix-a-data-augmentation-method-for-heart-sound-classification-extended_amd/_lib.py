@@ -27,6 +27,14 @@ SIGNATURES = {
     "pcgmix_partner_permutation_i64": (_c_int, [_ptr, _c_int, _c_int, ctypes.c_uint64, _ptr]),
     "pcgmix_py_uniform01": (ctypes.c_double, [ctypes.c_uint64]),
     "pcgmix_py_randint0": (ctypes.c_int64, [ctypes.c_uint64, ctypes.c_int64]),
+    "pcgmix_np_seed": (_c_int, [_ptr, ctypes.c_uint32]),
+    "pcgmix_np_beta": (_c_int, [_ptr, ctypes.c_double, ctypes.c_double, _ptr]),
+    "pcgmix_np_normal_fill": (_c_int, [_ptr, ctypes.c_double, ctypes.c_double, ctypes.c_longlong, _ptr]),
+    "pcgmix_npdraw_create": (_c_int, [_ptr, _c_int]),
+    "pcgmix_npdraw_destroy": (None, [_ptr]),
+    "pcgmix_npdraw_step": (_c_int, [_ptr, ctypes.c_uint32, ctypes.c_double, ctypes.c_double,
+                                    ctypes.c_longlong, _ptr, _ptr, _ptr, _ptr]),
+    "pcgmix_npdraw_stats": (ctypes.c_longlong, [_ptr, _ptr]),
     "pcgmix_pack_plan_i32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _ptr]),
     "pcgmix_mix_warp_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _ptr, _ptr, _c_int,
                                      _ptr, _c_int, _c_int, _c_int, _ptr]),

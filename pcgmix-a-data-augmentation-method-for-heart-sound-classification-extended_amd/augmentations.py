@@ -317,15 +317,10 @@ def splice_plain(recipe, data: torch.Tensor, labels, frames, step: int,
             raise ValueError("labels/frames do not match the batch size")
         lab_ptr = labels.ctypes.data
     fr_ptr, fr_keep = _frames_ptr(frames, B)
-    if alpha > 0.0:
-        np.random.seed(step)                      # global stream, as the reference
-        lam = np.random.beta(alpha, alpha)        # c_float rounds like np.float32 (:903)
-    else:
-        lam = 1.0
-    knots = knots_ptr = None
-    if n_knots:
-        knots = np.random.normal(loc=1.0, scale=sigma, size=(B, n_knots, C))
-        knots_ptr = knots.ctypes.data
+    # numpy's global stream, as the reference: seed -> beta -> normal (c_float rounds lam like
+    # np.float32, :903); the block was usually drawn ahead by the library (hostprep)
+    lam, knots = hostprep.draw_lambda_knots(step, alpha, sigma, B * n_knots * C)
+    knots_ptr = knots.ctypes.data if isinstance(knots, np.ndarray) else knots
     if out is None:
         out = torch.empty_like(data)
     elif out.shape != data.shape or out.dtype != data.dtype or not out.is_contiguous() \
@@ -389,15 +384,10 @@ def _salopt_step(srec, g, data: torch.Tensor, ohe: Optional[torch.Tensor], label
     else:
         with torch.cuda.device(data.device):
             sal = g.replay(data)
-    if alpha > 0.0:
-        np.random.seed(step)                      # global stream, as the reference
-        lam = np.random.beta(alpha, alpha)        # c_float rounds like np.float32 (:903)
-    else:
-        lam = 1.0
-    knots = knots_ptr = None
-    if n_knots:
-        knots = np.random.normal(loc=1.0, scale=sigma, size=(B, n_knots, C))
-        knots_ptr = knots.ctypes.data
+    # numpy's global stream, as the reference: seed -> beta -> normal (c_float rounds lam like
+    # np.float32, :903); the block was usually drawn ahead by the library (hostprep)
+    lam, knots = hostprep.draw_lambda_knots(step, alpha, sigma, B * n_knots * C)
+    knots_ptr = knots.ctypes.data if isinstance(knots, np.ndarray) else knots
     if out is None:
         out = torch.empty_like(data)
     mix = np.empty(B, dtype=np.int64)

@@ -248,6 +248,80 @@ def mask_rectangles(method: str, name: str, frames: np.ndarray, step: int, n_row
     return rect
 
 
+# ---- numpy's global stream: lambda and the warp knots ---------------------------------------------
+_NPDRAW = None        # (handle, lam, knots pointer, hit) of the process-wide draw object
+_NP_GLOBAL = None     # (bit generator of numpy's global RandomState, address of its MT19937 state)
+
+
+def _npdraw():
+    global _NPDRAW
+    if _NPDRAW is None:
+        import ctypes
+        import os
+        h = ctypes.c_void_p()
+        look = max(0, min(3, int(os.environ.get("PCGMIX_NPDRAW_LOOKAHEAD", "2"))))
+        if _lib.load().pcgmix_npdraw_create(ctypes.byref(h), look):
+            raise RuntimeError("pcgmix_npdraw_create failed")
+        _NPDRAW = (h, ctypes.c_double(), ctypes.c_void_p(), ctypes.c_int())
+    return _NPDRAW
+
+
+def _numpy_global_state():
+    """(lock, address) of the MT19937 state behind ``np.random.seed/beta/normal``, or None when
+    the global RandomState runs on another bit generator (``np.random.set_bit_generator``)."""
+    global _NP_GLOBAL
+    bg = np.random.get_bit_generator()
+    if _NP_GLOBAL is None or _NP_GLOBAL[0] is not bg:
+        addr = bg.ctypes.state_address if type(bg).__name__ == "MT19937" else None
+        _NP_GLOBAL = (bg, bg.lock, addr)
+    return _NP_GLOBAL[1], _NP_GLOBAL[2]
+
+
+def draw_lambda_knots(step: int, alpha: float, sigma: float, count: int):
+    """``np.random.seed(step); lam = np.random.beta(alpha, alpha)`` (augmentations.py:661-663) and,
+    for ``count`` > 0, ``np.random.normal(1.0, sigma, count)`` right behind it (:677) — the same
+    doubles, and numpy's GLOBAL stream left exactly where the reference leaves it (asserted by
+    tests/test_host_logic.py against numpy itself).  Returns (lam, knots) with knots = the host
+    address of ``count`` float64 (library memory, valid until the next call), an ndarray on the
+    fallback path, or None.
+
+    The 6144 normals of a (256, 6, 4) block cost numpy ~110 us per step — ten times the kernel they
+    feed.  The library restates the legacy stream (csrc/pcgmix_nprand.hip) and draws the blocks of
+    the NEXT steps on worker threads (they depend on (step, alpha, sigma, count) only); a matching
+    call picks its block up and writes the final generator state into numpy's own state memory.
+    Outside that restatement's contract (alpha <= 0: the reference does not seed; alpha > 1:
+    gamma-based beta; an odd count: numpy's Gaussian cache would be left full; a foreign bit
+    generator) the draws are numpy's own calls."""
+    lock, addr = _numpy_global_state()
+    if 0.0 < alpha <= 1.0 and count > 0 and not (count & 1) and addr is not None \
+            and 0 <= step <= 0xFFFFFFFF:
+        import ctypes
+        h, lam, kp, hit = _npdraw()
+        np.random.seed(step)                # key (overwritten below) AND the empty Gaussian cache
+        with lock:
+            err = _lib.load().pcgmix_npdraw_step(h, step, alpha, sigma, count, addr,
+                                                 ctypes.byref(lam), ctypes.byref(kp), ctypes.byref(hit))
+        if err:
+            raise RuntimeError("pcgmix_npdraw_step refused a draw inside its contract")
+        return lam.value, kp.value
+    if alpha > 0.0:
+        np.random.seed(step)                # global stream, as the reference (side effect kept)
+        lam = float(np.random.beta(alpha, alpha))
+    else:
+        lam = 1.0
+    knots = np.random.normal(loc=1.0, scale=sigma, size=count) if count else None
+    return lam, knots
+
+
+def knots_array(knots, shape) -> np.ndarray:
+    """``draw_lambda_knots``'s knots as an owned float64 array of ``shape`` (as numpy fills it)."""
+    if isinstance(knots, np.ndarray):
+        return knots.reshape(shape)
+    import ctypes
+    n = int(np.prod(shape))
+    return np.frombuffer((ctypes.c_double * n).from_address(knots), dtype=np.float64).reshape(shape).copy()
+
+
 def validate_frames(frames: np.ndarray, sig_len: int) -> None:
     """The reference silently mis-slices (and usually raises a shape error) when a cycle runs
     past the padded length; refuse such input up front."""
@@ -279,17 +353,13 @@ def make_plan(method: str, labels, frames: np.ndarray, wav: Sequence[str], step:
     # so the order BETWEEN the two streams is free — a callable `labels` that has to wait for the
     # GPU is asked as late as possible, after the ~0.1 ms of normal draws.
     alpha = 1.0 if is2d else parse_alpha(method, name)                      # augmentations2d.py:411
-    if alpha > 0.0:                                                         # augmentations.py:661-663
-        np.random.seed(step)            # global stream, as the reference (side effect kept)
-        plan.lam64 = float(np.random.beta(alpha, alpha))
-    else:
-        plan.lam64 = 1.0
+    sigma, knot = parse_magwarp(method) if (not is2d and name == "durmixmagwarp") else (0.0, -2)
+    # seed -> beta (augmentations.py:661-663) -> normal right behind it (:677)
+    plan.lam64, knots = draw_lambda_knots(step, alpha, sigma, batch * (knot + 2) * channels)
     plan.lam32 = np.float32(plan.lam64)                                     # augmentations.py:903
-    if not is2d and name == "durmixmagwarp":
-        sigma, knot = parse_magwarp(method)
+    if knot + 2:
         plan.n_knots = knot + 2
-        # continues the global stream right after the beta draw (augmentations.py:677)
-        plan.knots = np.random.normal(loc=1.0, scale=sigma, size=(batch, knot + 2, channels))
+        plan.knots = knots_array(knots, (batch, knot + 2, channels))
     if callable(labels):
         labels = labels()
     labels = np.asarray(labels).reshape(-1)

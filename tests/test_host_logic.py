@@ -246,3 +246,108 @@ def test_recording_plan_matches_loop_restatement():
     # no cycles at all: empty, correctly shaped tables
     empty = frontend.recording_plan([5000], [np.asarray([100, 600, 1100])], [[]], 34, 128, 128)
     assert empty["cycles"].shape == (0, 4) and empty["frames_spec"].shape == (0, 5) and empty["rec_of_cycle"].shape == (0,)
+
+
+# ---- numpy's legacy global stream restated in C (csrc/pcgmix_nprand.hip, round 4) ---------------
+def _numpy_reference(step, alpha, sigma, count):
+    """What the reference does (augmentations.py:661-663, 677) and where it leaves the stream."""
+    if alpha > 0.0:
+        np.random.seed(step)
+        lam = np.random.beta(alpha, alpha)
+    else:
+        lam = 1.0
+    knots = np.random.normal(loc=1.0, scale=sigma, size=count) if count else None
+    return lam, knots, np.random.get_state()
+
+
+def _same_state(a, b):
+    return a[0] == b[0] and np.array_equal(a[1], b[1]) and tuple(a[2:]) == tuple(b[2:])
+
+
+@pytest.mark.parametrize("alpha", [1.0, 0.5, 0.2, 0.05])
+def test_np_stream_primitives_equal_numpy(alpha):
+    """seed -> beta(alpha, alpha) -> normal(1, sigma, n) on a private state == numpy, bit for bit,
+    and the state behind it == numpy's (key, position)."""
+    lib = _lib.load()
+    st = (ctypes.c_uint32 * 625)()
+    lam = ctypes.c_double()
+    rs = np.random.RandomState(11)
+    for seed in list(range(40)) + [int(v) for v in rs.randint(0, 2 ** 32 - 1, 40, dtype=np.int64)] \
+            + [2 ** 32 - 1]:
+        n = int(rs.choice([0, 2, 48, 312, 1536, 6144]))
+        want_lam, want, state = _numpy_reference(seed, alpha, 0.2, n)
+        assert lib.pcgmix_np_seed(st, seed) == 0
+        assert lib.pcgmix_np_beta(st, alpha, alpha, ctypes.byref(lam)) == 0
+        out = np.empty(n)
+        assert lib.pcgmix_np_normal_fill(st, 1.0, 0.2, n, out.ctypes.data) == 0
+        assert lam.value == want_lam
+        if n:
+            assert np.array_equal(out, want)
+        mine = np.frombuffer(st, dtype=np.uint32)
+        assert np.array_equal(mine[:624], state[1]) and int(mine[624]) == int(state[2])
+    # outside the contract: refused, the caller draws with numpy
+    assert lib.pcgmix_np_normal_fill(st, 1.0, 0.2, 7, np.empty(7).ctypes.data) == 1
+    assert lib.pcgmix_np_beta(st, 2.0, 2.0, ctypes.byref(lam)) == 1
+
+
+def test_np_normal_fill_from_an_unaligned_stream_position():
+    """The block-wise trial evaluation assumes a position that is a multiple of four words; any
+    other position (a caller who drew something else first) goes word by word."""
+    lib = _lib.load()
+    addr = np.random.get_bit_generator().ctypes.state_address
+    for pre in (1, 2, 3, 5, 311, 623):
+        np.random.seed(99)
+        np.random.randint(0, 2 ** 31, size=pre)            # one 32-bit word each
+        want = np.random.normal(1.0, 0.3, 500)
+        state = np.random.get_state()
+        np.random.seed(99)
+        np.random.randint(0, 2 ** 31, size=pre)
+        out = np.empty(500)
+        assert lib.pcgmix_np_normal_fill(addr, 1.0, 0.3, 500, out.ctypes.data) == 0
+        assert np.array_equal(out, want) and _same_state(np.random.get_state(), state)
+
+
+@pytest.mark.parametrize("lookahead", ["0", "2"])
+def test_draw_lambda_knots_equals_numpy_and_leaves_the_global_stream_there(lookahead, monkeypatch):
+    """hostprep.draw_lambda_knots == the reference's seed -> beta -> normal: same lambda, same
+    knots, and ``np.random.get_state()`` afterwards == after numpy's own calls (the reference's
+    side effect, augmentations.py:662) — for consecutive steps (blocks drawn ahead by the worker
+    threads), repeated and out-of-order steps, changing shapes, and the fallbacks (alpha <= 0,
+    alpha > 1, odd counts)."""
+    monkeypatch.setenv("PCGMIX_NPDRAW_LOOKAHEAD", lookahead)
+    monkeypatch.setattr(hostprep, "_NPDRAW", None)
+    cases = [(s, 1.0, 0.2, 6144) for s in range(12)]
+    cases += [(5, 1.0, 0.2, 6144), (5, 1.0, 0.2, 6144), (3, 1.0, 0.2, 6144), (4, 1.0, 0.2, 1536),
+              (5, 0.5, 0.2, 1536), (6, 0.5, 0.3, 1536), (7, 0.5, 0.3, 48), (8, 0.05, 0.3, 48)]
+    cases += [(9, 2.0, 0.2, 48), (10, 0.0, 0.2, 48), (11, 1.0, 0.2, 45), (12, 1.0, 0.2, 0),
+              (13, 1.0, 0.2, 48), (14, 1.0, 0.2, 48)]
+    for step, alpha, sigma, n in cases:
+        np.random.seed(12345)                   # (alpha <= 0 continues whatever stream there is)
+        want_lam, want, state = _numpy_reference(step, alpha, sigma, n)
+        np.random.seed(12345)
+        lam, knots = hostprep.draw_lambda_knots(step, alpha, sigma, n)
+        assert lam == want_lam, (step, alpha)
+        if n:
+            assert np.array_equal(hostprep.knots_array(knots, (n,)), want), (step, alpha, n)
+        else:
+            assert knots is None
+        assert _same_state(np.random.get_state(), state), (step, alpha, n)
+    if lookahead != "0":
+        h = hostprep._NPDRAW[0]
+        misses = ctypes.c_longlong()
+        hits = _lib.load().pcgmix_npdraw_stats(h, ctypes.byref(misses))
+        assert hits >= 11                       # steps 1..11 of the run were drawn ahead
+
+
+def test_draw_lambda_knots_with_a_foreign_bit_generator_falls_back_to_numpy():
+    old = np.random.get_bit_generator()
+    try:
+        np.random.set_bit_generator(np.random.PCG64(1))
+        lam, knots = hostprep.draw_lambda_knots(3, 1.0, 0.2, 48)
+        assert isinstance(knots, np.ndarray) and knots.shape == (48,)
+    finally:
+        np.random.set_bit_generator(old)
+    np.random.seed(3)
+    want = (np.random.beta(1.0, 1.0), np.random.normal(1.0, 0.2, 48))
+    lam, knots = hostprep.draw_lambda_knots(3, 1.0, 0.2, 48)
+    assert lam == want[0] and np.array_equal(hostprep.knots_array(knots, (48,)), want[1])

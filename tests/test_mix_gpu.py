@@ -428,3 +428,34 @@ def test_step_context_entry_points_refuse_a_capturing_stream(device):
     assert np.array_equal(pay_dev.cpu().numpy(), pay_host)
     y1, _, mix1, _ = augmentations.augment(args, data, tgt, fr, wav, sc, None, device, "")
     assert np.array_equal(mix0, mix1) and torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("method,C", [("durmixmagwarp(0.2,4)", 4), ("durmixmagwarp(0.2,4)", 1),
+                                      ("(alpha=0.5)durmixmagwarp(0.1,3)", 4), ("durratiomixup", 4),
+                                      ("(rand)durmixmagwarp(0.2,4)", 2)])
+def test_augment_leaves_numpys_global_stream_where_the_reference_does(method, C, device):
+    """The reference reseeds numpy's GLOBAL stream in every call (augmentations.py:662) and leaves
+    it behind its beta / normal draws (:677).  The knots come from the library's restatement of
+    that stream, drawn ahead on worker threads (csrc/pcgmix_nprand.hip) — ``np.random.get_state()``
+    after ``augment()`` must still equal the state after numpy's own seed -> beta -> normal, and
+    the output the oracle's (which calls numpy) over consecutive steps."""
+    from pcgmix_amd import hostprep
+    B, T = 16, 2500
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, seed=21)
+    name = hostprep.select_method(method, False)
+    alpha = hostprep.parse_alpha(method, name)
+    sigma, knot = hostprep.parse_magwarp(method) if name == "durmixmagwarp" else (0.0, -2)
+    for step in (40, 41, 42, 43, 41, 7):
+        ref = O.augment(method, x, labels, frames, wav, step)
+        np.random.seed(step)
+        np.random.beta(alpha, alpha)
+        if knot + 2:
+            np.random.normal(1.0, sigma, size=(B, knot + 2, C))
+        want = np.random.get_state()
+        np.random.seed(777)
+        g = dict(x=x, labels=labels, frames=frames, wav=wav, step=step, method=method)
+        _, _, (y, _, mix, _) = run(augmentations, g, device)
+        got = np.random.get_state()
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]) and tuple(got[2:]) == tuple(want[2:])
+        assert np.array_equal(mix, ref["mix"])
+        assert np.abs(y.cpu().numpy() - ref["y"]).max() <= (WAVE_TOL if knot + 2 else 0.0)

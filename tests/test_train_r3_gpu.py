@@ -417,8 +417,8 @@ def test_pipelined_step_is_bit_identical_to_the_sequential_one(method, busy, dev
         losses = []
         if mode == "pipelined":
             if busy:
-                w = torch.randn(4096, 4096, device=device)
-                for _ in range(60):
+                w = torch.full((4096, 4096), 1e-3, device=device)     # (no draw from the device RNG:
+                for _ in range(60):                                   #  the dropout keys come from it)
                     w = (w @ w).clamp_(-1, 1)
             for b, nxt in tm.PipelinedTrainStep.pairs(batches):
                 losses.append(g.step(b, 1, sc, None, next_batch=nxt).clone())
