@@ -926,6 +926,11 @@ def main():
             leg("secondary_kernels", lambda: secondary_kernel_times(device))
             leg("cfg3_salopt", lambda: cfg3_salopt(device))
             if not a.no_train:
+                # PCGmix+ (the paper's durmixmagwarp) on the 1D-CNN: the same captured step with the
+                # warp fused into the splice; its knots are drawn ahead by the library
+                leg("train_potes_magwarp", lambda: max_over_ranks(train_steps_per_s(
+                    "durmixmagwarp(0.2,4)", "Potes", B, C, T, rate, device, max(20, a.steps),
+                    max(5, a.warmup), barrier, rank, tag="train_potes_magwarp")))
                 leg("cfg3_train", lambda: cfg3_train(device, max(20, a.steps), max(5, a.warmup), barrier,
                                                      rank))
                 leg("cfg4_spectrogram", lambda: cfg4_spectrogram(device))
@@ -937,6 +942,14 @@ def main():
             try:
                 result["cpu_baseline"] = cpu_baseline(a.method, B, C, T, rate)
                 result["extra"]["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+                if not a.no_extra:
+                    # the reference's CPU path for PCGmix+: B*C scipy CubicSpline constructions per
+                    # batch (augmentations.py:674-683), next to extra.augment_magwarp_*
+                    cb = cpu_baseline("durmixmagwarp(0.2,4)", B, C, T, rate, budget_s=8.0)
+                    result["extra"]["cpu_baseline_magwarp"] = cb
+                    aug = result["extra"].get(f"augment_magwarp_{B}x{C}x{T}", {})
+                    if aug.get("samples_per_s"):
+                        result["extra"]["gpu_over_cpu_magwarp"] = aug["samples_per_s"] / cb["value"]
             except Exception as e:      # noqa: BLE001
                 print(f"[bench] cpu_baseline failed: {e!r}", file=sys.stderr)
                 result["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0,
