@@ -202,6 +202,14 @@ int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames, float* sa
                              int ksize, double sigma, int B, int C, int T,
                              pcgmix_stream_t stream);
 
+/* The spectrogram branch of the same function (saliency.py:93-113, dim = 2).  grad (B, F, W)
+ * float32 (the single image channel folded away), frames (B,5) in spectrogram columns, sal (B, W):
+ * |grad| -> columns t >= f[4] zeroed -> sum over the F frequency rows -> `ksize`-tap Gaussian along
+ * time (the reference: 11 taps, sigma 1) with zero 'same' padding -> tail zeroed -> min/max
+ * normalisation over the cycle's own columns [0, f[4]) ONLY -> NaN -> 0.  W <= 1024.  [device] */
+int pcgmix_saliency_post2d_f32(const float* grad, const int32_t* frames, float* sal, int ksize,
+                               double sigma, int B, int F, int W, pcgmix_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Saliency-optimal displacement search.                                           [device]
  *

@@ -241,6 +241,27 @@ def saliency_post(grad: np.ndarray, frames: np.ndarray, gauss_k_n: int = 101) ->
     return np.squeeze(sal.numpy())
 
 
+def saliency_post2d(grad: np.ndarray, frames: np.ndarray) -> np.ndarray:
+    """saliency.py:93-113 (dim=2): |grad| (B,1,F,W) -> zero the columns t >= f[-1] -> sum over the
+    frequency axis -> 11-tap Gaussian, sigma 1 ('same', zero padded) -> per sample: zero the tail,
+    then (s - min)/max over the cycle's OWN columns only -> NaN->0.  torch CPU ops, as the
+    reference."""
+    sal = torch.from_numpy(np.abs(grad))
+    for s, f in zip(sal, frames):
+        s[:, :, int(f[-1]):] = 0
+    sal = torch.sum(sal, dim=2)[:, None, :]
+    sal = torch.squeeze(sal, 2)
+    kern = torch.FloatTensor([[gaussian_taps(11, 1)]])
+    sal = torch.nn.functional.conv1d(sal, kern, padding="same")
+    for s, f in zip(sal, frames):
+        e = int(f[-1])
+        s[:, e:] = 0
+        s[:, :e] -= s[:, :e].min()
+        s[:, :e] /= s[:, :e].max()
+    sal = torch.nan_to_num(sal, nan=0.0)
+    return np.squeeze(sal.numpy())
+
+
 def input_gradient(model: torch.nn.Module, x: np.ndarray, labels: np.ndarray) -> np.ndarray:
     """saliency.py:52-61: d(score of the true class)/d(input), model in eval mode."""
     model.eval()
@@ -255,7 +276,8 @@ def input_gradient(model: torch.nn.Module, x: np.ndarray, labels: np.ndarray) ->
 def augment(method: str, x: np.ndarray, labels: np.ndarray, frames: np.ndarray, wav,
             step: int, saliency_maps: np.ndarray | None = None, num_classes: int = 2):
     """The durmixmagwarp / durratiomixup branches of augmentations.py:864-981 (1D, x is
-    (B,C,T)) and the durratiomixup branch of augmentations2d.py:397-427 (x is (B,1,F,W)).
+    (B,C,T)) and the durratiomixup branch of augmentations2d.py:397-427 (x is (B,1,F,W); with
+    '(saloptenv' / '(saloptsum' in the method the saliency-guided splice of :125-204, maps (B,W)).
 
     Returns dict(y, target, mix, fired, lam, knots, disp).  ``y is x`` when the method
     does not apply or the gate rejects (the reference returns the input object).
@@ -283,8 +305,10 @@ def augment(method: str, x: np.ndarray, labels: np.ndarray, frames: np.ndarray, 
     y = torch.zeros(x.shape)
     disp = np.zeros((B, 4), dtype=np.int64)
     partners, partner_frames = data[mix], frames[mix]     # gathered copies, as :909 / :970 make
+    # 2D: only the durratiomixup branch looks at '(salopt' (augmentations2d.py:416-423)
+    salopt = "(salopt" in method and (not is2d or name == "durratiomixup")
     for i, (d1, f1, d2, f2) in enumerate(zip(data, frames, partners, partner_frames)):
-        if "(salopt" in method:
+        if salopt:
             y[i], disp[i] = splice_salopt(d1, d2, f1, f2, saliency_maps[i],
                                           saliency_maps[mix][i], lam, method)
         else:
@@ -303,7 +327,7 @@ def augment(method: str, x: np.ndarray, labels: np.ndarray, frames: np.ndarray, 
         y, knots = magnitude_warp(np.transpose(y, (0, 2, 1)), sigma, knot, return_knots=True)
         y = np.ascontiguousarray(np.transpose(y, (0, 2, 1)))
     res.update(y=y, target=target, mix=mix, fired=True, lam=lam64, knots=knots,
-               disp=disp if "(salopt" in method else None)
+               disp=disp if salopt else None)
     return res
 
 

@@ -9,7 +9,10 @@ Spectrogram batches are (B, 1, F, W); the four heart states are ranges of the la
 axis and ``frames`` holds their boundaries in spectrogram columns.  The splice is the 1D one
 applied to every frequency row, so the same kernel runs with C = F rows and T = W columns
 (augmentations2d.py:206-221).  alpha is fixed to 1 and only same-label partners exist in 2D
-(augmentations2d.py:410-411).
+(augmentations2d.py:410-411).  ``(saloptenv)durratiomixup`` / ``(saloptsum)durratiomixup`` place the
+shorter state inside the longer one by saliency (augmentations2d.py:125-204, 416-423): maps from the
+frozen ResNet9-2D 'base' checkpoint through ``saliency.get_saliency_maps(dim=2)``, then the 1D
+displacement search and offset splice.
 """
 from __future__ import annotations
 
@@ -24,8 +27,6 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
     step = int(step_counter.count)
     if hostprep.select_method(method, is2d=True) is None:
         return data, target_ohe, [], None
-    if "(salopt" in method:
-        raise NotImplementedError("saliency-guided mixing of spectrograms is out of scope")
     _check_data(data, 4)
     B, Cc, F, W = data.shape
     recipe = hostprep.plain_recipe(method, True)
@@ -40,5 +41,12 @@ def augment(args, data, target_ohe, frames, wav, step_counter, model, device, RE
     plan = hostprep.make_plan(method, labels, frames_np, wav, step, B, Cc * F, is2d=True, n_cols=W)
     if not plan.fired:
         return data, target_ohe, [], None
-    out = apply_plan(plan, data.view(B, Cc * F, W), frames_np).view(B, Cc, F, W)
+    sal = None
+    if plan.salopt_mode is not None:
+        # '(saloptenv)durratiomixup' / '(saloptsum)…' on spectrograms (augmentations2d.py:416-423):
+        # the frozen ResNet9-2D's input gradient -> (B, W) maps (saliency.get_saliency_maps, dim=2),
+        # then the same displacement search and offset splice as in 1D, with C = F rows, T = W columns
+        from . import saliency
+        sal = saliency.get_saliency_maps(args, device, data, target_ohe, frames_np, dim=2)
+    out = apply_plan(plan, data.view(B, Cc * F, W), frames_np, sal).view(B, Cc, F, W)
     return out, target_ohe, plan.mix, None

@@ -152,6 +152,78 @@ __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
   }
 }
 
+// Spectrogram saliency (saliency.py:93-113, dim = 2): |grad| of a (F, W) image -> zero the columns
+// t >= f[4] -> sum over the frequency rows -> `ksize`-tap Gaussian along time (zero 'same' padding)
+// -> zero the tail again -> min/max normalisation over the cycle's OWN columns [0, f[4]) only (the
+// 1D branch normalises over the whole row; here the tail is not part of the minimum) -> NaN -> 0.
+// One block per image; the row sum is split over G = 256 / W thread groups (rows g, g + G, ...)
+// whose partial columns are added in group order.  W <= 1024, ksize <= 255.
+constexpr int kSal2dThreads = 256;
+__global__ __launch_bounds__(kSal2dThreads) void saliency_post2d_kernel(
+    const float* __restrict__ grad, const int32_t* __restrict__ frames, float* __restrict__ sal,
+    Taps taps, int ksize, int B, int F, int W) {
+  extern __shared__ __align__(16) float smem[];
+  __shared__ float red[kSal2dThreads / 64];
+  const int b = blockIdx.x, half = ksize / 2;
+  const int G = W >= kSal2dThreads ? 1 : kSal2dThreads / W;
+  float* part = smem;                       // part[g * W + t]
+  float* a = smem + (size_t)G * W;          // a[half + t], zero halo
+  float* s = a + W + ksize - 1;             // s[t]
+  int f4 = frames[b * 5 + 4];
+  f4 = f4 < 0 ? 0 : (f4 > W ? W : f4);
+  const float* img = grad + (size_t)b * F * W;
+  for (int i = threadIdx.x; i < G * W; i += kSal2dThreads) {
+    const int g = i / W, t = i - g * W;
+    float acc = 0.f;
+    if (t < f4)
+      for (int r = g; r < F; r += G) acc = __fadd_rn(acc, fabsf(img[(size_t)r * W + t]));
+    part[i] = acc;
+  }
+  for (int i = threadIdx.x; i < W + ksize - 1; i += kSal2dThreads) a[i] = 0.f;
+  __syncthreads();
+  for (int t = threadIdx.x; t < W; t += kSal2dThreads) {
+    float acc = 0.f;
+    for (int g = 0; g < G; ++g) acc = __fadd_rn(acc, part[g * W + t]);
+    a[half + t] = acc;
+  }
+  __syncthreads();
+  auto reduce = [&](float v, bool is_max) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float other = __shfl_xor(v, o, 64);
+      v = is_max ? fmaxf(v, other) : fminf(v, other);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < kSal2dThreads / 64; ++i) r = is_max ? fmaxf(r, red[i]) : fminf(r, red[i]);
+    return r;
+  };
+  float lmin = INFINITY;
+  for (int t = threadIdx.x; t < W; t += kSal2dThreads) {
+    float acc = 0.f;
+    if (t < f4) {
+      for (int j = 0; j < ksize; ++j) acc = fmaf(taps.w[j], a[t + j], acc);
+      lmin = fminf(lmin, acc);
+    }
+    s[t] = acc;
+  }
+  const float rmin = reduce(lmin, false);
+  float lmax = -INFINITY;
+  for (int t = threadIdx.x; t < f4; t += kSal2dThreads) {
+    const float v = __fsub_rn(s[t], rmin);  // saliency.py:108
+    s[t] = v;
+    lmax = fmaxf(lmax, v);
+  }
+  const float rmax = reduce(lmax, true);
+  for (int t = threadIdx.x; t < W; t += kSal2dThreads) {
+    float v = t < f4 ? __fdiv_rn(s[t], rmax) : 0.f;  // saliency.py:109; 0/0 -> NaN -> 0 (:111)
+    if (v != v) v = 0.f;
+    sal[(size_t)b * W + t] = v;
+  }
+}
+
 // ---- numpy's pairwise float32 summation (numpy/_core/src/umath/loops_utils.h.src), restated ----
 // np.sum over a contiguous float32 array of n elements = 0 + pairwise(a, n) where
 //   n < 8      sequential from 0
@@ -541,6 +613,30 @@ extern "C" int pcgmix_saliency_post_f32(const float* grad, const int32_t* frames
     hipLaunchKernelGGL(saliency_post_kernel<0>, dim3((unsigned)B), dim3(kSalThreads), lds, st, grad,
                        frames, sal, taps, ksize, B, C, T);
   }
+  return (int)hipGetLastError();
+}
+
+extern "C" int pcgmix_saliency_post2d_f32(const float* grad, const int32_t* frames, float* sal,
+                                          int ksize, double sigma, int B, int F, int W,
+                                          pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!grad || !frames || !sal) return hipErrorInvalidValue;
+  if (B < 0 || F <= 0 || W <= 0 || W > 1024 || ksize < 1 || ksize > kMaxTaps || !(ksize & 1) ||
+      !(sigma > 0))
+    return hipErrorInvalidValue;
+  if (B == 0) return hipSuccess;
+  Taps taps;
+  const int half = ksize / 2;
+  for (int j = 0; j < ksize; ++j) {                  // gaussian_kernel(), saliency.py:15-18
+    const double xr = (double)(j - half);
+    const double w = 1.0 / (sigma * sqrt(2.0 * M_PI)) * exp(-(xr * xr) / (2.0 * (sigma * sigma)));
+    taps.w[j] = (float)w;
+  }
+  for (int j = ksize; j < kMaxTaps; ++j) taps.w[j] = 0.f;
+  const int G = W >= kSal2dThreads ? 1 : kSal2dThreads / W;
+  const size_t lds = sizeof(float) * ((size_t)G * W + (size_t)W + ksize - 1 + (size_t)W);
+  hipLaunchKernelGGL(saliency_post2d_kernel, dim3((unsigned)B), dim3(kSal2dThreads), lds,
+                     reinterpret_cast<hipStream_t>(stream), grad, frames, sal, taps, ksize, B, F, W);
   return (int)hipGetLastError();
 }
 

@@ -121,7 +121,7 @@ def plain_recipe(method: str, is2d: bool):
     if name is None:
         return None
     if is2d:
-        if name != "durratiomixup":
+        if name != "durratiomixup" or "(salopt" in method:
             return None
         return name, parse_probability(method), 1.0, 0.0, 0          # augmentations2d.py:411
     if any(t in method for t in ("(rand)", "(salopt", "(samePCG)", "(sameDataset)", "(mixAll)")):
@@ -368,14 +368,17 @@ def make_plan(method: str, labels, frames: np.ndarray, wav: Sequence[str], step:
     plan.mix = partner_indices(method, labels, wav, step, is2d)
     if is2d and name != "durratiomixup":
         plan.zero_rect = mask_rectangles(method, name, frames, step, channels, n_cols)
-    if not is2d:
-        if "(rand)" in method and "(salopt" not in method:
-            plan.rand_off = rand_offsets(frames, plan.mix, step)
+    if not is2d and "(rand)" in method and "(salopt" not in method:
+        plan.rand_off = rand_offsets(frames, plan.mix, step)
+    # saliency-guided placement: 1D augmentations.py:905-913; 2D only under durratiomixup
+    # (augmentations2d.py:416-423 — the mask variants never look at '(salopt')
+    if (not is2d or name == "durratiomixup") and "(salopt" in method:
         if "(saloptenv" in method:
             plan.salopt_mode = 0
         elif "(saloptsum" in method:
             plan.salopt_mode = 1
-        elif "(salopt" in method:
+        else:
             raise NotImplementedError("only (saloptenv…) and (saloptsum…) exist in the reference")
+    if not is2d:
         plan.mix_all = "(mixAll)" in method
     return plan

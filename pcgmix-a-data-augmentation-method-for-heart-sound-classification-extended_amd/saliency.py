@@ -220,6 +220,25 @@ def saliency_post(grad: torch.Tensor, frames_dev_ptr: int, gauss_k_n: int = 101)
     return sal
 
 
+def saliency_post2d(grad: torch.Tensor, frames_dev_ptr: int, gauss_k_n: int = 11,
+                    sigma: float = 1.0) -> torch.Tensor:
+    """The spectrogram branch (saliency.py:93-113): |grad| (B,1,F,W) or (B,F,W) -> (B,W) maps,
+    normalised over each cycle's own columns, with one kernel launch.  11 taps, sigma 1 are the
+    reference's constants (:101)."""
+    if grad.dim() == 4:
+        if grad.shape[1] != 1:
+            raise ValueError("spectrogram saliency expects one image channel (models2d.ResNet9)")
+        grad = grad[:, 0]
+    grad = grad.contiguous()
+    B, Fq, W = grad.shape
+    sal = torch.empty((B, W), dtype=torch.float32, device=grad.device)
+    stream = torch.cuda.current_stream(grad.device).cuda_stream
+    _lib.check(_lib.load().pcgmix_saliency_post2d_f32(
+        grad.data_ptr(), frames_dev_ptr, sal.data_ptr(), gauss_k_n, ctypes.c_double(sigma), B, Fq, W,
+        ctypes.c_void_p(stream)), "pcgmix_saliency_post2d_f32")
+    return sal
+
+
 class _SaliencyGraph:
     """Forward + input-gradient + post-processing of a FROZEN model for one batch shape, captured
     once in a hipGraph and replayed: the eager chain is ~40 small launches driven by Python
@@ -303,7 +322,7 @@ def step_graph(args, data, num_classes: int, dim: int = 1, gauss_k_n: int = 101,
     """The captured saliency pass for this model and batch shape (captured on first use), or None
     when graphs are off or the stream is capturing."""
     if dim != 1:
-        raise NotImplementedError("spectrogram (dim=2) saliency is out of scope")
+        return None          # spectrograms: the pass is 25 ms of MIOpen convolutions, run eagerly
     if not data.is_cuda:
         raise ValueError("data must live on a HIP device")
     if not USE_GRAPHS or torch.cuda.is_current_stream_capturing():
@@ -323,12 +342,21 @@ def step_graph(args, data, num_classes: int, dim: int = 1, gauss_k_n: int = 101,
 def get_saliency_maps(args, device, data, target_ohe, frames, dim=1, gauss_k_n=101,
                       model_sal: Optional[torch.nn.Module] = None) -> torch.Tensor:
     """Reference signature plus an optional explicit model.  Returns a (B, T) float32 tensor on
-    ``data``'s device."""
-    if dim != 1:
-        raise NotImplementedError("spectrogram (dim=2) saliency is out of scope")
+    ``data``'s device; ``dim=2`` (saliency.py:93-113): ``data`` is (B, 1, F, W), the maps are
+    (B, W), the model is the ResNet9-2D 'base' checkpoint (``gauss_k_n`` is not used on that
+    branch: the reference hard-codes 11 taps, sigma 1)."""
+    if dim not in (1, 2):
+        raise ValueError("Set dimension to either 1 or 2")          # saliency.py:45
     if not data.is_cuda:
         raise ValueError("data must live on a HIP device")
     frames_np = frames.detach().cpu().numpy() if isinstance(frames, torch.Tensor) else np.asarray(frames)
+    if dim == 2:
+        with torch.cuda.device(data.device):
+            from .augmentations import upload_array
+            model = model_sal or _INJECTED or _baseline_model(args, data.device, 2)
+            fr = upload_array(frames_np.astype(np.int32), data.device)
+            grad = input_gradient(model, data, target_ohe)
+            return saliency_post2d(grad, fr.data_ptr())
     with torch.cuda.device(data.device):
         g = step_graph(args, data, target_ohe.shape[1], dim, gauss_k_n, model_sal) \
             if target_ohe.dtype == torch.int64 else None

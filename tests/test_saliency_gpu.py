@@ -519,3 +519,129 @@ def test_salopt_begin_with_host_labels_all_paths(device):
                                       host_labels=wrong)
     finally:
         saliency.set_saliency_model(None)
+
+
+# ---- spectrograms: saliency.get_saliency_maps(dim=2) and '(salopt…)durratiomixup' in 2D (round 4) ----
+CASES2D = golden_files("salopt2d_")
+
+
+def _golden_args2d(method, experiments):
+    import argparse
+    return argparse.Namespace(
+        dataset="PhysioNet(spec128)", model="resnet9", method=method, num_epochs=50, batch_size=6,
+        n_fraction=1.0, op="adam", use_sched=True, lr_max=0.01, train_balance=True, num_channels=1,
+        grad_clip=0.1, seed_data=1100001, valid=False, seed=4, EXPERIMENTS=experiments,
+        num_classes=2, sample_rate=1000)
+
+
+def _write_resnet2d_base_checkpoint(tmp_path):
+    """The golden's frozen saliency model: models2d.ResNet9 under torch.manual_seed(4321) — the same
+    weights the reference's factory draws (make_golden_salopt2d.py; test_model_goldens) — saved the
+    way the reference's 'base' run saves it (DataParallel prefix, train_model.py:481-482)."""
+    import os
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_golden_salopt2d import SEED2D
+    from pcgmix_amd import models2d
+    base = _golden_args2d("base", str(tmp_path))
+    exp = saliency.experiment_dir(base)
+    os.makedirs(exp, exist_ok=True)
+    torch.manual_seed(SEED2D)
+    net = models2d.ResNet9(num_classes=2)
+    torch.save({"module." + k: v for k, v in net.state_dict().items()}, os.path.join(exp, "model.pth"))
+
+
+def test_saliency_post2d_matches_reference(device):
+    """pcgmix_saliency_post2d_f32 on the reference's recorded input gradient == the reference's
+    maps (saliency.py:93-113) up to the float32 summation order (128 rows, 11 taps)."""
+    g = load_golden(CASES2D[0])
+    grad = torch.from_numpy(g["grad"]).to(device)
+    fr = dev_i32(g["frames"], device)
+    sal = saliency.saliency_post2d(grad, fr.data_ptr()).cpu().numpy()
+    assert sal.shape == g["sal"].shape == (6, 128)
+    assert np.abs(sal - g["sal"]).max() <= 2e-6
+    for b, f in enumerate(g["frames"]):
+        assert (sal[b, f[4]:] == 0).all() and sal[b, :f[4]].min() == 0.0 and sal[b, :f[4]].max() == 1.0
+    # and against the oracle on a ragged batch: empty cycle, full-width cycle, W not a power of two
+    rs = np.random.RandomState(5)
+    grad2 = rs.standard_normal((5, 1, 40, 96)).astype(np.float32)
+    fr2 = np.array([[0, 5, 9, 20, 96], [0, 1, 2, 3, 4], [0, 10, 30, 50, 61], [0, 2, 4, 6, 8],
+                    [0, 20, 40, 60, 95]], dtype=np.int64)
+    got = saliency.saliency_post2d(torch.from_numpy(grad2).to(device), dev_i32(fr2, device).data_ptr())
+    assert np.abs(got.cpu().numpy() - O.saliency_post2d(grad2.copy(), fr2)).max() <= 2e-6
+
+
+@pytest.mark.parametrize("path", CASES2D, ids=lambda p: p.split("/")[-1][:-4])
+def test_displacements2d_bit_exact_given_reference_saliency(path, device):
+    """The search kernel on the reference's recorded (B, W) maps: short states (2 .. 40 columns,
+    the sequential n < 8 and the 8-accumulator branches of numpy's pairwise sum)."""
+    g = load_golden(path)
+    B, W = g["sal"].shape
+    sal = torch.from_numpy(g["sal"]).to(device)
+    fr, mix = dev_i32(g["frames"], device), dev_i32(g["mix"], device)
+    mode = 0 if "(saloptenv" in g["method"] else 1
+    disp = saliency.optimal_displacements(sal, fr.data_ptr(), mix.data_ptr(),
+                                          float(np.float32(g["lam"])), mode, B, W)
+    assert np.array_equal(disp.cpu().numpy().astype(np.int64), g["disp"])
+
+
+@pytest.mark.parametrize("path", CASES2D, ids=lambda p: p.split("/")[-1][:-4])
+def test_salopt2d_augment_end_to_end(path, device, tmp_path):
+    """augmentations2d.augment with '(saloptenv|saloptsum)durratiomixup' (augmentations2d.py:416-423)
+    end to end against the reference's recorded run: the ResNet9-2D 'base' checkpoint is read from
+    where ``utils.experiment_dir`` puts it, its input gradient comes from MIOpen instead of oneDNN
+    (maps equal to <= 1e-5), displacements may differ from the recorded ones only at proven
+    near-ties (``_check_against_reference_golden``), partners and lambda are exact."""
+    g = load_golden(path)
+    _write_resnet2d_base_checkpoint(tmp_path)
+    saliency.set_saliency_model(None)
+    saliency._LOADED.clear()
+    args = _golden_args2d(g["method"], str(tmp_path))
+    data = torch.from_numpy(g["x"]).to(device)
+    tgt = torch.nn.functional.one_hot(torch.from_numpy(g["labels"]), 2).to(device)
+    B, _, F, W = data.shape
+    from pcgmix_amd import augmentations2d
+    sal = saliency.get_saliency_maps(args, device, data, tgt, torch.from_numpy(g["frames"]), dim=2)
+    assert sal.shape == (B, W)
+    y, t_out, mix, cut = augmentations2d.augment(args, data, tgt, torch.from_numpy(g["frames"]), g["wav"],
+                                                 StepCounter(g["step"]), None, device, str(tmp_path))
+    assert cut is None and t_out is tgt and y.shape == data.shape
+    fr, mx = dev_i32(g["frames"], device), dev_i32(mix, device)
+    mode = 0 if "(saloptenv" in g["method"] else 1
+    disp = saliency.optimal_displacements(sal, fr.data_ptr(), mx.data_ptr(),
+                                          float(np.float32(g["lam"])), mode, B, W)
+    torch.cuda.synchronize()
+    _check_against_reference_golden(g, sal.cpu().numpy(), disp.cpu().numpy().astype(np.int64),
+                                    y.cpu().numpy(), mix)
+
+
+def test_salopt2d_on_reference_saliency_is_exact(device):
+    """With the reference's recorded maps injected, the 2D saliency-guided splice is the
+    reference's output bit for bit (no model in the loop: search + offset splice only)."""
+    from pcgmix_amd import hostprep
+    for path in CASES2D:
+        g = load_golden(path)
+        B, _, F, W = g["x"].shape
+        plan = hostprep.make_plan(g["method"], g["labels"], g["frames"], g["wav"], g["step"], B, F,
+                                  is2d=True, n_cols=W)
+        assert plan.fired and plan.salopt_mode == (0 if "(saloptenv" in g["method"] else 1)
+        assert np.array_equal(plan.mix, g["mix"]) and plan.lam64 == float(g["lam"])
+        data = torch.from_numpy(g["x"]).to(device)
+        y = augmentations.apply_plan(plan, data.view(B, F, W), g["frames"],
+                                     torch.from_numpy(g["sal"]).to(device)).view(B, 1, F, W)
+        assert np.array_equal(y.cpu().numpy(), g["y"])
+
+
+def test_mask_variants_ignore_salopt_in_2d(device):
+    """Only the durratiomixup branch looks at '(salopt' (augmentations2d.py:416-423): the mask
+    variants (:286-395) splice at offset 0 whatever the method string says."""
+    from pcgmix_amd import augmentations2d
+    g = load_golden(golden_files("mask2d_")[0])
+    data = torch.from_numpy(g["x"]).to(device)
+    tgt = torch.nn.functional.one_hot(torch.from_numpy(g["labels"]), 2).to(device)
+    out = []
+    for m in (g["method"], "(saloptenv)" + g["method"]):
+        y, _, mix, _ = augmentations2d.augment(Args(m), data, tgt, torch.from_numpy(g["frames"]), g["wav"],
+                                               StepCounter(g["step"]), None, device, "")
+        out.append(y.cpu().numpy())
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], g["y"])
