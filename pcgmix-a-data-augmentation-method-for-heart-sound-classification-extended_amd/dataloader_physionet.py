@@ -18,7 +18,7 @@ Mirrors the reference's ``dataloader_physionet.py``:
   (train_model.py:497) fixes the same shuffles.
 * ``file2dict`` / ``dict2file`` — the reference's dataset container (zlib-compressed pickle of
   ``{'train'|'test': {'data': {band: [arrays]}, 'label', 'frames', 'wav', 'sig_qual'}}``,
-  utils.py:172-186).  Unpickling executes code from the file: only open datasets you built.
+  utils.py:172-186), read through a restricted unpickler (plain containers and numpy arrays only).
 """
 from __future__ import annotations
 
@@ -42,10 +42,32 @@ def dict2file(dataset: dict, path: str) -> None:
         fd.write(zlib.compress(buf.getbuffer()))
 
 
+class _DatasetUnpickler(pickle.Unpickler):
+    """The dataset container holds dicts, lists, strings, ints and numpy arrays
+    (databuilder.ipynb cell 25) — nothing else is allowed to be constructed: an unpickler that
+    resolves only numpy's array/dtype/scalar reconstructors refuses every other global, so a
+    tampered file cannot run code through ``__reduce__``."""
+    _ALLOWED = {
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+        ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+        ("numpy", "ndarray"), ("numpy", "dtype"),
+        ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+        ("builtins", "list"), ("builtins", "dict"), ("builtins", "tuple"), ("builtins", "set"),
+        ("collections", "OrderedDict"),
+    }
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"dataset container may not reference {module}.{name}")
+
+
 def file2dict(path: str) -> dict:
-    """utils.py:181-186.  TRUSTED FILES ONLY (pickle)."""
+    """utils.py:181-186: zlib-compressed pickle -> dataset dictionary, through an unpickler
+    restricted to the types the container holds (object-dtype arrays are refused by numpy's own
+    reconstruction only if they carry foreign classes — those globals are not on the list)."""
     with open(path, "rb") as fd:
-        return pickle.loads(zlib.decompress(fd.read()))
+        return _DatasetUnpickler(io.BytesIO(zlib.decompress(fd.read()))).load()
 
 
 def _stack_bands(split: dict, num_channels: int) -> np.ndarray:

@@ -210,3 +210,31 @@ def test_run2d_batches_match_reference_dataloader_cpu():
 @pytest.mark.gpu
 def test_run2d_batches_match_reference_dataloader_on_device(device):
     _check_run2d_against_reference(device)
+
+
+def test_container_refuses_foreign_globals(tmp_path):
+    """file2dict reads the reference's container (utils.py:181-186) through a restricted
+    unpickler: numpy arrays and plain containers load, anything that would import and call a
+    foreign global is refused before it runs."""
+    import io
+    import pickle
+    import zlib
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > /dev/null",))
+    path = str(tmp_path / "evil.dat")
+    buf = io.BytesIO()
+    pickle.dump({"train": Evil()}, buf)
+    with open(path, "wb") as fd:
+        fd.write(zlib.compress(buf.getbuffer()))
+    with pytest.raises(pickle.UnpicklingError):
+        dl.file2dict(path)
+    ds = synthetic_dataset(seed=1, n_rec=4)
+    ds["train"]["extra"] = {"scalar": np.float32(1.5), "ints": np.arange(3), "t": (1, 2)}
+    good = str(tmp_path / "good.dat")
+    dl.dict2file(ds, good)
+    back = dl.file2dict(good)
+    assert back["train"]["extra"]["scalar"] == np.float32(1.5) and back["train"]["extra"]["t"] == (1, 2)
+    assert np.array_equal(back["train"]["frames"][0], ds["train"]["frames"][0])
