@@ -504,11 +504,17 @@ def secondary_kernel_times(device, B=256, iters=50):
                                             B * (4 * C * T + 4 * T))
     sal = saliency.saliency_post(grad, fr.data_ptr())
     mix = torch.from_numpy(np.random.RandomState(0).permutation(B).astype(np.int32)).to(device)
+    order = saliency.dispatch_order(frames, mix.cpu().numpy())
     for mode, name in ((0, "env"), (1, "sum")):
+        # what the step context launches: pairs dispatched longest chain first
         out[f"salopt_disp_{name}_256x5000"] = entry(
             timeit(lambda: saliency.optimal_displacements(sal, fr.data_ptr(), mix.data_ptr(), 0.37, mode, B, T,
-                                                          max_len=int(np.diff(frames, axis=1).max()))),
+                                                          max_len=int(np.diff(frames, axis=1).max()),
+                                                          order=order)),
             B * 8 * T)
+        out[f"salopt_disp_{name}_256x5000"]["natural_order_us"] = timeit(
+            lambda: saliency.optimal_displacements(sal, fr.data_ptr(), mix.data_ptr(), 0.37, mode, B, T,
+                                                   max_len=int(np.diff(frames, axis=1).max())))
     spec, fs = frontend.logmel(x1, frames)
     tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)
     sc = StepCounter()
