@@ -10,7 +10,7 @@ rs = np.random.RandomState(0)
 sal = torch.from_numpy(rs.rand(B, T).astype(np.float32)).to(dev)
 fr = torch.from_numpy(frames.astype(np.int32)).to(dev)
 mix = torch.from_numpy(rs.permutation(B).astype(np.int32)).to(dev)
-for _ in range(5):
+for _ in range(5):  # natural order; see disp_pmc_ordered.py
     saliency.optimal_displacements(sal, fr.data_ptr(), mix.data_ptr(), 0.37, 0, B, T,
                                    max_len=int(np.diff(frames, axis=1).max()))
 torch.cuda.synchronize()
