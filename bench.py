@@ -731,7 +731,9 @@ def main():
     if a.kernels_only:
         print("potes:", potes_kernel_times(device), flush=True)
         for k, v in secondary_kernel_times(device).items():
-            print(f"{k:32s} {v['us']:9.1f} us  {v['GBs']:8.1f} GB/s", flush=True)
+            print(f"{k:32s} {v['us']:9.1f} us  {v['GBs']:8.1f} GB/s"
+                  + (f"   (natural order {v['natural_order_us']:.1f} us)" if "natural_order_us" in v else ""),
+                  flush=True)
         for m, b, c, t in (("durratiomixup", 256, 1, 5000), ("durratiomixup", 256, 4, 5000),
                            ("durmixmagwarp(0.2,4)", 256, 1, 5000), ("durmixmagwarp(0.2,4)", 256, 4, 5000),
                            ("durratiomixup", 4096, 4, 5000), ("durmixmagwarp(0.2,4)", 4096, 4, 5000),

@@ -446,16 +446,21 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   // gridDim.x * 4 apart — a multiple of the CU count at the benchmark batch, i.e. the SAME CU,
   // whose LDS pipe the heaviest pair then saturates alone.  Rotating the sample index by a
   // z-dependent offset puts them on different CUs.
-  // The grid is one-dimensional: block i = (pair i / kDispSplit, slice i % kDispSplit) of the order
-  // the host hands over (ord: heaviest pair first — the launch ends when its longest chain does,
-  // so the long ones start first), or, without one, x = i % B, y = (i / B) % 4, z = i / 4B as above.
+  // The grid is one-dimensional: block i = (slice z = i / 4B, pair i % 4B) — slice-major in both
+  // forms, so that consecutive blocks (dealt round-robin to the eight XCDs) are different pairs of
+  // similar weight.  With `ord` the pairs come in the order the host hands over (heaviest first: the
+  // launch ends when its longest chain does, so the long ones start first); without one,
+  // x = i % B, y = (i / B) % 4 as above.  (Pair-major — the four slices of a pair as consecutive
+  // blocks — was 44 us against 34: the slices z >= 2 are mostly empty, so XCDs 2, 3, 6, 7 drained
+  // at once while the heavy z = 0, 1 slices of the long diastole pairs piled up four per CU on the
+  // other half of the chip.)
   int b, k, z;
   if (ord.n) {
-    const unsigned p = blockIdx.x / kDispSplit;
+    const unsigned p = blockIdx.x % (4u * (unsigned)B);
     const unsigned e = (ord.w[p >> 1] >> (16 * (p & 1))) & 0xffffu;
     b = (int)(e >> 2);
     k = (int)(e & 3u);
-    z = (int)(blockIdx.x % kDispSplit);
+    z = (int)(blockIdx.x / (4u * (unsigned)B));
     if (b >= B) b = B - 1;
   } else {
     const unsigned x = blockIdx.x % (unsigned)B, y = (blockIdx.x / (unsigned)B) & 3u;

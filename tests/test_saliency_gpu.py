@@ -74,7 +74,7 @@ def _golden_potes(device):
     return model.to(device)
 
 
-def _check_against_reference_golden(g, sal_gpu, disp_gpu, y_gpu, mix):
+def _check_against_reference_golden(g, sal_gpu, disp_gpu, y_gpu, mix, eps_max=1e-5):
     """Everything the saliency-guided step produced on the GPU against (i) the oracle run on the
     GPU's own saliency maps and (ii) the reference's recorded run.
 
@@ -90,7 +90,7 @@ def _check_against_reference_golden(g, sal_gpu, disp_gpu, y_gpu, mix):
     method, frames = g["method"], g["frames"]
     assert np.array_equal(mix, g["mix"])
     eps = float(np.abs(sal_gpu - g["sal"]).max())
-    assert eps <= 1e-5          # measured <= 2e-6; the near-tie bound below scales with it
+    assert eps <= eps_max       # Potes: measured <= 2e-6; the near-tie bound below scales with it
     ref = O.augment(method, g["x"], g["labels"], frames, g["wav"], g["step"], saliency_maps=sal_gpu)
     # (i) the GPU chain == the oracle fed the same saliency: indices bit-exact, waveform 1e-4
     assert np.array_equal(ref["mix"], mix)
@@ -590,7 +590,7 @@ def test_salopt2d_augment_end_to_end(path, device, tmp_path):
     """augmentations2d.augment with '(saloptenv|saloptsum)durratiomixup' (augmentations2d.py:416-423)
     end to end against the reference's recorded run: the ResNet9-2D 'base' checkpoint is read from
     where ``utils.experiment_dir`` puts it, its input gradient comes from MIOpen instead of oneDNN
-    (maps equal to <= 1e-5), displacements may differ from the recorded ones only at proven
+    (maps equal to <= 1e-4; measured 3.1e-5), displacements may differ from the recorded ones only at proven
     near-ties (``_check_against_reference_golden``), partners and lambda are exact."""
     g = load_golden(path)
     _write_resnet2d_base_checkpoint(tmp_path)
@@ -611,8 +611,10 @@ def test_salopt2d_augment_end_to_end(path, device, tmp_path):
     disp = saliency.optimal_displacements(sal, fr.data_ptr(), mx.data_ptr(),
                                           float(np.float32(g["lam"])), mode, B, W)
     torch.cuda.synchronize()
+    # the input gradient of an eight-convolution network through MIOpen's fp32 kernels instead of
+    # oneDNN's: measured 3.1e-5 on the normalised maps (north_star's bar for spectrograms is 1e-4)
     _check_against_reference_golden(g, sal.cpu().numpy(), disp.cpu().numpy().astype(np.int64),
-                                    y.cpu().numpy(), mix)
+                                    y.cpu().numpy(), mix, eps_max=1e-4)
 
 
 def test_salopt2d_on_reference_saliency_is_exact(device):
