@@ -1197,6 +1197,302 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_fused_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------- backward, channel pairs
+// potes_bwd_fused_kernel is VALU-issue-bound (profiles/r3_potes_bwd_sq_counters.json: 31.1 M VALU
+// instructions, 71 % of the launch) and of the ~455 multiply-add-related instructions a wave spends
+// per item only 236 are v_pk_fma_f32 — the other 219 are v_mov_b32 that assemble even-aligned
+// register pairs for operands that start at an odd offset (pairs run along POSITIONS there: a tap k
+// shifts the window by k, and every odd k breaks the alignment).  Here the two halves of every
+// packed multiply-add are the wave's two CHANNELS instead (wave w owns first-layer channels 2w,
+// 2w+1): one operand is a channel pair that is a pair by construction — first-layer weights,
+// second-layer weights (both wave-uniform: SGPR pairs), routed gradients, the a1 rows, which live
+// pair-interleaved in LDS — and the other is ONE position's value, broadcast to both halves by
+// op_sel from whichever half of its natural register pair it sits in.  No operand assembly at all.
+// And the second-layer weight gradient uses what the routing masks say: of the two conv2 outputs
+// under a pooled output only the winner carries gradient, so a lane takes ONE shifted 5-tap window
+// of a1 per pooled output (the shift, 0 or 1, moves the LDS address) instead of two overlapping
+// windows against a half-zero dz2 quad: half the multiply-adds of that phase.
+// Per lane and item: layer 1 40, back through conv2 80, gw1 40, gw2 40 packed multiply-adds
+// (fused kernel: 36 + 80 + 40 + 80 and 219 moves).  Same tiles, same ownership, same partial layout
+// and epilogue as the fused kernel.  The first layer is now an in-order fmaf chain from the bias
+// over k = 0..4 — bit for bit what the matrix-core forward computes (potes_fwd_mfma_kernel), so
+// the recomputed ReLU/pool routing of layer 1 IS the forward's.
+__device__ __forceinline__ void pkfma_lo(f2& acc, const f2& a, const f2& b) {   // acc += a * b.x
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pkfma_hi(f2& acc, const f2& a, const f2& b) {   // acc += a * b.y
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void pkfma_s_lo(f2& acc, const f2& a_uniform, const f2& b) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(a_uniform), "v"(b));
+}
+__device__ __forceinline__ void pkfma_s_hi(f2& acc, const f2& a_uniform, const f2& b) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(a_uniform), "v"(b));
+}
+// acc += a * (element j of the float sequence stored as pairs p[0], p[1], ...)
+template <int J, int N>
+__device__ __forceinline__ void pkfma_at(f2& acc, const f2& a, const f2 (&p)[N]) {
+  if (J & 1) pkfma_hi(acc, a, p[J >> 1]); else pkfma_lo(acc, a, p[J >> 1]);
+}
+template <int J, int N>
+__device__ __forceinline__ void pkfma_s_at(f2& acc, const f2& a_uniform, const f2 (&p)[N]) {
+  if (J & 1) pkfma_s_hi(acc, a_uniform, p[J >> 1]); else pkfma_s_lo(acc, a_uniform, p[J >> 1]);
+}
+
+template <int M>
+struct PairConv1 {   // cp[m] += w[k] * x[m + k], k = 0..4 in order, for m = M .. 7
+  template <int K>
+  static __device__ __forceinline__ void taps(f2& c, const f2 (&w)[kK], const f2 (&xp)[6]) {
+    if constexpr (K < kK) {
+      pkfma_s_at<M + K>(c, w[K], xp);
+      taps<K + 1>(c, w, xp);
+    }
+  }
+  static __device__ __forceinline__ void run(f2 (&cp)[8], const f2 (&w)[kK], const f2 (&xp)[6]) {
+    if constexpr (M < 8) {
+      taps<0>(cp[M], w, xp);
+      PairConv1<M + 1>::run(cp, w, xp);
+    }
+  }
+};
+template <int U>
+struct PairDgrad {   // da[u] += w2pair[k] * dz2[u + 4 - k], u = U .. 3
+  template <int K>
+  static __device__ __forceinline__ void taps(f2& d, const f2 (&w)[kK], const f2 (&dwp)[4]) {
+    if constexpr (K < kK) {
+      pkfma_s_at<U + 4 - K>(d, w[K], dwp);
+      taps<K + 1>(d, w, dwp);
+    }
+  }
+  static __device__ __forceinline__ void run(f2 (&da)[4], const f2 (&w)[kK], const f2 (&dwp)[4]) {
+    if constexpr (U < 4) {
+      taps<0>(da[U], w, dwp);
+      PairDgrad<U + 1>::run(da, w, dwp);
+    }
+  }
+};
+template <int I>
+struct PairGw1 {     // acc[k] += dd[i] * x[i + k], i = I .. 7
+  template <int K>
+  static __device__ __forceinline__ void taps(f2 (&acc)[kK], const f2& dd, const f2 (&xp)[6]) {
+    if constexpr (K < kK) {
+      pkfma_at<I + K>(acc[K], dd, xp);
+      taps<K + 1>(acc, dd, xp);
+    }
+  }
+  static __device__ __forceinline__ void run(f2 (&acc)[kK], const f2 (&dd)[8], const f2 (&xp)[6]) {
+    if constexpr (I < 8) {
+      taps<0>(acc, dd[I], xp);
+      PairGw1<I + 1>::run(acc, dd, xp);
+    }
+  }
+};
+
+__global__ __launch_bounds__(kPotThreads) void potes_bwd_pair_kernel(
+    const float* __restrict__ x, const float* __restrict__ gh2, const uint8_t* __restrict__ m2,
+    const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+    const float* __restrict__ b2, float* __restrict__ partial /* gridDim.x * 212 */, int N, int T) {
+  __shared__ __align__(16) float xs[kBwdNX + 4];
+  __shared__ __align__(16) float a1p[kC1 * kBwdNQ];            // [channel pair][position][2]
+  __shared__ __align__(16) float dz2s[kC2 * (kBwdNJ + 12)];
+  __shared__ float red[4 * kNAcc];
+  constexpr int kDz2Row = kBwdNJ + 12;
+  const PotesDims d = potes_dims(T);
+  const int tiles = potes_bwd_tiles(d);
+  const unsigned work = (unsigned)N * (unsigned)tiles;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < kC2 * kDz2Row; i += kPotThreads) dz2s[i] = 0.f;
+
+  // wave-uniform weight pairs (scalar loads): first-layer taps and bias of channels 2w, 2w+1, and
+  // for every (co, k) the second-layer weights towards those two channels
+  const int c0 = 2 * wave;
+  f2 w1p[kK], w2p[kC2][kK];
+#pragma unroll
+  for (int k = 0; k < kK; ++k) w1p[k] = f2{w1[c0 * kK + k], w1[(c0 + 1) * kK + k]};
+  const f2 b1p = {b1[c0], b1[c0 + 1]};
+#pragma unroll
+  for (int co = 0; co < kC2; ++co)
+#pragma unroll
+    for (int k = 0; k < kK; ++k)
+      w2p[co][k] = f2{w2[(co * kC1 + c0) * kK + k], w2[(co * kC1 + c0 + 1) * kK + k]};
+
+  f2 acc2p[kC1 / 2][kK], acc1p[kK], accb1p = {0.f, 0.f};
+  float accb2 = 0.f;
+#pragma unroll
+  for (int cp = 0; cp < kC1 / 2; ++cp)
+#pragma unroll
+    for (int k = 0; k < kK; ++k) acc2p[cp][k] = f2{0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < kK; ++k) acc1p[k] = f2{0.f, 0.f};
+
+  constexpr int kXPer = (kBwdNX + 4 + kPotThreads - 1) / kPotThreads;   // 3
+  float xr[kXPer], gr[2];
+  uint32_t mr[2] = {0u, 0u};
+  const int m2s = (d.P2 + 3) / 4;
+  auto prefetch = [&](unsigned it) {
+    const int n = (int)(it / (unsigned)tiles), p0 = (int)(it - (unsigned)n * (unsigned)tiles) * kBwdTP;
+    const int xlo = 2 * (2 * p0 - 5) - 1;
+    const float* xrow = x + (size_t)n * T;
+#pragma unroll
+    for (int j = 0; j < kXPer; ++j) {
+      const int u = threadIdx.x + j * kPotThreads, g = xlo + u;
+      xr[j] = (u < kBwdNX + 4 && g >= 0 && g < T) ? xrow[g] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pe = p0 - 2 + 2 * lane + u;
+      gr[u] = (pe >= 0 && pe < d.P2) ? gh2[((size_t)n * kC2 + wave) * d.P2 + pe] : 0.f;
+      mr[u] = (pe >= 0 && pe < d.P2)
+                  ? (m2[((size_t)n * kC2 + wave) * m2s + (pe >> 2)] >> (2 * (pe & 3))) & 3u
+                  : 0u;
+    }
+  };
+  if (blockIdx.x < work) prefetch(blockIdx.x);
+  __syncthreads();                                   // dz2s zeroed before the first item writes it
+  const int R0 = 4 * lane;                           // a1 positions r = R0 - 1 + u, u < 4
+
+  for (unsigned item = blockIdx.x; item < work; item += gridDim.x) {
+    const int p0 = (int)(item % (unsigned)tiles) * kBwdTP;
+    __syncthreads();  // previous item's LDS fully consumed
+#pragma unroll
+    for (int j = 0; j < kXPer; ++j) {
+      const int u = threadIdx.x + j * kPotThreads;
+      if (u < kBwdNX + 4) xs[u] = xr[j];
+    }
+    {
+      f4 dz;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        dz[2 * u] = mr[u] == 1u ? gr[u] : 0.f;
+        dz[2 * u + 1] = mr[u] == 2u ? gr[u] : 0.f;
+      }
+      *reinterpret_cast<f4*>(dz2s + wave * kDz2Row + 4 * lane) = dz;
+    }
+    if (item + gridDim.x < work) prefetch(item + gridDim.x);
+    __syncthreads();
+    {  // ---- phase A: channels 2w, 2w+1 at a1 positions r = R0 - 1 + u
+      f2 xp[6];
+      {
+        const f4 a = *reinterpret_cast<const f4*>(xs + 2 * R0 + 8),
+                 b = *reinterpret_cast<const f4*>(xs + 2 * R0 + 12),
+                 c = *reinterpret_cast<const f4*>(xs + 2 * R0 + 16);
+        xp[0] = f2{a.x, a.y}; xp[1] = f2{a.z, a.w}; xp[2] = f2{b.x, b.y};
+        xp[3] = f2{b.z, b.w}; xp[4] = f2{c.x, c.y}; xp[5] = f2{c.z, c.w};
+      }
+      f2 cp[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) cp[m] = b1p;
+      PairConv1<0>::run(cp, w1p, xp);
+      uint32_t sel[2] = {0u, 0u};                      // 2 bits per position u, per channel
+      f2 a1v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = 2 * p0 + R0 - 1 + u, r = R0 - 1 + u;
+        const bool valid = q >= 0 && q < d.P1, owned = r >= 0 && r < kBwdNS;
+        float a;
+        uint32_t sc;
+        relu_pool2(cp[2 * u].x, cp[2 * u + 1].x, valid, a, sc);
+        a1v[u].x = a;
+        if (owned) sel[0] |= sc << (2 * u);
+        relu_pool2(cp[2 * u].y, cp[2 * u + 1].y, valid, a, sc);
+        a1v[u].y = a;
+        if (owned) sel[1] |= sc << (2 * u);
+      }
+      {
+        float* dst = a1p + ((size_t)wave * kBwdNQ + R0 + 4) * 2;
+        *reinterpret_cast<f4*>(dst) = f4{a1v[0].x, a1v[0].y, a1v[1].x, a1v[1].y};
+        *reinterpret_cast<f4*>(dst + 4) = f4{a1v[2].x, a1v[2].y, a1v[3].x, a1v[3].y};
+      }
+      f2 da[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+      for (int co = 0; co < kC2; ++co) {
+        const f4 lo = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + R0),
+                 hi = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + R0 + 4);
+        const f2 dwp[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
+        PairDgrad<0>::run(da, w2p[co], dwp);
+      }
+      f2 dd[8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t s0 = (sel[0] >> (2 * u)) & 3u, s1 = (sel[1] >> (2 * u)) & 3u;
+        dd[2 * u] = f2{s0 == 1u ? da[u].x : 0.f, s1 == 1u ? da[u].y : 0.f};
+        dd[2 * u + 1] = f2{s0 == 2u ? da[u].x : 0.f, s1 == 2u ? da[u].y : 0.f};
+      }
+      accb1p += ((dd[0] + dd[1]) + (dd[2] + dd[3])) + ((dd[4] + dd[5]) + (dd[6] + dd[7]));
+      PairGw1<0>::run(acc1p, dd, xp);
+    }
+    __syncthreads();                                   // a1p complete
+    {  // ---- phase B, wave = co: owned conv2 positions s0 .. s0+3 = pooled outputs 2 lane, 2 lane + 1
+      const int s0 = 4 * lane;
+      const f4 dv = *reinterpret_cast<const f4*>(dz2s + wave * kDz2Row + s0 + 4);
+      // one of dv[2j], dv[2j+1] is zero (or both): the winner's gradient and which one it was
+      f2 g = {dv.x + dv.y, dv.z + dv.w};
+      const int sh0 = dv.y != 0.f ? 1 : 0, sh1 = dv.w != 0.f ? 1 : 0;
+      if (s0 >= kBwdNS) g = f2{0.f, 0.f};             // (kBwdNS is even: a pooled pair is owned or not)
+      if (s0 + 2 >= kBwdNS) g.y = 0.f;
+      accb2 += g.x + g.y;
+      if (s0 < kBwdNS) {
+        // a1 needed by conv2 position s, tap k: index s + 4 + k; pairs are 8 bytes
+        const float* base0 = a1p + (size_t)(s0 + 4 + sh0) * 2;
+        const float* base1 = a1p + (size_t)(s0 + 6 + sh1) * 2;
+#pragma unroll
+        for (int cpi = 0; cpi < kC1 / 2; ++cpi) {
+          f2 w0[kK], w1v[kK];
+#pragma unroll
+          for (int k = 0; k < kK; ++k) {
+            w0[k] = *reinterpret_cast<const f2*>(base0 + ((size_t)cpi * kBwdNQ + k) * 2);
+            w1v[k] = *reinterpret_cast<const f2*>(base1 + ((size_t)cpi * kBwdNQ + k) * 2);
+          }
+#pragma unroll
+          for (int k = 0; k < kK; ++k) {
+            pkfma_lo(acc2p[cpi][k], w0[k], g);
+            pkfma_hi(acc2p[cpi][k], w1v[k], g);
+          }
+        }
+      }
+    }
+  }
+
+  float flat[kNAcc];
+#pragma unroll
+  for (int ci = 0; ci < kC1; ++ci)
+#pragma unroll
+    for (int k = 0; k < kK; ++k) flat[ci * kK + k] = (ci & 1) ? acc2p[ci >> 1][k].y : acc2p[ci >> 1][k].x;
+  flat[40] = accb2;
+#pragma unroll
+  for (int k = 0; k < kK; ++k) {
+    flat[41 + k] = acc1p[k].x;
+    flat[41 + kK + k] = acc1p[k].y;
+  }
+  flat[51] = accb1p.x;
+  flat[52] = accb1p.y;
+#pragma unroll
+  for (int e = 0; e < kNAcc; ++e) flat[e] = wave_sum_lane63(flat[e]);
+  __syncthreads();
+  if (lane == 63)
+#pragma unroll
+    for (int e = 0; e < kNAcc; ++e) red[wave * kNAcc + e] = flat[e];
+  __syncthreads();
+  for (int e = threadIdx.x; e < kNGrad; e += kPotThreads) {
+    float v;
+    if (e < kNW1) {
+      const int ci = e / kK, k = e - ci * kK;
+      v = red[(ci >> 1) * kNAcc + 41 + (ci & 1) * kK + k];
+    } else if (e < kNW1 + kC1) {
+      const int ci = e - kNW1;
+      v = red[(ci >> 1) * kNAcc + 51 + (ci & 1)];
+    } else if (e < kNW1 + kC1 + kNW2) {
+      const int f = e - kNW1 - kC1;
+      const int co = f / (kC1 * kK), rest = f - co * (kC1 * kK);
+      v = red[co * kNAcc + rest];
+    } else {
+      v = red[(e - kNW1 - kC1 - kNW2) * kNAcc + 40];
+    }
+    partial[(size_t)blockIdx.x * kNGrad + e] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------- input gradient
 // dL/dx for saliency maps (saliency.py:52-61 differentiates the class score w.r.t. the INPUT).
 // Tile g owns the input positions u = 4*p0 + v, v < 4*TP (p0 = g*TP, TP = 124).  dL/dx[u] needs
@@ -1975,7 +2271,11 @@ extern "C" int pcgmix_potes_stack_bwd_mask_f32(const float* x, const float* grad
   const int G = pcgmix_potes_bwd_blocks(N, T);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   static const bool fused = getenv("PCGMIX_POTES_BWD_UNFUSED") == nullptr;     // A/B runs
-  if (fused)
+  static const bool pairs = getenv("PCGMIX_POTES_BWD_NO_PAIRS") == nullptr;
+  if (fused && pairs)
+    hipLaunchKernelGGL(potes_bwd_pair_kernel, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2,
+                       m2, w1, b1, w2, b2, partial, N, T);
+  else if (fused)
     hipLaunchKernelGGL(potes_bwd_fused_kernel, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2,
                        m2, w1, b1, w2, b2, partial, N, T);
   else
