@@ -1288,21 +1288,30 @@ struct PairGw1 {     // acc[k] += dd[i] * x[i + k], i = I .. 7
   }
 };
 
-__global__ __launch_bounds__(kPotThreads) void potes_bwd_pair_kernel(
+// One block barrier per item: the staging buffers (x window, routed dz2) are double-buffered, and a
+// wave needs nothing from the other waves after it — it owns its channel pair through ALL phases:
+// layer 1, back through conv2, gw1, and the second-layer weight gradient towards its two channels
+// for all four output channels (its a1 rows cross lanes through a wave-private LDS region, which
+// needs no barrier: a wave's LDS operations execute in order).  The first version of this kernel
+// kept the fused kernel's three barriers per item and was exactly as slow as it (73.6 us against
+// 73.8) with 44 % fewer VALU instructions: the fused kernel's "71 % VALU-issue-bound" was three
+// blocks per CU each waiting at barriers most of the time, not arithmetic.
+__global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
     const float* __restrict__ x, const float* __restrict__ gh2, const uint8_t* __restrict__ m2,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
     const float* __restrict__ b2, float* __restrict__ partial /* gridDim.x * 212 */, int N, int T) {
-  __shared__ __align__(16) float xs[kBwdNX + 4];
-  __shared__ __align__(16) float a1p[kC1 * kBwdNQ];            // [channel pair][position][2]
-  __shared__ __align__(16) float dz2s[kC2 * (kBwdNJ + 12)];
-  __shared__ float red[4 * kNAcc];
   constexpr int kDz2Row = kBwdNJ + 12;
+  constexpr int kXsLen = kBwdNX + 4;
+  __shared__ __align__(16) float xs2[2][kXsLen];
+  __shared__ __align__(16) float dz2s2[2][kC2 * kDz2Row];
+  __shared__ __align__(16) float a1p[kC1 * kBwdNQ];            // [wave = channel pair][position][2]
+  __shared__ float red[4 * kNAcc];
   const PotesDims d = potes_dims(T);
   const int tiles = potes_bwd_tiles(d);
   const unsigned work = (unsigned)N * (unsigned)tiles;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int i = threadIdx.x; i < kC2 * kDz2Row; i += kPotThreads) dz2s[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * kC2 * kDz2Row; i += kPotThreads) (&dz2s2[0][0])[i] = 0.f;
 
   // wave-uniform weight pairs (scalar loads): first-layer taps and bias of channels 2w, 2w+1, and
   // for every (co, k) the second-layer weights towards those two channels
@@ -1317,16 +1326,16 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_pair_kernel(
     for (int k = 0; k < kK; ++k)
       w2p[co][k] = f2{w2[(co * kC1 + c0) * kK + k], w2[(co * kC1 + c0 + 1) * kK + k]};
 
-  f2 acc2p[kC1 / 2][kK], acc1p[kK], accb1p = {0.f, 0.f};
-  float accb2 = 0.f;
+  f2 acc2p[kC2][kK], acc1p[kK], accb1p = {0.f, 0.f};   // acc2p[co][k] = (ci = 2w, ci = 2w+1)
+  float accb2 = 0.f;                                    // gb2[co = wave]
 #pragma unroll
-  for (int cp = 0; cp < kC1 / 2; ++cp)
+  for (int co = 0; co < kC2; ++co)
 #pragma unroll
-    for (int k = 0; k < kK; ++k) acc2p[cp][k] = f2{0.f, 0.f};
+    for (int k = 0; k < kK; ++k) acc2p[co][k] = f2{0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < kK; ++k) acc1p[k] = f2{0.f, 0.f};
 
-  constexpr int kXPer = (kBwdNX + 4 + kPotThreads - 1) / kPotThreads;   // 3
+  constexpr int kXPer = (kXsLen + kPotThreads - 1) / kPotThreads;   // 3
   float xr[kXPer], gr[2];
   uint32_t mr[2] = {0u, 0u};
   const int m2s = (d.P2 + 3) / 4;
@@ -1337,7 +1346,7 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_pair_kernel(
 #pragma unroll
     for (int j = 0; j < kXPer; ++j) {
       const int u = threadIdx.x + j * kPotThreads, g = xlo + u;
-      xr[j] = (u < kBwdNX + 4 && g >= 0 && g < T) ? xrow[g] : 0.f;
+      xr[j] = (u < kXsLen && g >= 0 && g < T) ? xrow[g] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -1351,14 +1360,19 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_pair_kernel(
   if (blockIdx.x < work) prefetch(blockIdx.x);
   __syncthreads();                                   // dz2s zeroed before the first item writes it
   const int R0 = 4 * lane;                           // a1 positions r = R0 - 1 + u, u < 4
+  float* const a1w = a1p + (size_t)wave * kBwdNQ * 2;   // this wave's rows (positions 0 .. 259)
 
-  for (unsigned item = blockIdx.x; item < work; item += gridDim.x) {
+  int buf = 0;
+  for (unsigned item = blockIdx.x; item < work; item += gridDim.x, buf ^= 1) {
     const int p0 = (int)(item % (unsigned)tiles) * kBwdTP;
-    __syncthreads();  // previous item's LDS fully consumed
+    float* const xs = xs2[buf];
+    float* const dz2s = dz2s2[buf];
+    // (no barrier in front: the buffers of this item were last READ two items ago, and every wave
+    // has passed the previous item's barrier since)
 #pragma unroll
     for (int j = 0; j < kXPer; ++j) {
       const int u = threadIdx.x + j * kPotThreads;
-      if (u < kBwdNX + 4) xs[u] = xr[j];
+      if (u < kXsLen) xs[u] = xr[j];
     }
     {
       f4 dz;
@@ -1371,20 +1385,20 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_pair_kernel(
     }
     if (item + gridDim.x < work) prefetch(item + gridDim.x);
     __syncthreads();
-    {  // ---- phase A: channels 2w, 2w+1 at a1 positions r = R0 - 1 + u
-      f2 xp[6];
-      {
-        const f4 a = *reinterpret_cast<const f4*>(xs + 2 * R0 + 8),
-                 b = *reinterpret_cast<const f4*>(xs + 2 * R0 + 12),
-                 c = *reinterpret_cast<const f4*>(xs + 2 * R0 + 16);
-        xp[0] = f2{a.x, a.y}; xp[1] = f2{a.z, a.w}; xp[2] = f2{b.x, b.y};
-        xp[3] = f2{b.z, b.w}; xp[4] = f2{c.x, c.y}; xp[5] = f2{c.z, c.w};
-      }
+    f2 xp[6];
+    {
+      const f4 a = *reinterpret_cast<const f4*>(xs + 2 * R0 + 8),
+               b = *reinterpret_cast<const f4*>(xs + 2 * R0 + 12),
+               c = *reinterpret_cast<const f4*>(xs + 2 * R0 + 16);
+      xp[0] = f2{a.x, a.y}; xp[1] = f2{a.z, a.w}; xp[2] = f2{b.x, b.y};
+      xp[3] = f2{b.z, b.w}; xp[4] = f2{c.x, c.y}; xp[5] = f2{c.z, c.w};
+    }
+    uint32_t sel[2] = {0u, 0u};                        // 2 bits per position u, per channel
+    {  // ---- layer 1 of channels 2w, 2w+1 at a1 positions r = R0 - 1 + u -> wave-private LDS rows
       f2 cp[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) cp[m] = b1p;
       PairConv1<0>::run(cp, w1p, xp);
-      uint32_t sel[2] = {0u, 0u};                      // 2 bits per position u, per channel
       f2 a1v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -1399,11 +1413,11 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_pair_kernel(
         a1v[u].y = a;
         if (owned) sel[1] |= sc << (2 * u);
       }
-      {
-        float* dst = a1p + ((size_t)wave * kBwdNQ + R0 + 4) * 2;
-        *reinterpret_cast<f4*>(dst) = f4{a1v[0].x, a1v[0].y, a1v[1].x, a1v[1].y};
-        *reinterpret_cast<f4*>(dst + 4) = f4{a1v[2].x, a1v[2].y, a1v[3].x, a1v[3].y};
-      }
+      float* dst = a1w + (size_t)(R0 + 4) * 2;
+      *reinterpret_cast<f4*>(dst) = f4{a1v[0].x, a1v[0].y, a1v[1].x, a1v[1].y};
+      *reinterpret_cast<f4*>(dst + 4) = f4{a1v[2].x, a1v[2].y, a1v[3].x, a1v[3].y};
+    }
+    {  // ---- back through conv2 to these positions, routed by the selectors into gw1 / gb1
       f2 da[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
       for (int co = 0; co < kC2; ++co) {
@@ -1422,43 +1436,49 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_pair_kernel(
       accb1p += ((dd[0] + dd[1]) + (dd[2] + dd[3])) + ((dd[4] + dd[5]) + (dd[6] + dd[7]));
       PairGw1<0>::run(acc1p, dd, xp);
     }
-    __syncthreads();                                   // a1p complete
-    {  // ---- phase B, wave = co: owned conv2 positions s0 .. s0+3 = pooled outputs 2 lane, 2 lane + 1
+    // the wave's a1 rows are complete in LDS for the wave itself (its LDS operations run in order);
+    // only the compiler has to be told not to move the reads below across the stores above
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {  // ---- gw2 towards channels 2w, 2w+1: owned conv2 positions s0 .. s0+3 = two pooled outputs
       const int s0 = 4 * lane;
-      const f4 dv = *reinterpret_cast<const f4*>(dz2s + wave * kDz2Row + s0 + 4);
-      // one of dv[2j], dv[2j+1] is zero (or both): the winner's gradient and which one it was
-      f2 g = {dv.x + dv.y, dv.z + dv.w};
-      const int sh0 = dv.y != 0.f ? 1 : 0, sh1 = dv.w != 0.f ? 1 : 0;
-      if (s0 >= kBwdNS) g = f2{0.f, 0.f};             // (kBwdNS is even: a pooled pair is owned or not)
-      if (s0 + 2 >= kBwdNS) g.y = 0.f;
-      accb2 += g.x + g.y;
       if (s0 < kBwdNS) {
-        // a1 needed by conv2 position s, tap k: index s + 4 + k; pairs are 8 bytes
-        const float* base0 = a1p + (size_t)(s0 + 4 + sh0) * 2;
-        const float* base1 = a1p + (size_t)(s0 + 6 + sh1) * 2;
 #pragma unroll
-        for (int cpi = 0; cpi < kC1 / 2; ++cpi) {
-          f2 w0[kK], w1v[kK];
+        for (int co = 0; co < kC2; ++co) {
+          const f4 dv = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + s0 + 4);
+          // one of dv[2j], dv[2j+1] is zero (or both): the winner's gradient and which one it was
+          f2 g = {dv.x + dv.y, dv.z + dv.w};
+          const int sh0 = dv.y != 0.f ? 1 : 0, sh1 = dv.w != 0.f ? 1 : 0;
+          if (s0 + 2 >= kBwdNS) g.y = 0.f;            // (kBwdNS is even: a pooled pair is owned or not)
+          if (co == wave) accb2 += g.x + g.y;
+          // a1 needed by conv2 position s, tap k: row index s + 4 + k; one (c0, c1) pair = 8 bytes
+          const float* base0 = a1w + (size_t)(s0 + 4 + sh0) * 2;
+          const float* base1 = a1w + (size_t)(s0 + 6 + sh1) * 2;
+          f2 wa[kK], wb[kK];
 #pragma unroll
           for (int k = 0; k < kK; ++k) {
-            w0[k] = *reinterpret_cast<const f2*>(base0 + ((size_t)cpi * kBwdNQ + k) * 2);
-            w1v[k] = *reinterpret_cast<const f2*>(base1 + ((size_t)cpi * kBwdNQ + k) * 2);
+            wa[k] = *reinterpret_cast<const f2*>(base0 + 2 * k);
+            wb[k] = *reinterpret_cast<const f2*>(base1 + 2 * k);
           }
 #pragma unroll
           for (int k = 0; k < kK; ++k) {
-            pkfma_lo(acc2p[cpi][k], w0[k], g);
-            pkfma_hi(acc2p[cpi][k], w1v[k], g);
+            pkfma_lo(acc2p[co][k], wa[k], g);
+            pkfma_hi(acc2p[co][k], wb[k], g);
           }
         }
       }
     }
   }
 
-  float flat[kNAcc];
+  float flat[kNAcc];   // [co*10 + c*5 + k] gw2 towards channel 2w+c | [40] gb2[w] | gw1 | gb1
 #pragma unroll
-  for (int ci = 0; ci < kC1; ++ci)
+  for (int co = 0; co < kC2; ++co)
 #pragma unroll
-    for (int k = 0; k < kK; ++k) flat[ci * kK + k] = (ci & 1) ? acc2p[ci >> 1][k].y : acc2p[ci >> 1][k].x;
+    for (int k = 0; k < kK; ++k) {
+      flat[co * 10 + k] = acc2p[co][k].x;
+      flat[co * 10 + kK + k] = acc2p[co][k].y;
+    }
   flat[40] = accb2;
 #pragma unroll
   for (int k = 0; k < kK; ++k) {
@@ -1485,7 +1505,8 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_pair_kernel(
     } else if (e < kNW1 + kC1 + kNW2) {
       const int f = e - kNW1 - kC1;
       const int co = f / (kC1 * kK), rest = f - co * (kC1 * kK);
-      v = red[co * kNAcc + rest];
+      const int ci = rest / kK, k = rest - ci * kK;
+      v = red[(ci >> 1) * kNAcc + co * 10 + (ci & 1) * kK + k];
     } else {
       v = red[(e - kNW1 - kC1 - kNW2) * kNAcc + 40];
     }

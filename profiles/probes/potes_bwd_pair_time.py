@@ -29,7 +29,7 @@ partial = torch.empty(4096, 212, device=dev); grads = torch.empty(212, device=de
 st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 P = lambda t: t.data_ptr()
 lib.pcgmix_potes_stack_fwd_save_f32(P(x), P(w1), P(b1), P(w2), P(b2), P(h2), P(m2), None, N, T, None, 0, None, 0, st)
-for blocks in (768, 1024):
+for blocks in (768, 1024, 1280):
     os.environ["PCGMIX_POTES_BWD_BLOCKS"] = str(blocks)
     f = lambda: lib.pcgmix_potes_stack_bwd_mask_f32(P(x), P(g), P(m2), P(w1), P(b1), P(w2), P(b2), P(partial), P(grads), N, T, st)
     for _ in range(10): f()
