@@ -1335,26 +1335,35 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
 #pragma unroll
   for (int k = 0; k < kK; ++k) acc1p[k] = f2{0.f, 0.f};
 
+  // The next item's inputs are requested into registers here and consumed one item later.  Every
+  // load goes to a clamped in-range address UNCONDITIONALLY and nothing is computed from a loaded
+  // value before the next iteration: `cond ? p[i] : 0` compiles to a branch around the load, and
+  // the routing byte's shift-and-mask right behind its load put an `s_waitcnt vmcnt` into that
+  // branch — two exposed memory round trips per item, which is what bounded the fused kernel and
+  // the first two versions of this one at ~5.5 us per item (three different instruction counts,
+  // barrier counts and occupancies, one and the same 73 us).
   constexpr int kXPer = (kXsLen + kPotThreads - 1) / kPotThreads;   // 3
   float xr[kXPer], gr[2];
-  uint32_t mr[2] = {0u, 0u};
+  uint32_t mb[2] = {0u, 0u};           // raw routing bytes; decoded when they are used
+  int p0_pref = 0;                     // the tile the registers belong to
   const int m2s = (d.P2 + 3) / 4;
   auto prefetch = [&](unsigned it) {
     const int n = (int)(it / (unsigned)tiles), p0 = (int)(it - (unsigned)n * (unsigned)tiles) * kBwdTP;
+    p0_pref = p0;
     const int xlo = 2 * (2 * p0 - 5) - 1;
     const float* xrow = x + (size_t)n * T;
 #pragma unroll
     for (int j = 0; j < kXPer; ++j) {
-      const int u = threadIdx.x + j * kPotThreads, g = xlo + u;
-      xr[j] = (u < kXsLen && g >= 0 && g < T) ? xrow[g] : 0.f;
+      const int g = xlo + (int)threadIdx.x + j * kPotThreads;
+      xr[j] = xrow[g < 0 ? 0 : (g >= T ? T - 1 : g)];
     }
+    const float* grow = gh2 + ((size_t)n * kC2 + wave) * d.P2;
+    const uint8_t* mrow = m2 + ((size_t)n * kC2 + wave) * m2s;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int pe = p0 - 2 + 2 * lane + u;
-      gr[u] = (pe >= 0 && pe < d.P2) ? gh2[((size_t)n * kC2 + wave) * d.P2 + pe] : 0.f;
-      mr[u] = (pe >= 0 && pe < d.P2)
-                  ? (m2[((size_t)n * kC2 + wave) * m2s + (pe >> 2)] >> (2 * (pe & 3))) & 3u
-                  : 0u;
+      const int pe = p0 - 2 + 2 * lane + u, pc = pe < 0 ? 0 : (pe >= d.P2 ? d.P2 - 1 : pe);
+      gr[u] = grow[pc];
+      mb[u] = mrow[pc >> 2];
     }
   };
   if (blockIdx.x < work) prefetch(blockIdx.x);
@@ -1369,17 +1378,21 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
     float* const dz2s = dz2s2[buf];
     // (no barrier in front: the buffers of this item were last READ two items ago, and every wave
     // has passed the previous item's barrier since)
-#pragma unroll
-    for (int j = 0; j < kXPer; ++j) {
-      const int u = threadIdx.x + j * kPotThreads;
-      if (u < kXsLen) xs[u] = xr[j];
-    }
     {
+      const int xlo = 2 * (2 * p0_pref - 5) - 1;
+#pragma unroll
+      for (int j = 0; j < kXPer; ++j) {
+        const int u = threadIdx.x + j * kPotThreads, g = xlo + u;
+        if (u < kXsLen) xs[u] = (g >= 0 && g < T) ? xr[j] : 0.f;
+      }
       f4 dz;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        dz[2 * u] = mr[u] == 1u ? gr[u] : 0.f;
-        dz[2 * u + 1] = mr[u] == 2u ? gr[u] : 0.f;
+        const int pe = p0_pref - 2 + 2 * lane + u;
+        const bool in = pe >= 0 && pe < d.P2;
+        const uint32_t code = in ? (mb[u] >> (2 * (pe & 3))) & 3u : 0u;
+        dz[2 * u] = code == 1u ? gr[u] : 0.f;
+        dz[2 * u + 1] = code == 2u ? gr[u] : 0.f;
       }
       *reinterpret_cast<f4*>(dz2s + wave * kDz2Row + 4 * lane) = dz;
     }
