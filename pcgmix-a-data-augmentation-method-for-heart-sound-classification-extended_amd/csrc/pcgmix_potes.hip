@@ -1304,7 +1304,15 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
   constexpr int kXsLen = kBwdNX + 4;
   __shared__ __align__(16) float xs2[2][kXsLen];
   __shared__ __align__(16) float dz2s2[2][kC2 * kDz2Row];
-  __shared__ __align__(16) float a1p[kC1 * kBwdNQ];            // [wave = channel pair][position][2]
+  // a1 of the wave's channel pair, one (c0, c1) pair = 8 bytes per position, in FOUR planes by
+  // position mod 4 (plane pitch kA1Plane pairs = 0 mod 32): lane l works on positions 4l + c, so for
+  // any fixed c the 64 lanes read consecutive 8-byte words of one plane, and lanes whose window is
+  // shifted by one (the winner of their pooled pair) read another plane at the same word offset —
+  // no two lanes of a pass share a bank.  (Position-major rows, lane stride 32 bytes, cost four-way
+  // conflicts on every one of the 40 window reads: 16.5 M conflict cycles, 62 % of the LDS pipe's
+  // active time, profiles/r4_potes_bwd_pair_sq_counters.json "v3".)
+  constexpr int kA1Plane = 96;                                  // >= kBwdNQ / 4 + 1, multiple of 32
+  __shared__ __align__(16) float a1p[4 * 4 * kA1Plane * 2];     // [wave][plane][word][2]
   __shared__ float red[4 * kNAcc];
   const PotesDims d = potes_dims(T);
   const int tiles = potes_bwd_tiles(d);
@@ -1369,7 +1377,7 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
   if (blockIdx.x < work) prefetch(blockIdx.x);
   __syncthreads();                                   // dz2s zeroed before the first item writes it
   const int R0 = 4 * lane;                           // a1 positions r = R0 - 1 + u, u < 4
-  float* const a1w = a1p + (size_t)wave * kBwdNQ * 2;   // this wave's rows (positions 0 .. 259)
+  float* const a1w = a1p + (size_t)wave * 4 * kA1Plane * 2;   // this wave's planes
 
   int buf = 0;
   for (unsigned item = blockIdx.x; item < work; item += gridDim.x, buf ^= 1) {
@@ -1426,9 +1434,9 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
         a1v[u].y = a;
         if (owned) sel[1] |= sc << (2 * u);
       }
-      float* dst = a1w + (size_t)(R0 + 4) * 2;
-      *reinterpret_cast<f4*>(dst) = f4{a1v[0].x, a1v[0].y, a1v[1].x, a1v[1].y};
-      *reinterpret_cast<f4*>(dst + 4) = f4{a1v[2].x, a1v[2].y, a1v[3].x, a1v[3].y};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)                      // position R0 + 4 + u: plane u, word lane + 1
+        *reinterpret_cast<f2*>(a1w + (size_t)(u * kA1Plane + lane + 1) * 2) = a1v[u];
     }
     {  // ---- back through conv2 to these positions, routed by the selectors into gw1 / gb1
       f2 da[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -1465,14 +1473,14 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
           const int sh0 = dv.y != 0.f ? 1 : 0, sh1 = dv.w != 0.f ? 1 : 0;
           if (s0 + 2 >= kBwdNS) g.y = 0.f;            // (kBwdNS is even: a pooled pair is owned or not)
           if (co == wave) accb2 += g.x + g.y;
-          // a1 needed by conv2 position s, tap k: row index s + 4 + k; one (c0, c1) pair = 8 bytes
-          const float* base0 = a1w + (size_t)(s0 + 4 + sh0) * 2;
-          const float* base1 = a1w + (size_t)(s0 + 6 + sh1) * 2;
+          // a1 needed by conv2 position s, tap k: position s + 4 + k = 4 lane + c with
+          // c = 4 + 2j + shift + k in 4 .. 11: plane c & 3, word lane + (c >> 2)
           f2 wa[kK], wb[kK];
 #pragma unroll
           for (int k = 0; k < kK; ++k) {
-            wa[k] = *reinterpret_cast<const f2*>(base0 + 2 * k);
-            wb[k] = *reinterpret_cast<const f2*>(base1 + 2 * k);
+            const int ca = 4 + k + sh0, cb = 6 + k + sh1;
+            wa[k] = *reinterpret_cast<const f2*>(a1w + (size_t)((ca & 3) * kA1Plane + lane + (ca >> 2)) * 2);
+            wb[k] = *reinterpret_cast<const f2*>(a1w + (size_t)((cb & 3) * kA1Plane + lane + (cb >> 2)) * 2);
           }
 #pragma unroll
           for (int k = 0; k < kK; ++k) {
