@@ -1462,30 +1462,30 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {  // ---- gw2 towards channels 2w, 2w+1: owned conv2 positions s0 .. s0+3 = two pooled outputs
+    {  // ---- gw2 towards channels 2w, 2w+1: owned conv2 positions s = s0 .. s0+3, all four co.
+       // a1 needed by position s0 + u, tap k: position 4 lane + 4 + u + k — eight pairs, read once
+       // (plane (u + k) & 3, word lane + 1 + ((u + k) >> 2): fixed offsets, conflict-free) and used
+       // by every co.  (Taking only the pooled pair's WINNER — one shifted 5-tap window per pooled
+       // output — halves the multiply-adds, but the shift is per lane and per co: 40 window reads
+       // with a select in every address instead of 8 fixed ones; measured 60.1 us against this.)
       const int s0 = 4 * lane;
       if (s0 < kBwdNS) {
+        f2 aw[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          aw[c] = *reinterpret_cast<const f2*>(a1w + (size_t)((c & 3) * kA1Plane + lane + 1 + (c >> 2)) * 2);
 #pragma unroll
         for (int co = 0; co < kC2; ++co) {
-          const f4 dv = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + s0 + 4);
-          // one of dv[2j], dv[2j+1] is zero (or both): the winner's gradient and which one it was
-          f2 g = {dv.x + dv.y, dv.z + dv.w};
-          const int sh0 = dv.y != 0.f ? 1 : 0, sh1 = dv.w != 0.f ? 1 : 0;
-          if (s0 + 2 >= kBwdNS) g.y = 0.f;            // (kBwdNS is even: a pooled pair is owned or not)
-          if (co == wave) accb2 += g.x + g.y;
-          // a1 needed by conv2 position s, tap k: position s + 4 + k = 4 lane + c with
-          // c = 4 + 2j + shift + k in 4 .. 11: plane c & 3, word lane + (c >> 2)
-          f2 wa[kK], wb[kK];
+          f4 dv = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + s0 + 4);
+          if (s0 + 2 >= kBwdNS) { dv.z = 0.f; dv.w = 0.f; }     // (kBwdNS is even)
+          if (co == wave) accb2 += (dv.x + dv.y) + (dv.z + dv.w);
+          const f2 dp[2] = {{dv.x, dv.y}, {dv.z, dv.w}};
 #pragma unroll
           for (int k = 0; k < kK; ++k) {
-            const int ca = 4 + k + sh0, cb = 6 + k + sh1;
-            wa[k] = *reinterpret_cast<const f2*>(a1w + (size_t)((ca & 3) * kA1Plane + lane + (ca >> 2)) * 2);
-            wb[k] = *reinterpret_cast<const f2*>(a1w + (size_t)((cb & 3) * kA1Plane + lane + (cb >> 2)) * 2);
-          }
-#pragma unroll
-          for (int k = 0; k < kK; ++k) {
-            pkfma_lo(acc2p[co][k], wa[k], g);
-            pkfma_hi(acc2p[co][k], wb[k], g);
+            pkfma_lo(acc2p[co][k], aw[k], dp[0]);
+            pkfma_hi(acc2p[co][k], aw[k + 1], dp[0]);
+            pkfma_lo(acc2p[co][k], aw[k + 2], dp[1]);
+            pkfma_hi(acc2p[co][k], aw[k + 3], dp[1]);
           }
         }
       }
