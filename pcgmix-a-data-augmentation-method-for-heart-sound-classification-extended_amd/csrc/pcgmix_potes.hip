@@ -1425,14 +1425,17 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
       for (int u = 0; u < 4; ++u) {
         const int q = 2 * p0 + R0 - 1 + u, r = R0 - 1 + u;
         const bool valid = q >= 0 && q < d.P1, owned = r >= 0 && r < kBwdNS;
-        float a;
-        uint32_t sc;
-        relu_pool2(cp[2 * u].x, cp[2 * u + 1].x, valid, a, sc);
-        a1v[u].x = a;
-        if (owned) sel[0] |= sc << (2 * u);
-        relu_pool2(cp[2 * u].y, cp[2 * u + 1].y, valid, a, sc);
-        a1v[u].y = a;
-        if (owned) sel[1] |= sc << (2 * u);
+        // relu_pool2's rule with one v_max3 for the value (finite operands): code 2 if the second
+        // candidate's ReLU is strictly larger, else 1 if the first survives its ReLU, else 0
+        const float za0 = cp[2 * u].x, zb0 = cp[2 * u + 1].x, za1 = cp[2 * u].y, zb1 = cp[2 * u + 1].y;
+        a1v[u].x = valid ? relu_max2(za0, zb0) : 0.f;
+        a1v[u].y = valid ? relu_max2(za1, zb1) : 0.f;
+        const uint32_t sc0 = (zb0 > za0 && zb0 > 0.f) ? 2u : (za0 > 0.f ? 1u : 0u);
+        const uint32_t sc1 = (zb1 > za1 && zb1 > 0.f) ? 2u : (za1 > 0.f ? 1u : 0u);
+        if (valid && owned) {
+          sel[0] |= sc0 << (2 * u);
+          sel[1] |= sc1 << (2 * u);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)                      // position R0 + 4 + u: plane u, word lane + 1
@@ -2194,7 +2197,11 @@ extern "C" int pcgmix_potes_bwd_blocks(int N, int T) {
   if (N <= 0 || T < 14) return 0;
   const pcgmix::PotesDims d = pcgmix::potes_dims(T);
   const long long work = (long long)N * ((d.P2 + 2 + pcgmix::kBwdTP - 1) / pcgmix::kBwdTP);  // = tiles
-  long long cap = 768;  // 3 persistent blocks per CU
+  // persistent blocks: 4 per CU for the channel-pair kernel (128 VGPRs, 4 waves per SIMD: 51.9 us at
+  // 1024 blocks, 53.0 at 768, 52.6 at 1536; profiles/r4_potes_bwd_pair.txt), 3 for the older ones
+  static const bool pairs = getenv("PCGMIX_POTES_BWD_NO_PAIRS") == nullptr &&
+                            getenv("PCGMIX_POTES_BWD_UNFUSED") == nullptr;
+  long long cap = pairs ? 1024 : 768;
   if (const char* env = getenv("PCGMIX_POTES_BWD_BLOCKS")) {   // tuning runs
     const long long v = atoll(env);
     if (v >= 1 && v <= 65535) cap = v;
