@@ -22,7 +22,6 @@
 #include <stdlib.h>
 
 #include <cmath>
-#include <type_traits>
 
 #include "pcgmix_kernels.h"
 
@@ -1380,17 +1379,8 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
   const int R0 = 4 * lane;                           // a1 positions r = R0 - 1 + u, u < 4
   float* const a1w = a1p + (size_t)wave * 4 * kA1Plane * 2;   // this wave's planes
 
-  // which of this lane's four a1 positions r = R0 - 1 + u the tile owns (0 <= r < kBwdNS): per lane
-  uint32_t own_mask = 0;
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-    if (R0 - 1 + u >= 0 && R0 - 1 + u < kBwdNS) own_mask |= 3u << (2 * u);
-
-  // One item.  EDGE = false: a tile in the interior of its row (8 of 10 at T = 5000) — every sample,
-  // pooled output and a1 position its lanes touch exists, so the range checks and their selects
-  // are compiled out.
-  auto run_item = [&](unsigned item, int buf, auto edge_tag) {
-    constexpr bool EDGE = decltype(edge_tag)::value;
+  int buf = 0;
+  for (unsigned item = blockIdx.x; item < work; item += gridDim.x, buf ^= 1) {
     const int p0 = (int)(item % (unsigned)tiles) * kBwdTP;
     float* const xs = xs2[buf];
     float* const dz2s = dz2s2[buf];
@@ -1401,13 +1391,13 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
 #pragma unroll
       for (int j = 0; j < kXPer; ++j) {
         const int u = threadIdx.x + j * kPotThreads, g = xlo + u;
-        if (u < kXsLen) xs[u] = (!EDGE || (g >= 0 && g < T)) ? xr[j] : 0.f;
+        if (u < kXsLen) xs[u] = (g >= 0 && g < T) ? xr[j] : 0.f;
       }
       f4 dz;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int pe = p0_pref - 2 + 2 * lane + u;
-        const bool in = !EDGE || (pe >= 0 && pe < d.P2);
+        const bool in = pe >= 0 && pe < d.P2;
         const uint32_t code = in ? (mb[u] >> (2 * (pe & 3))) & 3u : 0u;
         dz[2 * u] = code == 1u ? gr[u] : 0.f;
         dz[2 * u + 1] = code == 2u ? gr[u] : 0.f;
@@ -1433,8 +1423,8 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
       f2 a1v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int q = 2 * p0 + R0 - 1 + u;
-        const bool valid = !EDGE || (q >= 0 && q < d.P1);
+        const int q = 2 * p0 + R0 - 1 + u, r = R0 - 1 + u;
+        const bool valid = q >= 0 && q < d.P1, owned = r >= 0 && r < kBwdNS;
         // relu_pool2's rule with one v_max3 for the value (finite operands): code 2 if the second
         // candidate's ReLU is strictly larger, else 1 if the first survives its ReLU, else 0
         const float za0 = cp[2 * u].x, zb0 = cp[2 * u + 1].x, za1 = cp[2 * u].y, zb1 = cp[2 * u + 1].y;
@@ -1442,15 +1432,15 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
         a1v[u].y = valid ? relu_max2(za1, zb1) : 0.f;
         const uint32_t sc0 = (zb0 > za0 && zb0 > 0.f) ? 2u : (za0 > 0.f ? 1u : 0u);
         const uint32_t sc1 = (zb1 > za1 && zb1 > 0.f) ? 2u : (za1 > 0.f ? 1u : 0u);
-        sel[0] |= (valid ? sc0 : 0u) << (2 * u);
-        sel[1] |= (valid ? sc1 : 0u) << (2 * u);
+        if (valid && owned) {
+          sel[0] |= sc0 << (2 * u);
+          sel[1] |= sc1 << (2 * u);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)                      // position R0 + 4 + u: plane u, word lane + 1
         *reinterpret_cast<f2*>(a1w + (size_t)(u * kA1Plane + lane + 1) * 2) = a1v[u];
     }
-    sel[0] &= own_mask;
-    sel[1] &= own_mask;
     {  // ---- back through conv2 to these positions, routed by the selectors into gw1 / gb1
       f2 da[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
@@ -1502,22 +1492,6 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
           }
         }
       }
-    }
-  };
-
-  {
-    // interior tiles: 4 p0 - 11 >= 0, p0 - 2 >= 0, 2 p0 - 1 >= 0 and 4 p0 - 11 + kXsLen <= T,
-    // p0 - 2 + 128 <= P2, 2 p0 + 254 < P1
-    const int first_in = 3, p0_max_x = (T - kXsLen + 11) / 4, p0_max_p = d.P2 - 126,
-              p0_max_q = (d.P1 - 255) / 2;
-    int p0_hi = p0_max_x < p0_max_p ? p0_max_x : p0_max_p;
-    p0_hi = p0_hi < p0_max_q ? p0_hi : p0_max_q;
-    int buf = 0;
-    for (unsigned item = blockIdx.x; item < work; item += gridDim.x, buf ^= 1) {
-      // the registers hold the tile prefetched for THIS item (p0_pref), which decides the path
-      const int p0 = (int)(item % (unsigned)tiles) * kBwdTP;
-      if (p0 >= first_in && p0 <= p0_hi && (d.P1 - 255) >= 0) run_item(item, buf, std::false_type{});
-      else run_item(item, buf, std::true_type{});
     }
   }
 
