@@ -1271,6 +1271,22 @@ struct PairDgrad {   // da[u] += w2pair[k] * dz2[u + 4 - k], u = U .. 3
     }
   }
 };
+template <int U>
+struct PairDgradV {  // the same with the weight pairs in vector registers
+  template <int K>
+  static __device__ __forceinline__ void taps(f2& d, const f2 (&w)[kK], const f2 (&dwp)[4]) {
+    if constexpr (K < kK) {
+      pkfma_at<U + 4 - K>(d, w[K], dwp);
+      taps<K + 1>(d, w, dwp);
+    }
+  }
+  static __device__ __forceinline__ void run(f2 (&da)[4], const f2 (&w)[kK], const f2 (&dwp)[4]) {
+    if constexpr (U < 4) {
+      taps<0>(da[U], w, dwp);
+      PairDgradV<U + 1>::run(da, w, dwp);
+    }
+  }
+};
 template <int I>
 struct PairGw1 {     // acc[k] += dd[i] * x[i + k], i = I .. 7
   template <int K>
@@ -1314,6 +1330,10 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
   constexpr int kA1Plane = 96;                                  // >= kBwdNQ / 4 + 1, multiple of 32
   __shared__ __align__(16) float a1p[4 * 4 * kA1Plane * 2];     // [wave][plane][word][2]
   __shared__ float red[4 * kNAcc];
+  // second-layer weights as (towards channel 2w, towards 2w+1) pairs, [wave][co][k]: 40 SGPRs per
+  // wave next to the 12 of the first layer did not fit (59 scalar spills, 55 v_readlane per item);
+  // from LDS they are five broadcast 8-byte reads per co
+  __shared__ __align__(8) float w2ps[4 * kC2 * kK * 2];
   const PotesDims d = potes_dims(T);
   const int tiles = potes_bwd_tiles(d);
   const unsigned work = (unsigned)N * (unsigned)tiles;
@@ -1324,15 +1344,14 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
   // wave-uniform weight pairs (scalar loads): first-layer taps and bias of channels 2w, 2w+1, and
   // for every (co, k) the second-layer weights towards those two channels
   const int c0 = 2 * wave;
-  f2 w1p[kK], w2p[kC2][kK];
+  f2 w1p[kK];
 #pragma unroll
   for (int k = 0; k < kK; ++k) w1p[k] = f2{w1[c0 * kK + k], w1[(c0 + 1) * kK + k]};
   const f2 b1p = {b1[c0], b1[c0 + 1]};
-#pragma unroll
-  for (int co = 0; co < kC2; ++co)
-#pragma unroll
-    for (int k = 0; k < kK; ++k)
-      w2p[co][k] = f2{w2[(co * kC1 + c0) * kK + k], w2[(co * kC1 + c0 + 1) * kK + k]};
+  for (int i = threadIdx.x; i < 4 * kC2 * kK * 2; i += kPotThreads) {
+    const int h = i & 1, k = (i >> 1) % kK, co = (i >> 1) / kK % kC2, wv = (i >> 1) / (kK * kC2);
+    w2ps[i] = w2[(co * kC1 + 2 * wv + h) * kK + k];
+  }
 
   f2 acc2p[kC2][kK], acc1p[kK], accb1p = {0.f, 0.f};   // acc2p[co][k] = (ci = 2w, ci = 2w+1)
   float accb2 = 0.f;                                    // gb2[co = wave]
@@ -1448,7 +1467,11 @@ __global__ __launch_bounds__(kPotThreads, 4) void potes_bwd_pair_kernel(
         const f4 lo = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + R0),
                  hi = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + R0 + 4);
         const f2 dwp[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
-        PairDgrad<0>::run(da, w2p[co], dwp);
+        f2 wv[kK];
+#pragma unroll
+        for (int k = 0; k < kK; ++k)
+          wv[k] = *reinterpret_cast<const f2*>(w2ps + ((wave * kC2 + co) * kK + k) * 2);
+        PairDgradV<0>::run(da, wv, dwp);
       }
       f2 dd[8];
 #pragma unroll
