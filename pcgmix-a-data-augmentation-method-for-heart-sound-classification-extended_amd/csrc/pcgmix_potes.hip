@@ -1811,7 +1811,12 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_mask_kernel(
 // are bank-conflict free, and a position is one 8-byte word wherever it is, so a thread can own the
 // ALIGNED outputs 2t, 2t+1 (one 8-byte global store).  All global loads are unconditional, from
 // clamped addresses, and decoded after the barrier that already waits for them.
-constexpr int kInPlane = 72;
+// Persistent blocks (item = (row, tile), strided): the next item's bytes are requested into
+// registers before the current item's first barrier and decoded after its last one.  Two barriers
+// per item are inherent (dz2 crosses waves into the conv2 back-propagation, dz1 crosses waves into
+// the transposed first layer), and with two of them every LDS buffer's writers and readers are
+// already a barrier apart in both directions: no third one, no double buffering.
+constexpr int kInPlane = 68;     // = 4 mod 16: planes p, p+2, p+4, p+6 start 16 banks apart
 __global__ __launch_bounds__(kPotThreads) void potes_input_grad_pair_kernel(
     const float* __restrict__ gh2, const uint8_t* __restrict__ m2, const uint8_t* __restrict__ s1,
     const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ gx, int N,
@@ -1823,127 +1828,146 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_pair_kernel(
   const PotesDims d = potes_dims(T);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n = blockIdx.y, p0 = blockIdx.x * kInTP;
+  const int tiles = (T + kInNU - 1) / kInNU;
+  const unsigned work = (unsigned)N * (unsigned)tiles;
   const int m2s = (d.P2 + 3) / 4, s1row = potes_s1_row_bytes(d);
-  // ---- everything this block reads from memory, requested up front
-  uint32_t sb[2][2];                       // first-layer selector bytes b0 = b1 - 1, b1 per channel
-  const int sb1 = (p0 >> 1) + lane, sb0 = sb1 - 1;
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const uint8_t* row = s1 + ((size_t)n * kC1 + 2 * wave + c) * s1row;
-    sb[c][0] = row[sb0 < 0 ? 0 : (sb0 >= s1row ? s1row - 1 : sb0)];
-    sb[c][1] = row[sb1 < 0 ? 0 : (sb1 >= s1row ? s1row - 1 : sb1)];
-  }
-  float g[2];
-  uint32_t mbyte[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int pe = p0 - 3 + 2 * lane + u, pc = pe < 0 ? 0 : (pe >= d.P2 ? d.P2 - 1 : pe);
-    g[u] = gh2[((size_t)n * kC2 + wave) * d.P2 + pc];
-    mbyte[u] = m2[((size_t)n * kC2 + wave) * m2s + (pc >> 2)];
-  }
   for (int i = threadIdx.x; i < 4 * kC2 * kK * 2; i += kPotThreads) {
     const int h = i & 1, k = (i >> 1) % kK, co = (i >> 1) / kK % kC2, wv = (i >> 1) / (kK * kC2);
     w2ps[i] = w2[(co * kC1 + 2 * wv + h) * kK + k];
   }
+  for (int i = threadIdx.x; i < kC2 * 12; i += kPotThreads)     // the rows' 12-float pads stay zero
+    dz2s[(i / 12) * kDz2Row + kBwdNJ + i % 12] = 0.f;
   // first-layer weight pairs of all four channel pairs: block-uniform, scalar registers
   f2 w1p[4][kK];
 #pragma unroll
   for (int cp = 0; cp < 4; ++cp)
 #pragma unroll
     for (int k = 0; k < kK; ++k) w1p[cp][k] = f2{w1[(2 * cp) * kK + k], w1[(2 * cp + 1) * kK + k]};
-  {  // dz2 at pe = p0-3+2*lane+u (wave = co); the 12-float pad of each row is zeroed
-    f4 dz;
+
+  // ---- what an item reads from memory: unconditional loads from clamped addresses, decoded later
+  uint32_t sb[2][2];                       // first-layer selector bytes b0 = b1 - 1, b1 per channel
+  float g[2];
+  uint32_t mbyte[2];
+  int n_pref = 0, p0_pref = 0;
+  auto prefetch = [&](unsigned it) {
+    const int n = (int)(it / (unsigned)tiles), p0 = (int)(it - (unsigned)n * (unsigned)tiles) * kInTP;
+    n_pref = n;
+    p0_pref = p0;
+    const int sb1 = (p0 >> 1) + lane, sb0 = sb1 - 1;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const uint8_t* row = s1 + ((size_t)n * kC1 + 2 * wave + c) * s1row;
+      sb[c][0] = row[sb0 < 0 ? 0 : (sb0 >= s1row ? s1row - 1 : sb0)];
+      sb[c][1] = row[sb1 < 0 ? 0 : (sb1 >= s1row ? s1row - 1 : sb1)];
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int pe = p0 - 3 + 2 * lane + u;
-      const uint32_t code = (pe >= 0 && pe < d.P2) ? (mbyte[u] >> (2 * (pe & 3))) & 3u : 0u;
-      dz[2 * u] = code == 1u ? g[u] : 0.f;
-      dz[2 * u + 1] = code == 2u ? g[u] : 0.f;
+      const int pe = p0 - 3 + 2 * lane + u, pc = pe < 0 ? 0 : (pe >= d.P2 ? d.P2 - 1 : pe);
+      g[u] = gh2[((size_t)n * kC2 + wave) * d.P2 + pc];
+      mbyte[u] = m2[((size_t)n * kC2 + wave) * m2s + (pc >> 2)];
     }
-    *reinterpret_cast<f4*>(dz2s + wave * kDz2Row + 4 * lane) = dz;
-    if (lane < 3) *reinterpret_cast<f4*>(dz2s + wave * kDz2Row + kBwdNJ + 4 * lane) = f4{0.f, 0.f, 0.f, 0.f};
-  }
-  // first-layer selectors of this lane's 4 positions q = 2p0-2+4*lane+u for its two channels
-  // (packed: position q sits in bits 2*((q+1)&3) of byte (q+1)>>2; q+1 = 2*p0 - 1 + 4*lane + u with
-  // 2*p0 a multiple of 4, so u = 0 is the top pair of one byte and u = 1..3 the low pairs of the next)
-  uint32_t sc[2][4];
+  };
+  if (blockIdx.x < work) prefetch(blockIdx.x);
+
+  for (unsigned item = blockIdx.x; item < work; item += gridDim.x) {
+    const int n = n_pref, p0 = p0_pref;
+    {  // dz2 at pe = p0-3+2*lane+u (wave = co)
+      f4 dz;
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const uint32_t v0 = (sb0 >= 0 && sb0 < s1row) ? sb[c][0] : 0u;
-    const uint32_t v1 = (sb1 >= 0 && sb1 < s1row) ? sb[c][1] : 0u;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = 4 * lane + u, q = 2 * p0 - 2 + r;
-      const uint32_t code = u == 0 ? (v0 >> 6) & 3u : (v1 >> (2 * (u - 1))) & 3u;
-      sc[c][u] = (r < kInNR && q >= 0 && q < d.P1) ? code : 0u;
-    }
-  }
-  __syncthreads();
-  {  // dL/da1 of channels 2w, 2w+1 at q = 2p0-2+r, r = 4 lane + u, routed -> dz1 at index 2r (+1)
-    const int r0 = 4 * lane;
-    f2 da[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-    for (int co = 0; co < kC2; ++co) {
-      const f4 a = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + r0),
-               b = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + r0 + 4),
-               c = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + r0 + 8);
-      const f2 dwp[6] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}, {c.x, c.y}, {c.z, c.w}};
-      f2 wv[kK];
-#pragma unroll
-      for (int k = 0; k < kK; ++k)
-        wv[k] = *reinterpret_cast<const f2*>(w2ps + ((wave * kC2 + co) * kK + k) * 2);
-      // da[u] += wv[k] * dz2[u + 5 - k]
-      pkfma_at<5>(da[0], wv[0], dwp); pkfma_at<4>(da[0], wv[1], dwp); pkfma_at<3>(da[0], wv[2], dwp);
-      pkfma_at<2>(da[0], wv[3], dwp); pkfma_at<1>(da[0], wv[4], dwp);
-      pkfma_at<6>(da[1], wv[0], dwp); pkfma_at<5>(da[1], wv[1], dwp); pkfma_at<4>(da[1], wv[2], dwp);
-      pkfma_at<3>(da[1], wv[3], dwp); pkfma_at<2>(da[1], wv[4], dwp);
-      pkfma_at<7>(da[2], wv[0], dwp); pkfma_at<6>(da[2], wv[1], dwp); pkfma_at<5>(da[2], wv[2], dwp);
-      pkfma_at<4>(da[2], wv[3], dwp); pkfma_at<3>(da[2], wv[4], dwp);
-      pkfma_at<8>(da[3], wv[0], dwp); pkfma_at<7>(da[3], wv[1], dwp); pkfma_at<6>(da[3], wv[2], dwp);
-      pkfma_at<5>(da[3], wv[3], dwp); pkfma_at<4>(da[3], wv[4], dwp);
-    }
-    float* base = dz1p + ((size_t)wave * 8 * kInPlane + lane) * 2;   // element i -> plane i, word lane
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const f2 first = {sc[0][u] == 1u ? da[u].x : 0.f, sc[1][u] == 1u ? da[u].y : 0.f};
-      const f2 second = {sc[0][u] == 2u ? da[u].x : 0.f, sc[1][u] == 2u ? da[u].y : 0.f};
-      *reinterpret_cast<f2*>(base + (size_t)(2 * u) * kInPlane * 2) = first;
-      *reinterpret_cast<f2*>(base + (size_t)(2 * u + 1) * kInPlane * 2) = second;
-    }
-  }
-  __syncthreads();
-  {  // transposed conv1: dx[v] = sum_ci sum_k dz1[ci][v+5-k] * w1[ci][k]; thread t owns v = 2t, 2t+1
-     // and reads dz1 positions 2t+1 .. 2t+6 of every channel pair
-    const int t = threadIdx.x, v0 = 2 * t;
-    if (v0 < kInNU) {
-      int off[6];                                    // word offsets (in floats) inside a pair's planes
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int pos = v0 + 1 + j;
-        off[j] = ((pos & 7) * kInPlane + (pos >> 3)) * 2;
+      for (int u = 0; u < 2; ++u) {
+        const int pe = p0 - 3 + 2 * lane + u;
+        const uint32_t code = (pe >= 0 && pe < d.P2) ? (mbyte[u] >> (2 * (pe & 3))) & 3u : 0u;
+        dz[2 * u] = code == 1u ? g[u] : 0.f;
+        dz[2 * u + 1] = code == 2u ? g[u] : 0.f;
       }
-      f2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+      *reinterpret_cast<f4*>(dz2s + wave * kDz2Row + 4 * lane) = dz;
+    }
+    // first-layer selectors of this lane's 4 positions q = 2p0-2+4*lane+u for its two channels
+    // (packed: position q sits in bits 2*((q+1)&3) of byte (q+1)>>2; q+1 = 2*p0 - 1 + 4*lane + u
+    // with 2*p0 a multiple of 4, so u = 0 is the top pair of one byte and u = 1..3 the low pairs
+    // of the next)
+    uint32_t sc[2][4];
+    {
+      const int sb1 = (p0 >> 1) + lane, sb0 = sb1 - 1;
 #pragma unroll
-      for (int cp = 0; cp < 4; ++cp) {
-        f2 dp[6];
+      for (int c = 0; c < 2; ++c) {
+        const uint32_t v0 = (sb0 >= 0 && sb0 < s1row) ? sb[c][0] : 0u;
+        const uint32_t v1 = (sb1 >= 0 && sb1 < s1row) ? sb[c][1] : 0u;
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
-          dp[j] = *reinterpret_cast<const f2*>(dz1p + (size_t)cp * 8 * kInPlane * 2 + off[j]);
-#pragma unroll
-        for (int k = 0; k < kK; ++k) {
-          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc0) : "s"(w1p[cp][k]), "v"(dp[4 - k]));
-          asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc1) : "s"(w1p[cp][k]), "v"(dp[5 - k]));
+        for (int u = 0; u < 4; ++u) {
+          const int r = 4 * lane + u, q = 2 * p0 - 2 + r;
+          const uint32_t code = u == 0 ? (v0 >> 6) & 3u : (v1 >> (2 * (u - 1))) & 3u;
+          sc[c][u] = (r < kInNR && q >= 0 && q < d.P1) ? code : 0u;
         }
       }
-      const int u = 4 * p0 + v0;
-      float* dst = gx + (size_t)n * T + u;
-      const float o0 = acc0.x + acc0.y, o1 = acc1.x + acc1.y;
-      if (u + 1 < T && !(reinterpret_cast<uintptr_t>(dst) & 7)) {
-        *reinterpret_cast<f2*>(dst) = f2{o0, o1};
-      } else {
-        if (u < T) dst[0] = o0;
-        if (u + 1 < T) dst[1] = o1;
+    }
+    if (item + gridDim.x < work) prefetch(item + gridDim.x);
+    __syncthreads();
+    {  // dL/da1 of channels 2w, 2w+1 at q = 2p0-2+r, r = 4 lane + u, routed -> dz1 at index 2r (+1)
+      const int r0 = 4 * lane;
+      f2 da[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+      for (int co = 0; co < kC2; ++co) {
+        const f4 a = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + r0),
+                 b = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + r0 + 4),
+                 c = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + r0 + 8);
+        const f2 dwp[6] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}, {c.x, c.y}, {c.z, c.w}};
+        f2 wv[kK];
+#pragma unroll
+        for (int k = 0; k < kK; ++k)
+          wv[k] = *reinterpret_cast<const f2*>(w2ps + ((wave * kC2 + co) * kK + k) * 2);
+        // da[u] += wv[k] * dz2[u + 5 - k]
+        pkfma_at<5>(da[0], wv[0], dwp); pkfma_at<4>(da[0], wv[1], dwp); pkfma_at<3>(da[0], wv[2], dwp);
+        pkfma_at<2>(da[0], wv[3], dwp); pkfma_at<1>(da[0], wv[4], dwp);
+        pkfma_at<6>(da[1], wv[0], dwp); pkfma_at<5>(da[1], wv[1], dwp); pkfma_at<4>(da[1], wv[2], dwp);
+        pkfma_at<3>(da[1], wv[3], dwp); pkfma_at<2>(da[1], wv[4], dwp);
+        pkfma_at<7>(da[2], wv[0], dwp); pkfma_at<6>(da[2], wv[1], dwp); pkfma_at<5>(da[2], wv[2], dwp);
+        pkfma_at<4>(da[2], wv[3], dwp); pkfma_at<3>(da[2], wv[4], dwp);
+        pkfma_at<8>(da[3], wv[0], dwp); pkfma_at<7>(da[3], wv[1], dwp); pkfma_at<6>(da[3], wv[2], dwp);
+        pkfma_at<5>(da[3], wv[3], dwp); pkfma_at<4>(da[3], wv[4], dwp);
+      }
+      float* base = dz1p + ((size_t)wave * 8 * kInPlane + lane) * 2;   // element i -> plane i, word lane
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const f2 first = {sc[0][u] == 1u ? da[u].x : 0.f, sc[1][u] == 1u ? da[u].y : 0.f};
+        const f2 second = {sc[0][u] == 2u ? da[u].x : 0.f, sc[1][u] == 2u ? da[u].y : 0.f};
+        *reinterpret_cast<f2*>(base + (size_t)(2 * u) * kInPlane * 2) = first;
+        *reinterpret_cast<f2*>(base + (size_t)(2 * u + 1) * kInPlane * 2) = second;
+      }
+    }
+    __syncthreads();
+    {  // transposed conv1: dx[v] = sum_ci sum_k dz1[ci][v+5-k] * w1[ci][k]; thread t owns v = 2t, 2t+1
+       // and reads dz1 positions 2t+1 .. 2t+6 of every channel pair
+      const int t = threadIdx.x, v0 = 2 * t;
+      if (v0 < kInNU) {
+        int off[6];                                  // word offsets (in floats) inside a pair's planes
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int pos = v0 + 1 + j;
+          off[j] = ((pos & 7) * kInPlane + (pos >> 3)) * 2;
+        }
+        f2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) {
+          f2 dp[6];
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+            dp[j] = *reinterpret_cast<const f2*>(dz1p + (size_t)cp * 8 * kInPlane * 2 + off[j]);
+#pragma unroll
+          for (int k = 0; k < kK; ++k) {
+            asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc0) : "s"(w1p[cp][k]), "v"(dp[4 - k]));
+            asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc1) : "s"(w1p[cp][k]), "v"(dp[5 - k]));
+          }
+        }
+        const int u = 4 * p0 + v0;
+        float* dst = gx + (size_t)n * T + u;
+        const float o0 = acc0.x + acc0.y, o1 = acc1.x + acc1.y;
+        if (u + 1 < T && !(reinterpret_cast<uintptr_t>(dst) & 7)) {
+          *reinterpret_cast<f2*>(dst) = f2{o0, o1};
+        } else {
+          if (u < T) dst[0] = o0;
+          if (u + 1 < T) dst[1] = o1;
+        }
       }
     }
   }
@@ -2518,10 +2542,16 @@ extern "C" int pcgmix_potes_stack_input_grad_mask_f32(const float* grad_h2, cons
   if (N == 0) return hipSuccess;
   dim3 grid((unsigned)((T + kInNU - 1) / kInNU), (unsigned)N), block(kPotThreads);
   static const bool pairs = getenv("PCGMIX_POTES_INGRAD_NO_PAIRS") == nullptr;     // A/B runs
-  if (pairs)
-    hipLaunchKernelGGL(potes_input_grad_pair_kernel, grid, block, 0,
+  if (pairs) {
+    long long cap = 1536;             // persistent blocks: 6 per CU (50 VGPRs, 22 KB of LDS)
+    if (const char* env = getenv("PCGMIX_POTES_INGRAD_BLOCKS")) {   // tuning runs
+      const long long v = atoll(env);
+      if (v >= 1 && v <= 65535) cap = v;
+    }
+    const long long work = (long long)N * ((T + kInNU - 1) / kInNU);
+    hipLaunchKernelGGL(potes_input_grad_pair_kernel, dim3((unsigned)(work < cap ? work : cap)), block, 0,
                        reinterpret_cast<hipStream_t>(stream), grad_h2, m2, s1, w1, w2, grad_x, N, T);
-  else
+  } else
     hipLaunchKernelGGL(potes_input_grad_mask_kernel, grid, block, 0,
                        reinterpret_cast<hipStream_t>(stream), grad_h2, m2, s1, w1, w2, grad_x, N, T);
   return (int)hipGetLastError();

@@ -697,7 +697,9 @@ def _trained_potes(device, B, T, steps=300):
         losses.append(tm.train_step(args, net, pool[s % 4], device, opt, sched, crit, 1, sc))
     first, last = float(torch.stack(losses[:10]).mean()), float(torch.stack(losses[-10:]).mean())
     assert last < 0.5 * first, (first, last)            # it did learn
-    return net.eval()
+    cpu = tm.build_model(args)                          # the same architecture for the CPU side
+    cpu.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    return net.eval(), cpu.eval()
 
 
 @pytest.mark.parametrize("mode", ["(saloptenv)", "(saloptsum)"])
@@ -712,12 +714,10 @@ def test_displacement_flip_rate_with_a_trained_saliency_model(mode, device, reco
     rate is reported (record_property) and bounded."""
     from pcgmix_amd import synthetic
     B, C, T = 256, 4, 5000
-    net = _trained_potes(device, B, T)
+    net, cpu = _trained_potes(device, B, T)
     x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=2000, seed=77)
     x[labels == 1, 2] *= 3.0
     # reference side: same weights on the CPU through torch's own kernels, the oracle's post-processing
-    cpu = models.CNN_potes_TS(4, 2, "PhysioNet")
-    cpu.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
     sal_ref = O.saliency_post(O.input_gradient(cpu, x, labels), frames)
     # HIP side
     saliency.set_saliency_model(net)
