@@ -2543,7 +2543,10 @@ extern "C" int pcgmix_potes_stack_input_grad_mask_f32(const float* grad_h2, cons
   dim3 grid((unsigned)((T + kInNU - 1) / kInNU), (unsigned)N), block(kPotThreads);
   static const bool pairs = getenv("PCGMIX_POTES_INGRAD_NO_PAIRS") == nullptr;     // A/B runs
   if (pairs) {
-    long long cap = 1536;             // persistent blocks: 6 per CU (50 VGPRs, 22 KB of LDS)
+    // persistent blocks: 6 resident per CU (81 VGPRs, 22 KB of LDS); twice that many, the second
+    // half starting as the first ends, evens out the tail: 1024: 34.0, 1536: 33.2, 2048: 31.3,
+    // 3072: 30.6 us at N = 1024 x 5000 (profiles/r4_potes_ingrad_pair.txt)
+    long long cap = 3072;
     if (const char* env = getenv("PCGMIX_POTES_INGRAD_BLOCKS")) {   // tuning runs
       const long long v = atoll(env);
       if (v >= 1 && v <= 65535) cap = v;
