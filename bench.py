@@ -504,17 +504,11 @@ def secondary_kernel_times(device, B=256, iters=50):
                                             B * (4 * C * T + 4 * T))
     sal = saliency.saliency_post(grad, fr.data_ptr())
     mix = torch.from_numpy(np.random.RandomState(0).permutation(B).astype(np.int32)).to(device)
-    order = saliency.dispatch_order(frames, mix.cpu().numpy())
     for mode, name in ((0, "env"), (1, "sum")):
-        # what the step context launches: pairs dispatched longest chain first
         out[f"salopt_disp_{name}_256x5000"] = entry(
             timeit(lambda: saliency.optimal_displacements(sal, fr.data_ptr(), mix.data_ptr(), 0.37, mode, B, T,
-                                                          max_len=int(np.diff(frames, axis=1).max()),
-                                                          order=order)),
+                                                          max_len=int(np.diff(frames, axis=1).max()))),
             B * 8 * T)
-        out[f"salopt_disp_{name}_256x5000"]["natural_order_us"] = timeit(
-            lambda: saliency.optimal_displacements(sal, fr.data_ptr(), mix.data_ptr(), 0.37, mode, B, T,
-                                                   max_len=int(np.diff(frames, axis=1).max())))
     spec, fs = frontend.logmel(x1, frames)
     tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)
     sc = StepCounter()
@@ -731,9 +725,7 @@ def main():
     if a.kernels_only:
         print("potes:", potes_kernel_times(device), flush=True)
         for k, v in secondary_kernel_times(device).items():
-            print(f"{k:32s} {v['us']:9.1f} us  {v['GBs']:8.1f} GB/s"
-                  + (f"   (natural order {v['natural_order_us']:.1f} us)" if "natural_order_us" in v else ""),
-                  flush=True)
+            print(f"{k:32s} {v['us']:9.1f} us  {v['GBs']:8.1f} GB/s", flush=True)
         for m, b, c, t in (("durratiomixup", 256, 1, 5000), ("durratiomixup", 256, 4, 5000),
                            ("durmixmagwarp(0.2,4)", 256, 1, 5000), ("durmixmagwarp(0.2,4)", 256, 4, 5000),
                            ("durratiomixup", 4096, 4, 5000), ("durmixmagwarp(0.2,4)", 4096, 4, 5000),

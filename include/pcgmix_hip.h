@@ -234,16 +234,6 @@ long long pcgmix_salopt_workspace_bytes(int B);
 int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames, const int32_t* mix_idx,
                            float lam, int mode, int32_t* disp, void* workspace, int max_len, int B,
                            int T, pcgmix_stream_t stream);
-/* The same search with its (sample, state) pairs dispatched in a caller-given order (B <= 256; the
- * order travels in the kernel arguments).  pcgmix_salopt_dispatch_order computes the one the step
- * context uses from the boundaries and partners on the HOST: longest chain of sums first — a pair's
- * blocks run one candidate per lane, a block is as long as the own state, and the launch ends when
- * its last chain does.  order: host, uint16 (B*4), entry = sample << 2 | state.  Results are
- * identical to pcgmix_salopt_disp_f32's in any order.  [dispatch_order: host, returns 0 or 1] */
-int pcgmix_salopt_dispatch_order(const int64_t* frames, const int64_t* mix, int B, uint16_t* order);
-int pcgmix_salopt_disp_ordered_f32(const float* sal, const int32_t* frames, const int32_t* mix_idx,
-                                   float lam, int mode, int32_t* disp, void* workspace, int max_len,
-                                   const uint16_t* order, int B, int T, pcgmix_stream_t stream);
 /* The saliency-guided splice — mixup_keepdur_multidim_tensors_salopt for the whole batch
  * (augmentations.py:210-287 with :60-128, the loop at :909-917, magnitude_warp :674-683) — in one
  * call: the search above, then pcgmix_mix_warp_f32's kernel, whose blocks reduce the search's

@@ -45,9 +45,6 @@ SIGNATURES = {
     "pcgmix_salopt_workspace_bytes": (ctypes.c_longlong, [_c_int]),
     "pcgmix_salopt_disp_f32": (_c_int, [_ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _ptr, _c_int, _c_int,
                                         _c_int, _ptr]),
-    "pcgmix_salopt_dispatch_order": (_c_int, [_ptr, _ptr, _c_int, _ptr]),
-    "pcgmix_salopt_disp_ordered_f32": (_c_int, [_ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _ptr, _c_int,
-                                                _ptr, _c_int, _c_int, _ptr]),
     "pcgmix_salopt_mix_warp_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _ptr,
                                             _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_potes_head_saliency_f32": (_c_int, [_ptr] * 8 + [_c_int, _c_int, _c_int, _ptr]),

@@ -521,7 +521,6 @@ __global__ __launch_bounds__(kBnThreads) void bnrp_bwd_apply_win_kernel(
 // 0: generic kernels; 1: (1,1), 2: (1,2), 3: (2,2) windows with 32-bit indexing
 inline int bn_fast_kind(const BnShape& s) {
   if ((long long)s.B * s.H * s.W * s.Q >= (1ll << 31)) return 0;
-  if (getenv("PCGMIX_BN_GENERIC")) return 0;              // tuning / A-B runs
   if (s.ph == 1 && s.pw == 1) return 1;
   if (s.ph == 1 && s.pw == 2) return 2;
   if (s.ph == 2 && s.pw == 2) return 3;

@@ -554,8 +554,6 @@ struct pcgmix_ctx {
   void* ws = nullptr;              // displacement-search workspace of the saliency-guided step
   size_t ws_cap = 0;
   int sal_B = 0, sal_max_len = 0;  // what pcgmix_ctx_salopt_begin saw
-  std::vector<int16_t> sal_frames16;   // ... and the boundaries themselves (B <= kPackB): the search
-                                       // of pcgmix_ctx_salopt_finish is launched heaviest pair first
 };
 
 // Host-to-device copy as a kernel launch (see fetch_kernel) for callers with their own pinned
@@ -1064,7 +1062,6 @@ extern "C" int pcgmix_ctx_salopt_begin(pcgmix_ctx* c, const int64_t* target_ohe_
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     c->sal_B = B;
     c->sal_max_len = (int)(longest > T ? T : longest);
-    c->sal_frames16.assign(p16, p16 + (size_t)B * 5);
     return hipSuccess;
   }
   if (target_ohe_dev && (e = labels_begin(c, target_ohe_dev, num_classes, B, s, seed_out)) != hipSuccess)
@@ -1080,7 +1077,6 @@ extern "C" int pcgmix_ctx_salopt_begin(pcgmix_ctx* c, const int64_t* target_ohe_
     return (int)e;
   c->sal_B = B;
   c->sal_max_len = max_len;
-  c->sal_frames16.clear();
   return (int)slot_commit(c, my_slot, s);
 }
 
@@ -1137,7 +1133,6 @@ extern "C" int pcgmix_ctx_salopt_begin_labels(pcgmix_ctx* c, const int64_t* labe
     }
     c->sal_B = B;
     c->sal_max_len = (int)(longest > T ? T : longest);
-    c->sal_frames16.assign(p16, p16 + (size_t)B * 5);
     return hipSuccess;
   }
   const int my_slot = c->next;
@@ -1156,7 +1151,6 @@ extern "C" int pcgmix_ctx_salopt_begin_labels(pcgmix_ctx* c, const int64_t* labe
   if ((e = hipGetLastError()) != hipSuccess) return (int)e;
   c->sal_B = B;
   c->sal_max_len = max_len;
-  c->sal_frames16.clear();
   return (int)slot_commit(c, my_slot, s);
 }
 
@@ -1223,21 +1217,10 @@ extern "C" int pcgmix_ctx_salopt_finish(pcgmix_ctx* c, const float* x, float* y,
       return (int)e;
     mix_dev = reinterpret_cast<const int32_t*>(sl.dev);
   }
-  // The search is launched heaviest (sample, state) pair first (pcgmix_salopt_dispatch_order): the
-  // natural order started the long diastole chains wherever the batch happened to put them.
-  uint16_t order[pcgmix::kPackB * 4];
-  bool ordered = in_args && c->sal_B == B && c->sal_frames16.size() == (size_t)B * 5;
-  if (ordered) {
-    std::vector<int64_t>& f64 = c->keys;               // scratch (the partner draw is done with it)
-    f64.resize((size_t)B * 5);
-    for (size_t i = 0; i < (size_t)B * 5; ++i) f64[i] = c->sal_frames16[i];
-    ordered = pcgmix_salopt_dispatch_order(f64.data(), mix_out, B, order) == 0;
-  }
   int err = pcgmix::launch_salopt_search(sal, frames_dev, mix_dev, lam, mode, nullptr, c->ws,
                                          c->sal_B == B ? c->sal_max_len : 0, B, T, s,
                                          sl.pinned + n_mix_pad * 4, sl.dev + n_mix_pad * 4,
-                                         (int)(nk * sizeof(double) / 16), in_args ? mix16 : nullptr,
-                                         ordered ? order : nullptr);
+                                         (int)(nk * sizeof(double) / 16), in_args ? mix16 : nullptr);
   if (err) return err;
   err = pcgmix::launch_mix_warp(x, y, frames_dev, mix_dev, nullptr, lam, knots_dev, op_dev,
                                 knots ? n_knots : 0, nullptr, B, C, T, s, nullptr, nullptr, 0,

@@ -77,18 +77,10 @@ int launch_mix_karg(const float* x, float* y, const int16_t* frames16, const int
 // the per-block results in `workspace` for launch_mix_warp's disp_part.
 // pay_*: pay_n16 16-byte words that one otherwise idle block copies from pay_src (device-readable
 // host memory) to pay_dst while the search runs.
-// order (host, B * 4 entries (b << 2 | state), B <= kPackB; may be null): the (sample, state) pairs in
-// the order their blocks are to be dispatched — heaviest first; travels in the kernel arguments.
 int launch_salopt_search(const float* sal, const int32_t* frames, const int32_t* mix_idx, float lam,
                          int mode, int32_t* disp, void* workspace, int max_len, int B, int T,
                          hipStream_t s, const void* pay_src = nullptr, void* pay_dst = nullptr,
-                         int pay_n16 = 0, const int16_t* partners16 = nullptr,
-                         const uint16_t* order = nullptr);
-// Dispatch order of the displacement search's pairs, by value in its kernel arguments (2 KB).
-struct OrderPack {
-  uint32_t w[kPackB * 4 / 2];       // two uint16 entries (b << 2 | state) per word
-  int n;                            // 0: natural order
-};
+                         int pay_n16 = 0, const int16_t* partners16 = nullptr);
 
 }  // namespace pcgmix
 #endif

@@ -572,8 +572,7 @@ static MixVariant choose_mix_variant(long long B, int C, int T, bool vec4, int n
   const long long plane = (long long)C * T;
   v.vec = vec4 ? 4 : 1;
   v.U = vec4 ? choose_unroll(B, plane, warp) : 1;
-  static const bool tq_ok = getenv("PCGMIX_NO_WARP_TQ") == nullptr;     // tuning / A-B runs
-  if (!(vec4 && warp && !zero_rect && tq_ok && C <= 64)) return v;
+  if (!(vec4 && warp && !zero_rect && C <= 64)) return v;
   v.lds_tq = sizeof(double) * ((size_t)C * (n_knots - 1) * kRec + (size_t)n_knots +
                                4 * (size_t)(n_knots - 1) * n_knots + (size_t)n_knots * C) +
              sizeof(int) * (size_t)((n_knots + 1) & ~1);
@@ -581,15 +580,10 @@ static MixVariant choose_mix_variant(long long B, int C, int T, bool vec4, int n
   v.tq = true;
   // two quads per lane only where the registers allow it (CG = 4, UT = 2 needs 256 VGPRs)
   v.UT = (C % 4 != 0 && T >= 4096 && B * plane >= (64LL << 20)) ? 2 : 1;
-  if (const char* env = getenv("PCGMIX_WARP_TQ_UT")) v.UT = atoi(env) == 2 ? 2 : 1;     // tuning runs
   // channels whose loads a lane keeps in flight.  Measured at C = 4 (MI355X, back to back):
   // (256,4,5000) 14.2 / 11.9 / 12.1 us for 4 / 2 / 1, saturating 16384x4x5000 672 / 596 / 573 us
   // (fewer registers, more waves: 144 / 94 / 76 VGPRs)
   v.CG = (C % 2 == 0 && B * plane < (64LL << 20)) ? 2 : 1;
-  if (const char* env = getenv("PCGMIX_WARP_TQ_CG")) {  // tuning runs
-    const int e = atoi(env);
-    if ((e == 1 || e == 2 || e == 4) && C % e == 0) v.CG = e;
-  }
   return v;
 }
 }  // namespace pcgmix

@@ -1,4 +1,4 @@
-// pcgmix_potes.hip — the Potes 1D-CNN's convolutional branch as two fused kernels (gfx950).
+// pcgmix_potes.hip — the Potes 1D-CNN's convolutional branch as fused kernels (gfx950).
 //
 // Reference: models.py:359-381 (conv_block_1d, CNN_potes.cnn1) — per band-pass channel
 //     Conv1d(1->8, k5, pad1) + ReLU + MaxPool(2)  ->  Conv1d(8->4, k5, pad1) + ReLU + MaxPool(2)
@@ -7,16 +7,22 @@
 // fallback, layout transposes, separate ReLU / pooling / pooling-backward kernels;
 // profiles/r1_bench_kernel_stats.csv) for ~40 MB of unavoidable HBM traffic.  Here:
 //
-//   potes_fwd_kernel   reads each input row once, keeps the 8-channel intermediate in LDS,
-//                      writes the pooled (N,4,P2) activations: 4*T + 16*P2 bytes per row.
-//   potes_bwd_kernel   recomputes the forward tile from the input (cheaper than storing
-//                      the 8-channel intermediate: 2.6x the input size), back-propagates through
-//                      pool/ReLU/conv2/pool/ReLU and reduces the 212 weight/bias gradients per
-//                      block in registers; a second tiny kernel sums the per-block partials
-//                      (deterministic, no float atomics).  Reads 4*T + 16*P2 bytes per row.
-//
-// Small-channel direct convolutions are not GEMM-shaped (K = 5 or 40): this is VALU + LDS work
-// bounded by HBM, not MFMA work.
+//   potes_fwd_mfma_kernel         reads each input row once, keeps the 8-channel intermediate in
+//                                 LDS, writes the pooled (N,4,P2) activations and, on request, the
+//                                 ReLU/pool routing of both layers (m2, s1): 4*T + 16*P2 bytes per
+//                                 row; block-form matrix instruction v_mfma_f32_4x4x1_16b_f32.
+//   potes_bwd_pair_kernel         weight gradients from x, dL/dh2 and m2: recomputes layer 1 on the
+//                                 lane that consumes it, packed multiply-adds over channel pairs,
+//                                 212 gradients per block in registers; per-block partials are summed
+//                                 by a second tiny kernel or inside the optimiser launch
+//                                 (deterministic, no float atomics).
+//   potes_input_grad_pair_kernel  dL/dx from dL/dh2, m2 and s1 (saliency maps).
+//   potes_bwd_kernel<false>, potes_input_grad_kernel: the same two gradients for callers that kept
+//                                 no routing (they recompute the whole forward per tile).
+// The VALU forward and the earlier mask-based backward kernels (rounds 1-3: potes_fwd_kernel,
+// potes_bwd_kernel<true>, potes_bwd_fused_kernel, potes_input_grad_mask_kernel) were removed from
+// the product library in round 4; they are in the history at commit 2fa984b and their measurements
+// in profiles/r2_*, r3_*.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -213,7 +219,6 @@ constexpr int kFwdTP = 252;                     // pooled outputs per block (4 p
                                                 // channels = 1016 work items = 4 rounds of 256 threads
                                                 // (256 outputs would need a 5th round for 8 items)
 constexpr int kFwdNQ = 2 * kFwdTP + 4;          // 508
-constexpr int kFwdNX = 4 * kFwdTP + 12;         // 1020
 
 // SAVE: also write what the mask-based backward kernels need so that they do not recompute the
 // forward: m2 (N, 4, ceil(P2/4)) — per pooled output 2 bits (0 = ReLU-dead, 1 = first conv output
@@ -235,145 +240,6 @@ __device__ __forceinline__ uint32_t counter_hash(uint32_t i, uint32_t k0, uint32
   h *= 0xC2B2AE35u;
   h ^= h >> 16;
   return h;
-}
-
-template <bool SAVE>
-__global__ __launch_bounds__(kPotThreads) void potes_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
-    const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ h2,
-    uint8_t* __restrict__ m2, uint8_t* __restrict__ s1, int N, int T, uint4* __restrict__ rnd,
-    long long rnd_n16, const uint32_t* __restrict__ key, uint32_t key_lo, uint32_t key_hi) {
-  if (SAVE && rnd) {
-    const uint32_t k0 = key ? key[0] : key_lo, k1 = key ? key[1] : key_hi;
-    const long long stride = (long long)gridDim.x * gridDim.y * kPotThreads;
-    for (long long i = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * kPotThreads + threadIdx.x;
-         i < rnd_n16; i += stride) {
-      const uint32_t c = (uint32_t)i * 4u;
-      rnd[i] = make_uint4(counter_hash(c, k0, k1), counter_hash(c + 1, k0, k1),
-                          counter_hash(c + 2, k0, k1), counter_hash(c + 3, k0, k1));
-    }
-  }
-  __shared__ PotesWeights W;
-  // swizzled planes (see layer1_t): x = 255 float4 -> E 128 + O 128; a1 = 127 float4 per channel
-  // -> E 64 + O 64 per channel (+4 floats: lane 63 of conv2 reads E[64] of the last channel)
-  constexpr int kXPlane = 512, kAPlane = 256;
-  __shared__ __align__(16) float xs[2 * kXPlane];
-  __shared__ __align__(16) float a1s[kC1 * 2 * kAPlane + 4];
-  const PotesDims d = potes_dims(T);
-  const int n = blockIdx.y, p0 = blockIdx.x * kFwdTP;
-  const int qlo = 2 * p0 - 1, xlo = 2 * qlo - 1;
-  load_weights(&W, w1, b1, w2, b2);
-  {
-    const float* xrow = x + (size_t)n * T;
-    auto put = [&](int u, float v) {                 // tile element u -> swizzled planes
-      const int i = u >> 2;
-      xs[(i & 1) * kXPlane + 4 * (i >> 1) + (u & 3)] = v;
-    };
-    if (!(T & 3) && !(reinterpret_cast<uintptr_t>(x) & 15)) {
-      // The tile starts at x[4*p0 - 3]: one aligned 16-byte load per thread from x[4*p0 - 4]
-      // (256 threads cover the 1020 elements) instead of four 4-byte loads; rows are 16-byte
-      // aligned and T % 4 == 0, so a quad is wholly inside the row or wholly outside.
-      const int g0 = 4 * p0 - 4 + 4 * (int)threadIdx.x;
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      if (g0 >= 0 && g0 < T) v = *reinterpret_cast<const f4*>(xrow + g0);
-      const int u0 = 4 * (int)threadIdx.x - 1;       // tile index of v.x
-      if (u0 >= 0) put(u0, v.x);
-      put(u0 + 1, v.y);
-      put(u0 + 2, v.z);
-      if (u0 + 3 < kFwdNX) put(u0 + 3, v.w);
-    } else {
-      for (int u = threadIdx.x; u < kFwdNX; u += kPotThreads) {
-        const int g = xlo + u;
-        put(u, (g >= 0 && g < T) ? xrow[g] : 0.f);
-      }
-    }
-  }
-  __syncthreads();
-  if (SAVE && s1) {
-    const int s1row = potes_s1_row_bytes(d);          // four 2-bit selectors per byte
-    layer1_t<true>(W, xs, a1s, nullptr, qlo, kFwdNQ, d.P1, kXPlane, kAPlane,
-                   s1 + (size_t)n * kC1 * s1row, 0, s1row);
-  } else {
-    layer1_t<true>(W, xs, a1s, nullptr, qlo, kFwdNQ, d.P1, kXPlane, kAPlane);
-  }
-  __syncthreads();
-  // conv 8->4 k5 + ReLU + pool 2: wave = output channel, lane = 4 consecutive pooled outputs
-  // co is wave-uniform: its 40 weights come through the scalar cache into SGPRs instead of
-  // costing an LDS broadcast read per FMA pair (the LDS pipe is this kernel's busiest unit)
-  const int co = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  // The 8 conv outputs c[m] = sum_k w[k] * aw[m + k] of a lane are accumulated as float2 pairs
-  // so that the FMAs issue as v_pk_fma_f32 (two per instruction): the operand pair (aw[m+k],
-  // aw[m+k+1]) must sit in an even-aligned register pair, so even taps pair (c0,c1)..(c6,c7)
-  // and odd taps pair (c1,c2)..(c5,c6) with c0, c7 left scalar: 22 instructions per input channel
-  // instead of 40.  The two partial sums are added at the end.
-  f2 ce[4], co_[3];
-  float o0 = 0.f, o7 = 0.f;
-  const float bias2 = b2[co];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) ce[m] = f2{bias2, bias2};
-#pragma unroll
-  for (int m = 0; m < 3; ++m) co_[m] = f2{0.f, 0.f};
-#pragma unroll
-  for (int ci = 0; ci < kC1; ++ci) {
-    float aw[12], w[kK];
-    {
-      const float* row = a1s + ci * 2 * kAPlane;
-      const f4 a = *reinterpret_cast<const f4*>(row + 4 * lane),
-               b = *reinterpret_cast<const f4*>(row + kAPlane + 4 * lane),
-               c = *reinterpret_cast<const f4*>(row + 4 * lane + 4);
-      aw[0] = a.x; aw[1] = a.y; aw[2] = a.z; aw[3] = a.w; aw[4] = b.x; aw[5] = b.y; aw[6] = b.z;
-      aw[7] = b.w; aw[8] = c.x; aw[9] = c.y; aw[10] = c.z; aw[11] = c.w;
-    }
-#pragma unroll
-    for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci) * kK + k];
-#pragma unroll
-    for (int k = 0; k < kK; k += 2) {                  // even taps: outputs (2m, 2m+1)
-      const f2 wk = {w[k], w[k]};
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        ce[m] = __builtin_elementwise_fma(wk, f2{aw[2 * m + k], aw[2 * m + k + 1]}, ce[m]);
-    }
-#pragma unroll
-    for (int k = 1; k < kK; k += 2) {                  // odd taps: outputs (2m+1, 2m+2), c0, c7
-      const f2 wk = {w[k], w[k]};
-#pragma unroll
-      for (int m = 0; m < 3; ++m)
-        co_[m] = __builtin_elementwise_fma(wk, f2{aw[2 * m + 1 + k], aw[2 * m + 2 + k]}, co_[m]);
-      o0 = fmaf(w[k], aw[k], o0);
-      o7 = fmaf(w[k], aw[7 + k], o7);
-    }
-  }
-  float c[8];
-  c[0] = ce[0].x + o0;
-  c[7] = ce[3].y + o7;
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    c[2 * m + 1] = ce[m].y + co_[m].x;
-    c[2 * m + 2] = ce[m + 1].x + co_[m].y;
-  }
-  const int p = p0 + 4 * lane;
-  float* dst = h2 + ((size_t)n * kC2 + co) * d.P2 + p;
-  f4 o;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) o[u] = fmaxf(fmaxf(c[2 * u], 0.f), fmaxf(c[2 * u + 1], 0.f));
-  if (4 * lane >= kFwdTP) return;                  // lane 63: outputs owned by the next tile
-  if (SAVE && p < d.P2) {
-    uint32_t code = 0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {                   // the backward's routing rule, verbatim
-      const float ra = fmaxf(c[2 * u], 0.f), rb = fmaxf(c[2 * u + 1], 0.f);
-      const uint32_t sc = rb > ra ? 2u : (ra > 0.f ? 1u : 0u);
-      if (p + u < d.P2) code |= sc << (2 * u);
-    }
-    m2[((size_t)n * kC2 + co) * ((d.P2 + 3) / 4) + (p >> 2)] = (uint8_t)code;
-  }
-  if (p + 3 < d.P2 && (d.P2 & 3) == 0) {
-    *reinterpret_cast<f4*>(dst) = o;
-  } else {
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (p + u < d.P2) dst[u] = o[u];
-  }
 }
 
 // ---------------------------------------------------------------------------------- forward, MFMA
@@ -983,220 +849,6 @@ __global__ __launch_bounds__(kPotThreads) void potes_bwd_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------------- backward, fused
-// potes_bwd_kernel<true> with the first-layer recompute moved onto the lane that consumes it
-// (VERDICT r2 item 6 / DESIGN §7.1).  In that kernel a work item of layer 1 is (channel, group of
-// 4 pooled positions) spread over the block in two rounds, its ReLU/pool selectors go to LDS
-// (sel1), a barrier, and then lane l of wave w — which owns a1 positions 4l..4l+3 of channels
-// 2w, 2w+1 for dgrad / gw1 — reads them back together with a second copy of the same x window.
-// Here that lane computes layer-1 group l+1 (a1 positions r = 4l-1 .. 4l+2 relative to the tile's
-// first owned position) of its two channels itself, from ONE 12-float x window that it keeps for
-// gw1; the selectors never leave registers, a1 goes to LDS (one 16-byte store per channel) only
-// for the gw2 phase of the other waves, the dz2 window shrinks from 12 to 8 floats and is 16-byte
-// aligned, and dgrad + gw1 no longer wait for the barrier behind layer 1.  Positions shifted by
-// one (r = 4l-1+u): the groups then cover exactly what gw2 reads (a1 index 4 .. 259), position
-// r = -1 is computed for that halo and owned by the previous tile.  Same arithmetic per value as
-// potes_bwd_kernel<true> (conv1_window; the accumulations per lane differ only in which lane
-// holds which position), same partial layout.
-__global__ __launch_bounds__(kPotThreads) void potes_bwd_fused_kernel(
-    const float* __restrict__ x, const float* __restrict__ gh2, const uint8_t* __restrict__ m2,
-    const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-    const float* __restrict__ b2, float* __restrict__ partial /* gridDim.x * 212 */, int N, int T) {
-  __shared__ PotesWeights W;
-  __shared__ __align__(16) float xs[kBwdNX + 4];
-  __shared__ __align__(16) float a1s[kC1 * kBwdNQ];
-  __shared__ __align__(16) float dz2s[kC2 * (kBwdNJ + 12)];
-  __shared__ float red[4 * kNAcc];
-  constexpr int kDz2Row = kBwdNJ + 12;
-  const PotesDims d = potes_dims(T);
-  const int tiles = potes_bwd_tiles(d);
-  const unsigned work = (unsigned)N * (unsigned)tiles;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  load_weights(&W, w1, b1, w2, b2);
-  for (int i = threadIdx.x; i < kC2 * kDz2Row; i += kPotThreads) dz2s[i] = 0.f;
-
-  float acc2[kC1][kK], acc1[2][kK], accb1[2] = {0.f, 0.f}, accb2 = 0.f;
-#pragma unroll
-  for (int ci = 0; ci < kC1; ++ci)
-#pragma unroll
-    for (int k = 0; k < kK; ++k) acc2[ci][k] = 0.f;
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int k = 0; k < kK; ++k) acc1[c][k] = 0.f;
-
-  constexpr int kXPer = (kBwdNX + 4 + kPotThreads - 1) / kPotThreads;   // 3
-  float xr[kXPer], gr[2];
-  uint32_t mr[2] = {0u, 0u};
-  const int m2s = (d.P2 + 3) / 4;
-  auto prefetch = [&](unsigned it) {
-    const int n = (int)(it / (unsigned)tiles), p0 = (int)(it - (unsigned)n * (unsigned)tiles) * kBwdTP;
-    const int xlo = 2 * (2 * p0 - 5) - 1;
-    const float* xrow = x + (size_t)n * T;
-#pragma unroll
-    for (int j = 0; j < kXPer; ++j) {
-      const int u = threadIdx.x + j * kPotThreads, g = xlo + u;
-      xr[j] = (u < kBwdNX + 4 && g >= 0 && g < T) ? xrow[g] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int pe = p0 - 2 + 2 * lane + u;
-      gr[u] = (pe >= 0 && pe < d.P2) ? gh2[((size_t)n * kC2 + wave) * d.P2 + pe] : 0.f;
-      mr[u] = (pe >= 0 && pe < d.P2)
-                  ? (m2[((size_t)n * kC2 + wave) * m2s + (pe >> 2)] >> (2 * (pe & 3))) & 3u
-                  : 0u;
-    }
-  };
-  if (blockIdx.x < work) prefetch(blockIdx.x);
-  __syncthreads();                                   // weights in LDS before the first item reads them
-
-  // this lane's two first-layer channels: weights in registers for the whole kernel
-  const int ci0 = __builtin_amdgcn_readfirstlane(2 * wave);
-  float wl[2][kK], bl[2];
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-#pragma unroll
-    for (int k = 0; k < kK; ++k) wl[c][k] = W.w1[(ci0 + c) * kK + k];
-    bl[c] = W.b1[ci0 + c];
-  }
-  const int R0 = 4 * lane;                           // positions r = R0 - 1 + u, u < 4
-
-  for (unsigned item = blockIdx.x; item < work; item += gridDim.x) {
-    const int n = (int)(item / (unsigned)tiles), p0 = (int)(item - (unsigned)n * (unsigned)tiles) * kBwdTP;
-    (void)n;
-    __syncthreads();  // previous item's LDS fully consumed
-#pragma unroll
-    for (int j = 0; j < kXPer; ++j) {
-      const int u = threadIdx.x + j * kPotThreads;
-      if (u < kBwdNX + 4) xs[u] = xr[j];
-    }
-    {
-      f4 dz;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        dz[2 * u] = mr[u] == 1u ? gr[u] : 0.f;
-        dz[2 * u + 1] = mr[u] == 2u ? gr[u] : 0.f;
-      }
-      *reinterpret_cast<f4*>(dz2s + wave * kDz2Row + 4 * lane) = dz;
-    }
-    if (item + gridDim.x < work) prefetch(item + gridDim.x);
-    __syncthreads();
-    {  // layer 1 (group lane+1 of channels 2w, 2w+1) -> a1 to LDS, selectors in registers;
-       // back through conv2 to these positions; routed by the selectors straight into gw1 / gb1
-      float xw[12];
-      lds_load12(xs + 2 * R0 + 8, xw);
-      uint32_t sel[2] = {0u, 0u};                      // 2 bits per position u
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        float cv[8];
-        conv1_window(xw, wl[c], bl[c], cv);
-        f4 out;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int q = 2 * p0 + R0 - 1 + u;
-          float a;
-          uint32_t sc;
-          relu_pool2(cv[2 * u], cv[2 * u + 1], q >= 0 && q < d.P1, a, sc);
-          out[u] = a;
-          // owned by this tile (gradient accumulated here) only for 0 <= r < kBwdNS
-          const int r = R0 - 1 + u;
-          if (r >= 0 && r < kBwdNS) sel[c] |= sc << (2 * u);
-        }
-        *reinterpret_cast<f4*>(a1s + (ci0 + c) * kBwdNQ + R0 + 4) = out;
-      }
-      float da1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll 1
-      for (int co = 0; co < kC2; ++co) {
-        float dw[8];
-        lds_load8(dz2s + co * kDz2Row + R0, dw);       // dz2 index r + 5 - k = R0 + u + 4 - k
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          float w[kK];
-#pragma unroll
-          for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci0 + c) * kK + k];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int k = 0; k < kK; ++k) da1[c][u] = fmaf(dw[u + 4 - k], w[k], da1[c][u]);
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        float dd[8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t sc = (sel[c] >> (2 * u)) & 3u;
-          dd[2 * u] = sc == 1u ? da1[c][u] : 0.f;
-          dd[2 * u + 1] = sc == 2u ? da1[c][u] : 0.f;
-        }
-        accb1[c] += ((dd[0] + dd[1]) + (dd[2] + dd[3])) + ((dd[4] + dd[5]) + (dd[6] + dd[7]));
-#pragma unroll
-        for (int k = 0; k < kK; ++k)
-#pragma unroll
-          for (int u = 0; u < 8; ++u) acc1[c][k] = fmaf(dd[u], xw[u + k], acc1[c][k]);
-      }
-    }
-    __syncthreads();                                   // a1s complete
-    {  // gw2 / gb2: wave = co, lane -> owned s0 = 4*lane .. +3 (s < 250)
-      const int co = wave, s0 = 4 * lane;
-      const f4 dv = *reinterpret_cast<const f4*>(dz2s + co * kDz2Row + s0 + 4);
-      float dd[4] = {dv.x, dv.y, dv.z, dv.w};
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (s0 + u >= kBwdNS) dd[u] = 0.f;
-      accb2 += (dd[0] + dd[1]) + (dd[2] + dd[3]);
-      if (s0 < kBwdNS) {
-#pragma unroll
-        for (int ci = 0; ci < kC1; ++ci) {
-          float aw[8];
-          lds_load8(a1s + ci * kBwdNQ + s0 + 4, aw);
-#pragma unroll
-          for (int k = 0; k < kK; ++k)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc2[ci][k] = fmaf(dd[u], aw[u + k], acc2[ci][k]);
-        }
-      }
-    }
-  }
-
-  float flat[kNAcc];
-#pragma unroll
-  for (int ci = 0; ci < kC1; ++ci)
-#pragma unroll
-    for (int k = 0; k < kK; ++k) flat[ci * kK + k] = acc2[ci][k];
-  flat[40] = accb2;
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-#pragma unroll
-    for (int k = 0; k < kK; ++k) flat[41 + c * kK + k] = acc1[c][k];
-    flat[51 + c] = accb1[c];
-  }
-#pragma unroll
-  for (int e = 0; e < kNAcc; ++e) flat[e] = wave_sum_lane63(flat[e]);
-  __syncthreads();
-  if (lane == 63)
-#pragma unroll
-    for (int e = 0; e < kNAcc; ++e) red[wave * kNAcc + e] = flat[e];
-  __syncthreads();
-  for (int e = threadIdx.x; e < kNGrad; e += kPotThreads) {
-    float v;
-    if (e < kNW1) {
-      const int ci = e / kK, k = e - ci * kK;
-      v = red[(ci >> 1) * kNAcc + 41 + (ci & 1) * kK + k];
-    } else if (e < kNW1 + kC1) {
-      const int ci = e - kNW1;
-      v = red[(ci >> 1) * kNAcc + 51 + (ci & 1)];
-    } else if (e < kNW1 + kC1 + kNW2) {
-      const int f = e - kNW1 - kC1;
-      const int co = f / (kC1 * kK), rest = f - co * (kC1 * kK);
-      v = red[co * kNAcc + rest];
-    } else {
-      v = red[(e - kNW1 - kC1 - kNW2) * kNAcc + 40];
-    }
-    partial[(size_t)blockIdx.x * kNGrad + e] = v;
-  }
-}
-
 // ---------------------------------------------------------------------------------- backward, channel pairs
 // potes_bwd_fused_kernel is VALU-issue-bound (profiles/r3_potes_bwd_sq_counters.json: 31.1 M VALU
 // instructions, 71 % of the launch) and of the ~455 multiply-add-related instructions a wave spends
@@ -1687,120 +1339,10 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_kernel(
 
 // The same gradient from the forward's saved routing (m2, s1) instead of a recomputed forward:
 // neither x nor the activations are needed — dz2 = route(gh2, m2), dL/da1 = conv2^T dz2,
-// dz1 = route(dL/da1, s1), dL/dx = conv1^T dz1.  Half the multiply-adds of the kernel above and
-// two barrier phases instead of four.  Same tile geometry.
-__global__ __launch_bounds__(kPotThreads) void potes_input_grad_mask_kernel(
-    const float* __restrict__ gh2, const uint8_t* __restrict__ m2, const uint8_t* __restrict__ s1,
-    const float* __restrict__ w1, const float* __restrict__ w2, float* __restrict__ gx, int N,
-    int T) {
-  constexpr int kDz2Row = kBwdNJ + 12;
-  __shared__ __align__(16) float dz2s[kC2 * kDz2Row];
-  __shared__ __align__(16) float dz1s[kC1 * kBwdNIpad];
-  const PotesDims d = potes_dims(T);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = blockIdx.y, p0 = blockIdx.x * kInTP;
-  const int m2s = (d.P2 + 3) / 4;
-  // first-layer selectors of this lane's 4 positions q = 2p0-2+4*lane+u for its two channels:
-  // issued now, consumed after the first barrier
-  // (packed: position q sits in bits 2*((q+1)&3) of byte (q+1)>>2; q+1 = 2*p0 - 1 + 4*lane + u with
-  // 2*p0 a multiple of 4, so u = 0 is the top pair of one byte and u = 1..3 the low pairs of the next)
-  uint32_t sc[2][4];
-  const int s1row = potes_s1_row_bytes(d);
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const uint8_t* row = s1 + ((size_t)n * kC1 + 2 * wave + c) * s1row;
-    const int b1 = (p0 >> 1) + lane, b0 = b1 - 1;
-    const uint32_t v0 = (b0 >= 0 && b0 < s1row) ? row[b0] : 0u;
-    const uint32_t v1 = (b1 >= 0 && b1 < s1row) ? row[b1] : 0u;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = 4 * lane + u, q = 2 * p0 - 2 + r;
-      const uint32_t code = u == 0 ? (v0 >> 6) & 3u : (v1 >> (2 * (u - 1))) & 3u;
-      sc[c][u] = (r < kInNR && q >= 0 && q < d.P1) ? code : 0u;
-    }
-  }
-  {  // dz2 at pe = p0-3+2*lane+u (wave = co); the 12-float pad of each row stays zero
-    const int co = wave;
-    f4 dz;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int pe = p0 - 3 + 2 * lane + u;
-      float g = 0.f;
-      uint32_t code = 0u;
-      if (pe >= 0 && pe < d.P2) {
-        g = gh2[((size_t)n * kC2 + co) * d.P2 + pe];
-        code = (m2[((size_t)n * kC2 + co) * m2s + (pe >> 2)] >> (2 * (pe & 3))) & 3u;
-      }
-      dz[2 * u] = code == 1u ? g : 0.f;
-      dz[2 * u + 1] = code == 2u ? g : 0.f;
-    }
-    *reinterpret_cast<f4*>(dz2s + co * kDz2Row + 4 * lane) = dz;
-    if (lane < 3) *reinterpret_cast<f4*>(dz2s + co * kDz2Row + kBwdNJ + 4 * lane) = f4{0.f, 0.f, 0.f, 0.f};
-  }
-  __syncthreads();
-  {  // dL/da1 at q = 2p0-2+r (r < 251), through pool1/ReLU1 -> dz1 at i = 4p0-4+2r(+1)
-    const int r0 = 4 * lane;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int ci = __builtin_amdgcn_readfirstlane(2 * wave + c);
-      float da1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int co = 0; co < kC2; ++co) {
-        float dw[12], w[kK];
-        lds_load12(dz2s + co * kDz2Row + r0, dw);   // dz2 index r+5-k
-#pragma unroll
-        for (int k = 0; k < kK; ++k) w[k] = w2[(co * kC1 + ci) * kK + k];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int k = 0; k < kK; ++k) da1[u] = fmaf(dw[u + 5 - k], w[k], da1[u]);
-      }
-      float out[8];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        out[2 * u] = sc[c][u] == 1u ? da1[u] : 0.f;
-        out[2 * u + 1] = sc[c][u] == 2u ? da1[u] : 0.f;
-      }
-      f4* dst = reinterpret_cast<f4*>(dz1s + ci * kBwdNIpad + 8 * lane);
-      dst[0] = f4{out[0], out[1], out[2], out[3]};
-      dst[1] = f4{out[4], out[5], out[6], out[7]};
-    }
-  }
-  __syncthreads();
-  {  // transposed conv1: dx[u] = sum_ci sum_k dz1[ci][u+1-k] * w1[ci][k]; dz1 index v+5-k.
-     // Thread t takes the outputs v = 2t-1 and 2t: its six dz1 values then start at the EVEN index
-     // 2t — three 8-byte LDS reads per channel instead of six 4-byte ones — and the 40 weights
-     // come through the scalar cache (block-uniform) instead of 40 more LDS reads per thread:
-     // this phase issued 88 LDS reads for its 80 multiply-adds.
-    const int v0 = 2 * (int)threadIdx.x - 1;
-    if (v0 < kInNU) {
-      float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll
-      for (int ci = 0; ci < kC1; ++ci) {
-        float dw[6];
-#pragma unroll
-        for (int j = 0; j < 6; j += 2) {
-          const float2 v = *reinterpret_cast<const float2*>(dz1s + ci * kBwdNIpad + v0 + 1 + j);
-          dw[j] = v.x;
-          dw[j + 1] = v.y;
-        }
-#pragma unroll
-        for (int k = 0; k < kK; ++k) {
-          const float w = w1[ci * kK + k];
-          acc0 = fmaf(dw[4 - k], w, acc0);
-          acc1 = fmaf(dw[5 - k], w, acc1);
-        }
-      }
-      const int u = 4 * p0 + v0;
-      float* dst = gx + (size_t)n * T + u;
-      if (v0 >= 0 && u < T) dst[0] = acc0;
-      if (v0 + 1 < kInNU && u + 1 < T) dst[1] = acc1;
-    }
-  }
-}
-
-// potes_input_grad_mask_kernel with the packed multiply-adds running over CHANNEL pairs (round 4;
-// the weight-gradient kernel's recipe, potes_bwd_pair_kernel): wave w back-propagates through conv2
+// dz1 = route(dL/da1, s1), dL/dx = conv1^T dz1.  Same tile geometry.  The packed multiply-adds run
+// over CHANNEL pairs (the weight-gradient kernel's recipe, potes_bwd_pair_kernel; the round-2/3
+// kernel with scalar multiply-adds over positions, potes_input_grad_mask_kernel, 44.5 us against
+// 30.6, is in the history at 2fa984b): wave w back-propagates through conv2
 // towards channels 2w, 2w+1 with the two channels as the halves of every v_pk_fma_f32 (weights as
 // (c0, c1) pairs — broadcast 8-byte LDS reads —, the dz2 value broadcast by op_sel), the routed
 // first-layer gradient goes to LDS pair-interleaved, and the transposed first layer multiplies
@@ -2394,22 +1936,14 @@ extern "C" int pcgmix_potes_bwd_blocks(int N, int T) {
   if (N <= 0 || T < 14) return 0;
   const pcgmix::PotesDims d = pcgmix::potes_dims(T);
   const long long work = (long long)N * ((d.P2 + 2 + pcgmix::kBwdTP - 1) / pcgmix::kBwdTP);  // = tiles
-  // persistent blocks: 4 per CU for the channel-pair kernel (128 VGPRs, 4 waves per SIMD: 51.9 us at
-  // 1024 blocks, 53.0 at 768, 52.6 at 1536; profiles/r4_potes_bwd_pair.txt), 3 for the older ones
-  static const bool pairs = getenv("PCGMIX_POTES_BWD_NO_PAIRS") == nullptr &&
-                            getenv("PCGMIX_POTES_BWD_UNFUSED") == nullptr;
-  long long cap = pairs ? 1024 : 768;
+  // persistent blocks: 4 per CU (128 VGPRs, 4 waves per SIMD: 51.9 us at 1024 blocks, 53.0 at 768,
+  // 52.6 at 1536; profiles/r4_potes_bwd_sweep.txt)
+  long long cap = 1024;
   if (const char* env = getenv("PCGMIX_POTES_BWD_BLOCKS")) {   // tuning runs
     const long long v = atoll(env);
     if (v >= 1 && v <= 65535) cap = v;
   }
   return (int)(work < cap ? work : cap);
-}
-
-// The forward runs on the matrix cores unless PCGMIX_POTES_FWD_VALU=1 (A/B runs).
-static bool potes_fwd_use_mfma() {
-  static const bool on = getenv("PCGMIX_POTES_FWD_VALU") == nullptr;
-  return on;
 }
 
 // Persistent blocks of the matrix-core forward: four per CU (128 VGPRs), tiles handed out by stride.
@@ -2431,15 +1965,9 @@ extern "C" int pcgmix_potes_stack_fwd_f32(const float* x, const float* w1, const
     return hipErrorInvalidValue;
   if (N == 0) return hipSuccess;
   const PotesDims d = potes_dims(T);
-  if (potes_fwd_use_mfma()) {
-    hipLaunchKernelGGL(potes_fwd_mfma_kernel<false>, dim3(potes_fwd_mfma_blocks(N, d)),
-                       dim3(kPotThreads), 0, reinterpret_cast<hipStream_t>(stream), x, w1, b1, w2, b2, h2,
-                       nullptr, nullptr, N, T, nullptr, 0ll, nullptr, 0u, 0u);
-    return (int)hipGetLastError();
-  }
-  dim3 grid((unsigned)((d.P2 + kFwdTP - 1) / kFwdTP), (unsigned)N), block(kPotThreads);
-  hipLaunchKernelGGL(potes_fwd_kernel<false>, grid, block, 0, reinterpret_cast<hipStream_t>(stream),
-                     x, w1, b1, w2, b2, h2, nullptr, nullptr, N, T, nullptr, 0ll, nullptr, 0u, 0u);
+  hipLaunchKernelGGL(potes_fwd_mfma_kernel<false>, dim3(potes_fwd_mfma_blocks(N, d)),
+                     dim3(kPotThreads), 0, reinterpret_cast<hipStream_t>(stream), x, w1, b1, w2, b2, h2,
+                     nullptr, nullptr, N, T, nullptr, 0ll, nullptr, 0u, 0u);
   return (int)hipGetLastError();
 }
 
@@ -2464,17 +1992,10 @@ extern "C" int pcgmix_potes_stack_fwd_save_f32(const float* x, const float* w1, 
     return hipErrorInvalidValue;
   if (N == 0) return hipSuccess;
   const PotesDims d = potes_dims(T);
-  if (potes_fwd_use_mfma()) {
-    hipLaunchKernelGGL(potes_fwd_mfma_kernel<true>, dim3(potes_fwd_mfma_blocks(N, d)),
-                       dim3(kPotThreads), 0, reinterpret_cast<hipStream_t>(stream), x, w1, b1, w2, b2, h2, m2, s1, N, T,
-                       reinterpret_cast<uint4*>(rnd_out), rnd_out ? rnd_bytes / 16 : 0ll, key_dev,
-                       (uint32_t)key, (uint32_t)(key >> 32));
-    return (int)hipGetLastError();
-  }
-  dim3 grid((unsigned)((d.P2 + kFwdTP - 1) / kFwdTP), (unsigned)N), block(kPotThreads);
-  hipLaunchKernelGGL(potes_fwd_kernel<true>, grid, block, 0, reinterpret_cast<hipStream_t>(stream),
-                     x, w1, b1, w2, b2, h2, m2, s1, N, T, reinterpret_cast<uint4*>(rnd_out),
-                     rnd_out ? rnd_bytes / 16 : 0ll, key_dev, (uint32_t)key, (uint32_t)(key >> 32));
+  hipLaunchKernelGGL(potes_fwd_mfma_kernel<true>, dim3(potes_fwd_mfma_blocks(N, d)),
+                     dim3(kPotThreads), 0, reinterpret_cast<hipStream_t>(stream), x, w1, b1, w2, b2, h2, m2, s1, N, T,
+                     reinterpret_cast<uint4*>(rnd_out), rnd_out ? rnd_bytes / 16 : 0ll, key_dev,
+                     (uint32_t)key, (uint32_t)(key >> 32));
   return (int)hipGetLastError();
 }
 
@@ -2516,17 +2037,8 @@ extern "C" int pcgmix_potes_stack_bwd_mask_f32(const float* x, const float* grad
     return hipErrorInvalidValue;
   const int G = pcgmix_potes_bwd_blocks(N, T);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  static const bool fused = getenv("PCGMIX_POTES_BWD_UNFUSED") == nullptr;     // A/B runs
-  static const bool pairs = getenv("PCGMIX_POTES_BWD_NO_PAIRS") == nullptr;
-  if (fused && pairs)
-    hipLaunchKernelGGL(potes_bwd_pair_kernel, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2,
-                       m2, w1, b1, w2, b2, partial, N, T);
-  else if (fused)
-    hipLaunchKernelGGL(potes_bwd_fused_kernel, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2,
-                       m2, w1, b1, w2, b2, partial, N, T);
-  else
-    hipLaunchKernelGGL(potes_bwd_kernel<true>, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2,
-                       m2, w1, b1, w2, b2, partial, N, T);
+  hipLaunchKernelGGL(potes_bwd_pair_kernel, dim3((unsigned)G), dim3(kPotThreads), 0, s, x, grad_h2,
+                     m2, w1, b1, w2, b2, partial, N, T);
   if (grads)      // NULL: the caller reduces later (pcgmix_adam_clip_multi_reduce_dev_f32 / pcgmix_potes_reduce_f32)
     hipLaunchKernelGGL(potes_reduce_kernel, dim3(kNGrad), dim3(kPotThreads), 0, s, partial, grads, G);
   return (int)hipGetLastError();
@@ -2540,23 +2052,18 @@ extern "C" int pcgmix_potes_stack_input_grad_mask_f32(const float* grad_h2, cons
   if (!grad_h2 || !m2 || !s1 || !w1 || !w2 || !grad_x || N < 0 || N > 65535 || T < 14)
     return hipErrorInvalidValue;
   if (N == 0) return hipSuccess;
-  dim3 grid((unsigned)((T + kInNU - 1) / kInNU), (unsigned)N), block(kPotThreads);
-  static const bool pairs = getenv("PCGMIX_POTES_INGRAD_NO_PAIRS") == nullptr;     // A/B runs
-  if (pairs) {
-    // persistent blocks: 6 resident per CU (81 VGPRs, 22 KB of LDS); twice that many, the second
-    // half starting as the first ends, evens out the tail: 1024: 34.0, 1536: 33.2, 2048: 31.3,
-    // 3072: 30.6 us at N = 1024 x 5000 (profiles/r4_potes_ingrad_pair.txt)
-    long long cap = 3072;
-    if (const char* env = getenv("PCGMIX_POTES_INGRAD_BLOCKS")) {   // tuning runs
-      const long long v = atoll(env);
-      if (v >= 1 && v <= 65535) cap = v;
-    }
-    const long long work = (long long)N * ((T + kInNU - 1) / kInNU);
-    hipLaunchKernelGGL(potes_input_grad_pair_kernel, dim3((unsigned)(work < cap ? work : cap)), block, 0,
-                       reinterpret_cast<hipStream_t>(stream), grad_h2, m2, s1, w1, w2, grad_x, N, T);
-  } else
-    hipLaunchKernelGGL(potes_input_grad_mask_kernel, grid, block, 0,
-                       reinterpret_cast<hipStream_t>(stream), grad_h2, m2, s1, w1, w2, grad_x, N, T);
+  // persistent blocks: 6 resident per CU (81 VGPRs, 22 KB of LDS); twice that many, the second
+  // half starting as the first ends, evens out the tail: 1024: 34.0, 1536: 33.2, 2048: 31.3,
+  // 3072: 30.6 us at N = 1024 x 5000 (profiles/r4_potes_ingrad_pair.txt)
+  long long cap = 3072;
+  if (const char* env = getenv("PCGMIX_POTES_INGRAD_BLOCKS")) {   // tuning runs
+    const long long v = atoll(env);
+    if (v >= 1 && v <= 65535) cap = v;
+  }
+  const long long work = (long long)N * ((T + kInNU - 1) / kInNU);
+  hipLaunchKernelGGL(potes_input_grad_pair_kernel, dim3((unsigned)(work < cap ? work : cap)),
+                     dim3(kPotThreads), 0, reinterpret_cast<hipStream_t>(stream), grad_h2, m2, s1, w1,
+                     w2, grad_x, N, T);
   return (int)hipGetLastError();
 }
 

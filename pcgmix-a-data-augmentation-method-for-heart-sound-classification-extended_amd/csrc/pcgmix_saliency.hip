@@ -428,14 +428,14 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
     const float* __restrict__ sal, const int32_t* __restrict__ frames,
     const int32_t* __restrict__ mix_idx, float lam, float oml, float2* __restrict__ part, int B,
     int T, int max_len, const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst,
-    int pay_n16, const PartnerPack pk, const OrderPack ord) {
+    int pay_n16, const PartnerPack pk) {
   extern __shared__ __align__(16) float smem[];
   // Side job of the LAST block in launch order (shortest state, last candidate slice: it almost
   // never has candidates of its own): copy pay_n16 16-byte words from pay_src — host memory the
   // device can read, e.g. the warp knots in the step context's pinned slot — to pay_dst.  The
   // splice kernel launched behind this one reads them from device memory; a hipMemcpyAsync of
   // this size (49 KB at bs 256) takes the SDMA path and stalls the stream for ~25 us.
-  if (pay_n16 && blockIdx.x == gridDim.x - 1)
+  if (pay_n16 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 3 && blockIdx.z == gridDim.z - 1)
     for (int i = threadIdx.x; i < pay_n16; i += kDispThreads) pay_dst[i] = pay_src[i];
   __shared__ float best_v[kDispThreads / 64];
   __shared__ int best_d[kDispThreads / 64];
@@ -446,28 +446,13 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   // gridDim.x * 4 apart — a multiple of the CU count at the benchmark batch, i.e. the SAME CU,
   // whose LDS pipe the heaviest pair then saturates alone.  Rotating the sample index by a
   // z-dependent offset puts them on different CUs.
-  // The grid is one-dimensional: block i = (slice z = i / 4B, pair i % 4B) — slice-major in both
-  // forms, so that consecutive blocks (dealt round-robin to the eight XCDs) are different pairs of
-  // similar weight.  With `ord` the pairs come in the order the host hands over (heaviest first: the
-  // launch ends when its longest chain does, so the long ones start first); without one,
-  // x = i % B, y = (i / B) % 4 as above.  (Pair-major — the four slices of a pair as consecutive
-  // blocks — was 44 us against 34: the slices z >= 2 are mostly empty, so XCDs 2, 3, 6, 7 drained
-  // at once while the heavy z = 0, 1 slices of the long diastole pairs piled up four per CU on the
-  // other half of the chip.)
-  int b, k, z;
-  if (ord.n) {
-    const unsigned p = blockIdx.x % (4u * (unsigned)B);
-    const unsigned e = (ord.w[p >> 1] >> (16 * (p & 1))) & 0xffffu;
-    b = (int)(e >> 2);
-    k = (int)(e & 3u);
-    z = (int)(blockIdx.x / (4u * (unsigned)B));
-    if (b >= B) b = B - 1;
-  } else {
-    const unsigned x = blockIdx.x % (unsigned)B, y = (blockIdx.x / (unsigned)B) & 3u;
-    z = (int)(blockIdx.x / (4u * (unsigned)B));
-    b = (int)((x + (unsigned)z * ((unsigned)B / kDispSplit + 3)) % (unsigned)B);
-    k = (0x2013 >> (4 * y)) & 3;                    // y 0,1,2,3 -> state 3,1,0,2
-  }
+  // (Round 4 tried handing the pairs over sorted by the length of one candidate's chain of sums —
+  // the own state's length —, heaviest first, in the kernel arguments: 35.3 us against 35.2 in this
+  // order, profiles/r4_disp_dispatch_order_null.txt.  The state-major order below is already a
+  // coarse longest-first and deals one long diastole block to every CU.)
+  const int z = blockIdx.z;
+  const int b = (int)((blockIdx.x + (unsigned)z * (gridDim.x / kDispSplit + 3)) % gridDim.x);
+  const int k = (0x2013 >> (4 * blockIdx.y)) & 3;   // blockIdx.y 0,1,2,3 -> state 3,1,0,2
   float2* out = part + ((size_t)b * 4 + k) * kDispSplit + z;
   int m = pk.n ? partner_get(pk, b) : mix_idx[b];
   m = (m < 0 || m >= B) ? b : m;
@@ -672,46 +657,6 @@ extern "C" int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames,
                                       reinterpret_cast<hipStream_t>(stream));
 }
 
-// Dispatch order of the search's (sample, state) pairs, longest chain first.  A pair's blocks run
-// ONE candidate per lane, so a block is as long as one candidate's chain of sums — the OWN state's
-// length either way (head + middle + tail when it is the longer one, the middle sum over it when
-// it is the shorter one) — and the launch ends when its last such chain does.  Bucket sort, O(B).
-extern "C" int pcgmix_salopt_dispatch_order(const int64_t* frames, const int64_t* mix, int B,
-                                            uint16_t* order) {
-  if (!frames || !mix || !order || B <= 0 || B > pcgmix::kPackB) return 1;
-  constexpr int kBuckets = 4096;
-  int cnt[kBuckets + 1];
-  uint16_t chain[pcgmix::kPackB * 4];
-  for (int i = 0; i <= kBuckets; ++i) cnt[i] = 0;
-  for (int b = 0; b < B; ++b) {
-    const int64_t m = mix[b];
-    if (m < 0 || m >= B) return 1;
-    for (int k = 0; k < 4; ++k) {
-      const int64_t n1 = frames[b * 5 + k + 1] - frames[b * 5 + k],
-                    n2 = frames[m * 5 + k + 1] - frames[m * 5 + k];
-      int64_t len = n1 == n2 ? 0 : n1;                 // equal lengths: no search at all
-      len = len < 0 ? 0 : (len > kBuckets ? kBuckets : len);
-      chain[b * 4 + k] = (uint16_t)len;
-      ++cnt[len];
-    }
-  }
-  int at = 0;
-  for (int l = kBuckets; l >= 0; --l) { const int n = cnt[l]; cnt[l] = at; at += n; }
-  for (int i = 0; i < B * 4; ++i) order[cnt[chain[i]]++] = (uint16_t)i;
-  return 0;
-}
-
-extern "C" int pcgmix_salopt_disp_ordered_f32(const float* sal, const int32_t* frames,
-                                              const int32_t* mix_idx, float lam, int mode,
-                                              int32_t* disp, void* workspace, int max_len,
-                                              const uint16_t* order, int B, int T,
-                                              pcgmix_stream_t stream) {
-  if (!disp) return hipErrorInvalidValue;
-  return pcgmix::launch_salopt_search(sal, frames, mix_idx, lam, mode, disp, workspace, max_len, B, T,
-                                      reinterpret_cast<hipStream_t>(stream), nullptr, nullptr, 0,
-                                      nullptr, B <= pcgmix::kPackB ? order : nullptr);
-}
-
 // The saliency-guided splice in one call: the displacement search, then the fused splice(+warp)
 // kernel, whose blocks reduce the search's per-block results for their own sample themselves —
 // no finalize launch between the two.  disp_out (optional): the displacements as int32 (B,4),
@@ -741,16 +686,10 @@ extern "C" int pcgmix_salopt_mix_warp_f32(const float* x, float* y, const float*
 int pcgmix::launch_salopt_search(const float* sal, const int32_t* frames, const int32_t* mix_idx,
                                  float lam, int mode, int32_t* disp, void* workspace, int max_len,
                                  int B, int T, hipStream_t s, const void* pay_src_v, void* pay_dst_v,
-                                 int pay_n16, const int16_t* partners16, const uint16_t* order) {
+                                 int pay_n16, const int16_t* partners16) {
   using namespace pcgmix;
   const PartnerPack pk = make_partner_pack(partners16, B);
-  OrderPack ord;
-  ord.n = 0;
-  if (order && B > 0 && B <= kPackB) {
-    uint16_t* e = reinterpret_cast<uint16_t*>(ord.w);
-    for (int i = 0; i < B * 4; ++i) e[i] = order[i];
-    ord.n = B * 4;
-  }
+
   const uint4* pay_src = static_cast<const uint4*>(pay_src_v);
   uint4* pay_dst = static_cast<uint4*>(pay_dst_v);
   if (pay_n16 < 0 || (pay_n16 > 0 && (!pay_src || !pay_dst ||
@@ -780,12 +719,12 @@ int pcgmix::launch_salopt_search(const float* sal, const int32_t* frames, const 
   for (int i = 0; i < 8; ++i)
     if (hipError_t e = allow_large_lds(kerns[i], &lds_ok[i], 150 * 1024)) return (int)e;
   const float oml = 1.0f - lam;
-  dim3 grid((unsigned)B * 4u * kDispSplit), block(kDispThreads);
+  dim3 grid((unsigned)B, 4, kDispSplit), block(kDispThreads);
   float2* part = static_cast<float2*>(workspace);
   const bool shallow = max_len <= kPwShallowN;
 #define PCGMIX_DISP(M, CP, DP)                                                                       \
   hipLaunchKernelGGL((salopt_disp_kernel<M, CP, DP>), grid, block, lds, s, sal, frames, mix_idx, lam, \
-                     oml, part, B, T, max_len, pay_src, pay_dst, pay_n16, pk, ord)
+                     oml, part, B, T, max_len, pay_src, pay_dst, pay_n16, pk)
 #define PCGMIX_DISP_D(M, CP) do { if (shallow) PCGMIX_DISP(M, CP, 4); else PCGMIX_DISP(M, CP, 8); } while (0)
   if (mode == 0) { if (copies) PCGMIX_DISP_D(0, true); else PCGMIX_DISP_D(0, false); }
   else { if (copies) PCGMIX_DISP_D(1, true); else PCGMIX_DISP_D(1, false); }

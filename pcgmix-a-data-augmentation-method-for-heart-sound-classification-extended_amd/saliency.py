@@ -369,28 +369,11 @@ def get_saliency_maps(args, device, data, target_ohe, frames, dim=1, gauss_k_n=1
         return saliency_post(grad, fr.data_ptr(), gauss_k_n)
 
 
-def dispatch_order(frames: np.ndarray, mix: np.ndarray) -> Optional[np.ndarray]:
-    """(sample, state) pairs of the displacement search, longest chain of sums first
-    (``pcgmix_salopt_dispatch_order``; batches of up to 256 samples, else None): what the step
-    context hands its own search launch."""
-    B = int(frames.shape[0])
-    if B == 0 or B > 256:
-        return None
-    f = np.ascontiguousarray(frames, dtype=np.int64)
-    m = np.ascontiguousarray(mix, dtype=np.int64)
-    order = np.empty(B * 4, dtype=np.uint16)
-    if _lib.load().pcgmix_salopt_dispatch_order(f.ctypes.data, m.ctypes.data, B, order.ctypes.data):
-        return None
-    return order
-
-
 def optimal_displacements(saliency_maps: torch.Tensor, frames_dev_ptr: int, mix_dev_ptr: int,
-                          lam: float, mode: int, B: int, T: int, max_len: int = 0,
-                          order: Optional[np.ndarray] = None) -> torch.Tensor:
+                          lam: float, mode: int, B: int, T: int, max_len: int = 0) -> torch.Tensor:
     """Displacement of the shorter state inside the longer one for every (sample, state):
     int32 (B,4) on device (augmentations.py:60-128 via pcgmix_salopt_disp_f32).  ``max_len``: the
-    longest heart state of the batch in samples (from the host copy of ``frames``); 0 = unknown.
-    ``order`` (``dispatch_order``): launch the pairs in that order — same results, shorter launch."""
+    longest heart state of the batch in samples (from the host copy of ``frames``); 0 = unknown."""
     if saliency_maps.shape != (B, T) or saliency_maps.dtype != torch.float32 \
             or not saliency_maps.is_contiguous() or not saliency_maps.is_cuda:
         raise ValueError("saliency maps must be a contiguous float32 (B, T) device tensor")
@@ -399,14 +382,6 @@ def optimal_displacements(saliency_maps: torch.Tensor, frames_dev_ptr: int, mix_
     ws = torch.empty(max(1, lib.pcgmix_salopt_workspace_bytes(B) // 8), dtype=torch.int64,
                      device=saliency_maps.device)
     stream = torch.cuda.current_stream(saliency_maps.device).cuda_stream
-    if order is not None:
-        if order.dtype != np.uint16 or order.shape != (B * 4,) or not order.flags.c_contiguous:
-            raise ValueError("order must be dispatch_order()'s uint16 (B*4,) array")
-        _lib.check(lib.pcgmix_salopt_disp_ordered_f32(
-            saliency_maps.data_ptr(), frames_dev_ptr, mix_dev_ptr, ctypes.c_float(lam), mode,
-            disp.data_ptr(), ws.data_ptr(), int(max_len), order.ctypes.data, B, T,
-            ctypes.c_void_p(stream)), "pcgmix_salopt_disp_ordered_f32")
-        return disp
     _lib.check(lib.pcgmix_salopt_disp_f32(saliency_maps.data_ptr(), frames_dev_ptr, mix_dev_ptr,
                                           ctypes.c_float(lam), mode, disp.data_ptr(), ws.data_ptr(),
                                           int(max_len), B, T, ctypes.c_void_p(stream)),

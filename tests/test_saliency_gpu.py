@@ -761,31 +761,3 @@ def test_displacement_flip_rate_with_a_trained_saliency_model(mode, device, reco
     warnings.warn(f"[a7 flip rate] {mode} trained model, (256,4,5000): {len(flips)} of {searched} searched "
                   f"states differ from the CPU reference (all proven near-ties), eps={eps:.2e}")
     assert rate <= 0.01, (len(flips), searched)
-
-
-@pytest.mark.parametrize("mode", [0, 1])
-def test_ordered_dispatch_gives_the_same_displacements(mode, device):
-    """pcgmix_salopt_disp_ordered_f32 with pcgmix_salopt_dispatch_order's order (what the step
-    context launches: longest chain first) == the natural-order search, on the bench batch and on a
-    batch with equal-length pairs; the order is a permutation sorted by the own state's length."""
-    from pcgmix_amd import synthetic
-    for B, T, seed in ((256, 5000, 0), (37, 2500, 3)):
-        frames, labels, wav = synthetic.make_index_data(B, T, sample_rate=T // 2.5, seed=seed)
-        frames[1] = frames[0]
-        rs = np.random.RandomState(seed)
-        sal = rs.rand(B, T).astype(np.float32)
-        sal[np.arange(T)[None, :] >= frames[:, 4:5]] = 0
-        mix = rs.permutation(B)
-        mix[0], mix[1] = 1, 0
-        order = saliency.dispatch_order(frames, mix)
-        assert sorted(order.tolist()) == list(range(B * 4))
-        lens = np.diff(frames, axis=1)
-        key = np.where(lens != lens[mix], lens, 0).reshape(-1)[order]
-        assert (np.diff(key.astype(np.int64)) <= 0).all()
-        fr, mx = dev_i32(frames, device), dev_i32(mix, device)
-        s = torch.from_numpy(sal).to(device)
-        a = saliency.optimal_displacements(s, fr.data_ptr(), mx.data_ptr(), 0.41, mode, B, T,
-                                           max_len=int(lens.max()))
-        b = saliency.optimal_displacements(s, fr.data_ptr(), mx.data_ptr(), 0.41, mode, B, T,
-                                           max_len=int(lens.max()), order=order)
-        assert torch.equal(a, b)
