@@ -50,14 +50,24 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 //                  im: -win[k] * sin(2 pi bin k / n_fft);   0 for padded bins / k > n_fft/2
 //   [off_wts]      float  wts[n_mels][n_bins]             librosa.filters.mel, slaney, float32
 //   [off_krange]   int32  krange[n_mels][2]               first / last non-zero bin
+//   [off_left]     double left[n_left][n_fft/2][2]        (re, im) coefficients of the bins beyond
+//                  the last FULL 16-bin tile, k = 1 .. n_fft/2: those few rows (5 of 69 at
+//                  n_fft = 136) run on the float64 VALU instead of costing a whole matrix tile
+// m_tiles counts the 16-row tiles the power spectrogram has room for; m_mfma of them go through
+// the matrix cores (round 4: the f64 matrix instruction issues every ~150 cycles per SIMD, the
+// phase was 476 of them on the busiest SIMD — profiles/r4_logmel_sq_counters.json —, and a fifth
+// tile holding five real bins was a fifth of that).
 struct MelTables {
-  int m_tiles, ksteps, n_bins;
-  size_t off_wts, off_krange, total;
+  int m_tiles, m_mfma, n_left, ksteps, n_bins;
+  size_t off_wts, off_krange, off_left, total;
 };
 __host__ __device__ inline MelTables mel_tables(int n_fft, int n_mels) {
   MelTables t;
   t.n_bins = n_fft / 2 + 1;
   t.m_tiles = (t.n_bins + 15) / 16;
+  const int rem = t.n_bins % 16;
+  t.n_left = (rem > 0 && rem <= 8 && t.n_bins > 16) ? rem : 0;
+  t.m_mfma = t.n_left ? t.n_bins / 16 : t.m_tiles;
   t.ksteps = (n_fft / 2 + 3) / 4;
   size_t o = (size_t)t.m_tiles * t.ksteps * 2 * 64 * sizeof(double);
   t.off_wts = o;
@@ -65,12 +75,15 @@ __host__ __device__ inline MelTables mel_tables(int n_fft, int n_mels) {
   o = (o + 7) & ~(size_t)7;
   t.off_krange = o;
   o += (size_t)n_mels * 2 * sizeof(int32_t);
+  o = (o + 7) & ~(size_t)7;
+  t.off_left = o;
+  o += (size_t)t.n_left * (n_fft / 2) * 2 * sizeof(double);
   t.total = (o + 15) & ~(size_t)15;
   return t;
 }
 
 struct MelLayout {  // byte offsets into dynamic LDS
-  int xrow, ps, img, melw, total;
+  int xrow, ps, img, melw, left, total;
   int nfp, xr;
 };
 // n_frames = frames one block transforms: 1 + T/hop of a heart-cycle item, or the tile size of
@@ -87,6 +100,7 @@ __host__ __device__ inline MelLayout mel_layout(int n_frames, int n_fft, int hop
   L.ps = o;   o += tb.m_tiles * 16 * L.nfp * 4; // power spectrogram [bin][frame]        (float)
   L.img = o;  o += (image ? n_mels * W : 0) * 4;  // dB image                            (float)
   L.melw = o; o += n_mels * 8 * 4;              // per band: klo, khi, 4 weights (+2 pad) (32 B)
+  L.left = o; o += tb.n_left * (n_fft / 2) * 2 * 8;   // coefficients of the VALU bins       (double)
   L.total = o;
   return L;
 }
@@ -140,6 +154,11 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   float* ps = reinterpret_cast<float*>(smem + L.ps);
   float* img = reinterpret_cast<float*>(smem + L.img);
   float* melw = reinterpret_cast<float*>(smem + L.melw);
+  double* leftc = reinterpret_cast<double*>(smem + L.left);
+  {
+    const double* lg = reinterpret_cast<const double*>(tables + tb.off_left);
+    for (int i = tid; i < tb.n_left * (n_fft / 2) * 2; i += kMelThreads) leftc[i] = lg[i];
+  }
 
   // per-band filter span and its first 4 weights -> LDS (global latency overlaps the row copy)
   for (int m = tid; m < n_mels; m += kMelThreads) {
@@ -181,9 +200,35 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   // C layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4*reg, col = lane&15.  The re and the
   // im GEMM use the same row -> bin map, so a lane holds re and im of the same (bin, frame) in
   // the same register slot of its two accumulators: |.|^2 needs no cross-lane traffic.
-  const int n_units = tb.m_tiles * (L.nfp / (16 * kNGroup));
+  const int n_units = tb.m_mfma * (L.nfp / (16 * kNGroup));
   const int n_groups = L.nfp / (16 * kNGroup);
   const int col = lane & 15, kq = lane >> 4;
+  // The bins beyond the last full tile on the float64 VALU, one (bin, frame) per lane, k ascending,
+  // by the waves that get one matrix unit fewer than the others (or by all of them): it runs
+  // beside the other waves' matrix instructions, which occupy a different pipe.
+  if (tb.n_left) {
+    const int spare0 = n_units % kMelWaves;        // waves >= spare0 have the shorter unit list
+    const int first = (spare0 > 0 && spare0 < kMelWaves) ? spare0 : 0;
+    if (wave >= first) {
+      const int nh = n_fft / 2, n_out = tb.n_left * L.nfp;
+      for (int o = (wave - first) * 64 + lane; o < n_out; o += (kMelWaves - first) * 64) {
+        const int lb = o / L.nfp, f = o - lb * L.nfp;
+        const float* xl = xrow + f * hop;
+        const float* xh = xrow + f * hop + n_fft;
+        const double* cf = leftc + (size_t)lb * nh * 2;
+        double re = 0.0, im = 0.0;
+#pragma unroll 4
+        for (int k = 1; k <= nh; ++k) {
+          const double lo = (double)xl[k], hi = (double)xh[-k];
+          re = fma(cf[2 * (k - 1)], lo + hi, re);
+          im = fma(cf[2 * (k - 1) + 1], lo - hi, im);
+        }
+        const float fr = (float)re, fi = (float)im;
+        const float mag = hypotf(fr, fi);
+        ps[(16 * tb.m_mfma + lb) * L.nfp + f] = mag * mag;
+      }
+    }
+  }
   for (int unit = wave; unit < n_units; unit += kMelWaves) {
     const int mt = unit / n_groups, ng = unit - mt * n_groups;
     d4 are[kNGroup], aim[kNGroup];
@@ -423,6 +468,16 @@ extern "C" int pcgmix_logmel_tables(int n_fft, int n_mels, float fmin, float fma
         dst[l] = vr;
         dst[64 + l] = vi;
       }
+  {
+    double* left = reinterpret_cast<double*>(base + tb.off_left);
+    for (int lb = 0; lb < tb.n_left; ++lb)
+      for (int k = 1; k <= nh; ++k) {
+        const int bin = 16 * tb.m_mfma + lb;
+        const int idx = (int)(((long long)bin * k) % n_fft);
+        left[((size_t)lb * nh + (k - 1)) * 2] = win[k % n_fft] * cs[idx] * (k == nh ? 0.5 : 1.0);
+        left[((size_t)lb * nh + (k - 1)) * 2 + 1] = k == nh ? 0.0 : -win[k % n_fft] * sn[idx];
+      }
+  }
   // librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax, htk=False, norm='slaney', dtype=float32)
   std::vector<double> melf(n_mels + 2);
   const double m0 = hz_to_mel((double)fmin), m1 = hz_to_mel((double)fmax);
