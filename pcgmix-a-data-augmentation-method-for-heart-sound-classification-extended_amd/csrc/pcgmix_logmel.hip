@@ -105,6 +105,15 @@ __host__ __device__ inline MelLayout mel_layout(int n_frames, int n_fft, int hop
   return L;
 }
 
+// power_to_db's 10 * log10(max(amin, S)), amin = 1e-10, as 10 log10(2) * v_log_f32: the hardware
+// base-2 logarithm is good to 1 ulp, i.e. <= 3e-5 dB at the -100 dB end of the range, against the
+// ~40 instructions of the library log10f — the mel/dB phase was 8.2 us of a 35 us block and bound
+// by exactly that (profiles/r4_logmel_phases.txt).  The per-recording slice pass references its
+// columns with the same function, so the recording's maximum still maps to exactly 0 dB.
+__device__ __forceinline__ float power_db(float p) {
+  return 3.01029995663981195f * __builtin_amdgcn_logf(fmaxf(1e-10f, p));
+}
+
 constexpr int kPadConstant = 0, kPadReflect = 1;
 constexpr int kTileFrames = 128;   // frames per block of the per-recording pass
 
@@ -114,7 +123,15 @@ constexpr int kTileFrames = 128;   // frames per block of the per-recording pass
 //                 columns to the scratch `spec` (n_mels, scratch_cols), the tile's maximum mel
 //                 power folded into ref_pow[recording] (non-negative floats order like their bit
 //                 patterns, so an unsigned atomicMax is a float max).
-template <bool RECORD>
+// KS > 0: the number of k-steps is the compile-time constant KS (17 at n_fft = 136; 9 <= KS <= 24)
+// and a wave keeps a ring of eight A fragments in registers (slot = k-step mod 8, 32 VGPRs): at step
+// ks it consumes slot ks % 8 and refills it with step ks + 8 of the same unit or, once that is past
+// the end, with step ks % 8 of the wave's NEXT unit — eight k-steps of distance throughout, also
+// across units.  KS == 0: any n_fft, one k-step of prefetch.  Round 4 (profiles/r4_logmel_phases.txt, wall_clock64 around the phases of
+// one block): the matrix phase was 22-23 us of a 35 us block whether it held 476 or 340 matrix
+// instructions on its busiest SIMD — every k-step waited for its fragment's L2 round trip
+// (~650 ns, prefetch distance one k-step), 34 of them in a row on the waves with two units.
+template <bool RECORD, int KS>
 __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ frames,
     const long long* __restrict__ rec_off, const int32_t* __restrict__ rec_len,
@@ -229,6 +246,15 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
       }
     }
   }
+  double fr_re[8], fr_im[8];                         // KS > 0: the fragment ring
+  if (KS > 0 && wave < n_units) {
+    const double* ap0 = afrag + (size_t)(wave / n_groups) * KS * 128 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      fr_re[ks] = ap0[(size_t)ks * 128];
+      fr_im[ks] = ap0[(size_t)ks * 128 + 64];
+    }
+  }
   for (int unit = wave; unit < n_units; unit += kMelWaves) {
     const int mt = unit / n_groups, ng = unit - mt * n_groups;
     d4 are[kNGroup], aim[kNGroup];
@@ -238,25 +264,55 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
     // B operands: x[f*hop + k] +- x[f*hop + n_fft - k], frame f = 16*(kNGroup*ng + i) + col
     const float* xlo = xrow + (16 * kNGroup * ng + col) * hop + kq + 1;
     const float* xhi = xrow + (16 * kNGroup * ng + col) * hop + n_fft - kq - 1;
-    double a_re = ap[0], a_im = ap[64];
-    for (int ks = 0; ks < tb.ksteps; ++ks) {
-      const double cr = a_re, ci = a_im;
-      if (ks + 1 < tb.ksteps) {                      // prefetch the next k-step's A fragments
-        a_re = ap[(size_t)(ks + 1) * 128];
-        a_im = ap[(size_t)(ks + 1) * 128 + 64];
-      }
-      double bs[kNGroup], bd[kNGroup];
+    if (KS > 0) {
+      const int nxt = unit + kMelWaves;
+      const bool more = nxt < n_units;                // wave-uniform
+      const double* apn = afrag + (size_t)((more ? nxt : unit) / n_groups) * KS * 128 + lane;
 #pragma unroll
-      for (int i = 0; i < kNGroup; ++i) {
-        const double lo = (double)xlo[(16 * i) * hop + 4 * ks];
-        const double hi = (double)xhi[(16 * i) * hop - 4 * ks];
-        bs[i] = lo + hi;                             // exact in float64
-        bd[i] = lo - hi;
-      }
+      for (int ks = 0; ks < (KS > 0 ? KS : 1); ++ks) {
+        const double cr = fr_re[ks & 7], ci = fr_im[ks & 7];
+        if (ks + 8 < KS) {                           // eight steps ahead in this unit
+          fr_re[ks & 7] = ap[(size_t)(ks + 8) * 128];
+          fr_im[ks & 7] = ap[(size_t)(ks + 8) * 128 + 64];
+        } else if (more && KS - ks <= 8) {           // ... or the next unit's step ks % 8
+          fr_re[ks & 7] = apn[(size_t)(ks & 7) * 128];
+          fr_im[ks & 7] = apn[(size_t)(ks & 7) * 128 + 64];
+        }
+        double bs[kNGroup], bd[kNGroup];
 #pragma unroll
-      for (int i = 0; i < kNGroup; ++i) {
-        are[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(cr, bs[i], are[i], 0, 0, 0);
-        aim[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(ci, bd[i], aim[i], 0, 0, 0);
+        for (int i = 0; i < kNGroup; ++i) {
+          const double lo = (double)xlo[(16 * i) * hop + 4 * ks];
+          const double hi = (double)xhi[(16 * i) * hop - 4 * ks];
+          bs[i] = lo + hi;                           // exact in float64
+          bd[i] = lo - hi;
+        }
+#pragma unroll
+        for (int i = 0; i < kNGroup; ++i) {
+          are[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(cr, bs[i], are[i], 0, 0, 0);
+          aim[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(ci, bd[i], aim[i], 0, 0, 0);
+        }
+      }
+    } else {
+      double a_re = ap[0], a_im = ap[64];
+      for (int ks = 0; ks < tb.ksteps; ++ks) {
+        const double cr = a_re, ci = a_im;
+        if (ks + 1 < tb.ksteps) {                    // prefetch the next k-step's A fragments
+          a_re = ap[(size_t)(ks + 1) * 128];
+          a_im = ap[(size_t)(ks + 1) * 128 + 64];
+        }
+        double bs[kNGroup], bd[kNGroup];
+#pragma unroll
+        for (int i = 0; i < kNGroup; ++i) {
+          const double lo = (double)xlo[(16 * i) * hop + 4 * ks];
+          const double hi = (double)xhi[(16 * i) * hop - 4 * ks];
+          bs[i] = lo + hi;                           // exact in float64
+          bd[i] = lo - hi;
+        }
+#pragma unroll
+        for (int i = 0; i < kNGroup; ++i) {
+          are[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(cr, bs[i], are[i], 0, 0, 0);
+          aim[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(ci, bd[i], aim[i], 0, 0, 0);
+        }
       }
     }
 #pragma unroll
@@ -295,7 +351,7 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
       } else {
         for (int k = klo; k <= khi; ++k) accm = fmaf(wts[m * n_bins + k], ps[k * L.nfp + t], accm);
       }
-      const float db = 10.0f * log10f(fmaxf(1e-10f, accm));  // power_to_db, amin = 1e-10
+      const float db = power_db(accm);                       // power_to_db, amin = 1e-10
       if (RECORD) {
         pmax = fmaxf(pmax, accm);
         spec[(size_t)m * scratch_cols + out_col + t] = db;    // 256-byte runs per wave
@@ -375,7 +431,7 @@ __global__ __launch_bounds__(256) void logmel_slice_kernel(
     const int4* __restrict__ cycles, float* __restrict__ spec, int n_mels, float mean, float stdv,
     int W) {
   const int4 cy = cycles[blockIdx.x];
-  const float ref_db = 10.0f * log10f(fmaxf(1e-10f, __uint_as_float(ref_pow[cy.x])));
+  const float ref_db = power_db(__uint_as_float(ref_pow[cy.x]));
   const float floor_db = (ref_db - ref_db) - 80.0f;
   const int n = cy.z < 0 ? 0 : (cy.z > W ? W : cy.z);
   float* out = spec + (size_t)blockIdx.x * n_mels * W;
@@ -519,11 +575,21 @@ extern "C" int pcgmix_logmel_f32(const float* x, const int32_t* frames, const vo
   if (B == 0) return hipSuccess;
   const MelLayout L = mel_layout(1 + T / hop, n_fft, hop, n_mels, W);
   if (L.total > 158 * 1024) return hipErrorInvalidValue;
-  static unsigned long long lds_ok = 0;
-  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(logmel_kernel<false>), &lds_ok,
+  static unsigned long long lds_ok = 0, lds_ok17 = 0;
+  if (mel_tables(n_fft, n_mels).ksteps == 17) {      // the reference's n_fft = 136
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(logmel_kernel<false, 17>),
+                                       &lds_ok17, 158 * 1024))
+      return (int)e;
+    hipLaunchKernelGGL((logmel_kernel<false, 17>), dim3((unsigned)B), dim3(kMelThreads),
+                       (size_t)L.total, reinterpret_cast<hipStream_t>(stream), x, frames, nullptr,
+                       nullptr, nullptr, static_cast<const unsigned char*>(tables), spec, nullptr, 0LL,
+                       frames_out, B, T, n_fft, hop, n_mels, mean, std, W, pad_mode);
+    return (int)hipGetLastError();
+  }
+  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(logmel_kernel<false, 0>), &lds_ok,
                                      158 * 1024))
     return (int)e;
-  hipLaunchKernelGGL(logmel_kernel<false>, dim3((unsigned)B), dim3(kMelThreads), (size_t)L.total,
+  hipLaunchKernelGGL((logmel_kernel<false, 0>), dim3((unsigned)B), dim3(kMelThreads), (size_t)L.total,
                      reinterpret_cast<hipStream_t>(stream), x, frames, nullptr, nullptr, nullptr,
                      static_cast<const unsigned char*>(tables), spec, nullptr, 0LL, frames_out, B, T,
                      n_fft, hop, n_mels, mean, std, W, pad_mode);
@@ -547,18 +613,28 @@ extern "C" int pcgmix_logmel_recordings_f32(
     return hipErrorInvalidValue;
   const MelLayout L = mel_layout(kTileFrames, n_fft, hop, n_mels, W, false);
   if (L.total > 158 * 1024) return hipErrorInvalidValue;
-  static unsigned long long lds_ok = 0;
-  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(logmel_kernel<true>), &lds_ok,
-                                     158 * 1024))
+  static unsigned long long lds_ok = 0, lds_ok17 = 0;
+  const bool ks17 = mel_tables(n_fft, n_mels).ksteps == 17;
+  if (hipError_t e = ks17 ? allow_large_lds(reinterpret_cast<const void*>(logmel_kernel<true, 17>),
+                                            &lds_ok17, 158 * 1024)
+                          : allow_large_lds(reinterpret_cast<const void*>(logmel_kernel<true, 0>),
+                                            &lds_ok, 158 * 1024))
     return (int)e;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, ref_pow, R);
   static_assert(sizeof(long long) == sizeof(int64_t), "rec_off is read as long long");
-  hipLaunchKernelGGL(logmel_kernel<true>, dim3((unsigned)n_tiles), dim3(kMelThreads),
-                     (size_t)L.total, s, y, nullptr, reinterpret_cast<const long long*>(rec_off),
-                     rec_len, reinterpret_cast<const int4*>(tiles),
-                     static_cast<const unsigned char*>(tables), db_scratch, ref_pow, scratch_cols,
-                     nullptr, n_tiles, 0, n_fft, hop, n_mels, mean, std, W, pad_mode);
+  if (ks17)
+    hipLaunchKernelGGL((logmel_kernel<true, 17>), dim3((unsigned)n_tiles), dim3(kMelThreads),
+                       (size_t)L.total, s, y, nullptr, reinterpret_cast<const long long*>(rec_off),
+                       rec_len, reinterpret_cast<const int4*>(tiles),
+                       static_cast<const unsigned char*>(tables), db_scratch, ref_pow, scratch_cols,
+                       nullptr, n_tiles, 0, n_fft, hop, n_mels, mean, std, W, pad_mode);
+  else
+    hipLaunchKernelGGL((logmel_kernel<true, 0>), dim3((unsigned)n_tiles), dim3(kMelThreads),
+                       (size_t)L.total, s, y, nullptr, reinterpret_cast<const long long*>(rec_off),
+                       rec_len, reinterpret_cast<const int4*>(tiles),
+                       static_cast<const unsigned char*>(tables), db_scratch, ref_pow, scratch_cols,
+                       nullptr, n_tiles, 0, n_fft, hop, n_mels, mean, std, W, pad_mode);
   if (n_cycles > 0)
     hipLaunchKernelGGL(logmel_slice_kernel, dim3((unsigned)n_cycles), dim3(256), 0, s, db_scratch,
                        scratch_cols, ref_pow, reinterpret_cast<const int4*>(cycles), spec, n_mels,
