@@ -131,6 +131,18 @@ constexpr int kTileFrames = 128;   // frames per block of the per-recording pass
 // one block): the matrix phase was 22-23 us of a 35 us block whether it held 476 or 340 matrix
 // instructions on its busiest SIMD — every k-step waited for its fragment's L2 round trip
 // (~650 ns, prefetch distance one k-step), 34 of them in a row on the waves with two units.
+// Probe builds only (-DPCGMIX_PHASE_CLOCK, profiles/probes/logmel_phase_clock.py): block 7 of the
+// per-cycle launch leaves wall_clock64 (100 MHz) at its phase boundaries in g_logmel_clock.
+#ifdef PCGMIX_PHASE_CLOCK
+__device__ long long g_logmel_clock[8];
+#define PCGMIX_CLOCK(i)                                                          \
+  do {                                                                           \
+    if (!RECORD && blockIdx.x == 7 && threadIdx.x == 0) g_logmel_clock[i] = wall_clock64(); \
+  } while (0)
+#else
+#define PCGMIX_CLOCK(i) do { } while (0)
+#endif
+
 template <bool RECORD, int KS>
 __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ frames,
@@ -142,6 +154,7 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ float red[kMelWaves];
   const MelTables tb = mel_tables(n_fft, n_mels);
+  PCGMIX_CLOCK(0);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_bins = tb.n_bins, pad = n_fft / 2;
   // what this block transforms: `n_frames` centred frames of the signal xg[0..len), the first
@@ -212,6 +225,7 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
     }
   }
   __syncthreads();
+  PCGMIX_CLOCK(1);
 
   // ---- STFT power on the f64 matrix cores -----------------------------------------------------
   // C layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4*reg, col = lane&15.  The re and the
@@ -224,11 +238,17 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   // by the waves that get one matrix unit fewer than the others (or by all of them): it runs
   // beside the other waves' matrix instructions, which occupy a different pipe.
   if (tb.n_left) {
-    const int spare0 = n_units % kMelWaves;        // waves >= spare0 have the shorter unit list
-    const int first = (spare0 > 0 && spare0 < kMelWaves) ? spare0 : 0;
-    if (wave >= first) {
+    // waves whose LAST round is empty (see unit_of below) take the VALU work; all of them if the
+    // rounds are full
+    const int spare = n_units % kMelWaves;         // units in the last, partial round (0: none)
+    const int last_r = n_units / kMelWaves;
+    const int jw = last_r == 0 ? wave : ((13 * wave) & 15);      // this wave's slot in that round
+    const bool idle = spare == 0 || jw >= spare;
+    const int n_idle = spare == 0 ? kMelWaves : kMelWaves - spare;
+    const int my = spare == 0 ? wave : jw - spare;               // rank among the idle waves
+    if (idle) {
       const int nh = n_fft / 2, n_out = tb.n_left * L.nfp;
-      for (int o = (wave - first) * 64 + lane; o < n_out; o += (kMelWaves - first) * 64) {
+      for (int o = my * 64 + lane; o < n_out; o += n_idle * 64) {
         const int lb = o / L.nfp, f = o - lb * L.nfp;
         const float* xl = xrow + f * hop;
         const float* xh = xrow + f * hop + n_fft;
@@ -246,6 +266,13 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
       }
     }
   }
+  // Units are dealt in rounds of 16.  In a round that is not full the waves that get a unit must
+  // sit on different SIMDs, and how a block's 16 waves map to the CU's four SIMDs is not something
+  // to rely on: with `unit = wave + 16 r` the four second-round units of the 20 went to waves 0-3,
+  // and the matrix phase took exactly as long as with 25 units (waves 0-3 share a SIMD, it seems:
+  // 8 units on it either way).  Round r >= 1 hands unit 16 r + j to wave 5 j mod 16 — 0, 5, 10, 15,
+  // 4, 9, ... — which spreads any prefix over both plausible mappings (wave mod 4 and wave / 4).
+  auto unit_of = [&](int r) { return r == 0 ? wave : 16 * r + ((13 * wave) & 15); };
   double fr_re[8], fr_im[8];                         // KS > 0: the fragment ring
   if (KS > 0 && wave < n_units) {
     const double* ap0 = afrag + (size_t)(wave / n_groups) * KS * 128 + lane;
@@ -255,7 +282,7 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
       fr_im[ks] = ap0[(size_t)ks * 128 + 64];
     }
   }
-  for (int unit = wave; unit < n_units; unit += kMelWaves) {
+  for (int round = 0, unit = wave; unit < n_units; ++round, unit = unit_of(round)) {
     const int mt = unit / n_groups, ng = unit - mt * n_groups;
     d4 are[kNGroup], aim[kNGroup];
 #pragma unroll
@@ -265,7 +292,7 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
     const float* xlo = xrow + (16 * kNGroup * ng + col) * hop + kq + 1;
     const float* xhi = xrow + (16 * kNGroup * ng + col) * hop + n_fft - kq - 1;
     if (KS > 0) {
-      const int nxt = unit + kMelWaves;
+      const int nxt = unit_of(round + 1);
       const bool more = nxt < n_units;                // wave-uniform
       const double* apn = afrag + (size_t)((more ? nxt : unit) / n_groups) * KS * 128 + lane;
 #pragma unroll
@@ -328,6 +355,7 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   }
   __syncthreads();
 
+  PCGMIX_CLOCK(2);
   // ---- mel projection, dB, maximum ------------------------------------------------------------
   float vmax = -INFINITY;  // cycle mode: max over the item of 10*log10(max(amin, S)), all columns
   float pmax = 0.f;        // recording mode: max mel power of this tile's valid frames
@@ -380,6 +408,7 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   float ref_db = red[0];
   for (int i = 1; i < kMelWaves; ++i) ref_db = fmaxf(ref_db, red[i]);
 
+  PCGMIX_CLOCK(3);
   // ---- column boundaries, dB referencing, top_db clip, normalisation, crop --------------------
   int col_end = W;
   {
@@ -415,6 +444,10 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
       out[i] = v;
     }
   }
+#ifdef PCGMIX_PHASE_CLOCK
+  __syncthreads();
+  PCGMIX_CLOCK(4);
+#endif
 }
 
 __global__ void zero_u32_kernel(unsigned* p, int n) {
@@ -486,6 +519,12 @@ static double mel_to_hz(double m) {
 }
 
 }  // namespace pcgmix
+
+#ifdef PCGMIX_PHASE_CLOCK
+extern "C" int pcgmix_logmel_phase_clock(long long* out5) {
+  return (int)hipMemcpyFromSymbol(out5, HIP_SYMBOL(pcgmix::g_logmel_clock), 5 * sizeof(long long));
+}
+#endif
 
 extern "C" long long pcgmix_logmel_tables_size(int n_fft, int n_mels) {
   if (n_fft < 2 || (n_fft & 1) || n_mels < 1) return 0;
