@@ -290,6 +290,7 @@ struct DrawEntry {
 
 struct pcgmix_npdraw {
   static constexpr int kMaxEntries = 4;
+  static constexpr int kSpinUs = 2000;
   DrawEntry entry[kMaxEntries];
   int entries = 1;                  // lookahead + 1
   bool use_workers = false;
@@ -301,12 +302,14 @@ struct pcgmix_npdraw {
 
   void run(DrawEntry* e) {
     for (;;) {
-      // a hot loop posts a job every few ten microseconds: spin briefly before sleeping
+      // a hot loop posts a job every few ten microseconds: spin for a while before sleeping (a
+      // sleeping worker costs its wake-up, tens of microseconds and more under a hypervisor, right
+      // when a short timed region starts)
       const auto t0 = std::chrono::steady_clock::now();
       int spins = 0;
       while (e->job.load(std::memory_order_acquire) != 1 && !quit.load(std::memory_order_relaxed)) {
         if ((++spins & 63) ||
-            std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(60)) {
+            std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(kSpinUs)) {
           _mm_pause();
           continue;
         }
@@ -380,18 +383,7 @@ extern "C" int pcgmix_npdraw_step(pcgmix_npdraw* d, uint32_t seed, double alpha,
     const bool match = e->key == k;
     have = d->settle(e, !match) == 2 && match;
   }
-  if (have) {
-    ++d->hits;
-  } else {
-    e->key = k;
-    e->draw(k, nullptr);
-    ++d->misses;
-  }
-  if (np_state) std::memcpy(np_state, &e->end, sizeof(NpMt));
-  *lam = e->lam;
-  *knots = e->knots.data();
-  if (hit) *hit = have ? 1 : 0;
-  if (d->use_workers) {             // the next steps' blocks, while the caller works on this one
+  auto post_ahead = [&] {           // the next steps' blocks, while the caller works on this one
     bool posted = false;
     for (int a = 1; a < d->entries; ++a) {
       DrawKey nk = k;
@@ -410,7 +402,19 @@ extern "C" int pcgmix_npdraw_step(pcgmix_npdraw* d, uint32_t seed, double alpha,
       { std::lock_guard<std::mutex> lk(d->mu); }          // a worker is before its check or asleep
       d->cv.notify_all();
     }
+  };
+  if (d->use_workers) post_ahead();   // (before an inline draw: the workers start beside it)
+  if (have) {
+    ++d->hits;
+  } else {
+    e->key = k;
+    e->draw(k, nullptr);
+    ++d->misses;
   }
+  if (np_state) std::memcpy(np_state, &e->end, sizeof(NpMt));
+  *lam = e->lam;
+  *knots = e->knots.data();
+  if (hit) *hit = have ? 1 : 0;
   return 0;
 }
 
