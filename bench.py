@@ -892,8 +892,10 @@ def main():
             _, d1, t1, f1, _, w1 = make_device_batch(256, 1, 5000, rate, 0, device)
 
             def augment_leg(m, dd, tt, ff, ww):
-                dte, _ = run_augment_steps(m, dd, tt, ff, ww, device, a.steps, a.warmup, barrier)
-                return {"samples_per_s": 256 * a.steps / dte, "ms_per_step": 1e3 * dte / a.steps}
+                tr = {}
+                dte, _ = run_augment_steps(m, dd, tt, ff, ww, device, a.steps, a.warmup, barrier, trace=tr)
+                return {"samples_per_s": 256 * a.steps / dte, "ms_per_step": 1e3 * dte / a.steps,
+                        "call_trace": tr}
             for tag, m, (dd, tt, ff, ww) in (
                 ("augment_mix_256x1x5000", "durratiomixup", (d1, t1, f1, w1)),
                 ("augment_magwarp_256x1x5000", "durmixmagwarp(0.2,4)", (d1, t1, f1, w1)),

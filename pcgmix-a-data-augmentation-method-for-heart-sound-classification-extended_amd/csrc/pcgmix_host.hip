@@ -638,16 +638,29 @@ hipError_t slot_reserve(pcgmix_ctx* c, int i, size_t nbytes) {
     }
   }
   if (s.cap >= nbytes) return hipSuccess;
+  // A step needs more staging than this slot has: grow EVERY slot now.  One slot at a time put a
+  // hipHostMalloc + hipMalloc (~250 us) on each of the first eight calls of a larger shape — five
+  // of them inside a 5-step warm-up and three at the head of the timed region behind it (round 4:
+  // calls of 246 / 249 / 243 us, then 28 us, at the head of the durmixmagwarp (256,4,5000) leg).
+  // The other slots' device twins may still be read by launches in flight (a group's event is
+  // recorded at its last slot only), so the device is drained first; this happens once per shape.
   size_t cap = 8192;
   while (cap < nbytes) cap <<= 1;
-  if (s.pinned) (void)hipHostFree(s.pinned);
-  if (s.dev) (void)hipFree(s.dev);
-  s.pinned = s.dev = nullptr;
-  s.cap = 0;
-  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&s.pinned), cap, hipHostMallocDefault);
+  hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return e;
-  if ((e = hipMalloc(reinterpret_cast<void**>(&s.dev), cap)) != hipSuccess) return e;
-  s.cap = cap;
+  for (int j = 0; j < kSlots; ++j) {
+    Slot& t = c->slot[j];
+    t.busy = false;
+    if (t.cap >= cap) continue;
+    if (t.pinned) (void)hipHostFree(t.pinned);
+    if (t.dev) (void)hipFree(t.dev);
+    t.pinned = t.dev = nullptr;
+    t.cap = 0;
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&t.pinned), cap, hipHostMallocDefault)) != hipSuccess)
+      return e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&t.dev), cap)) != hipSuccess) return e;
+    t.cap = cap;
+  }
   return hipSuccess;
 }
 
