@@ -351,3 +351,48 @@ def test_draw_lambda_knots_with_a_foreign_bit_generator_falls_back_to_numpy():
     want = (np.random.beta(1.0, 1.0), np.random.normal(1.0, 0.2, 48))
     lam, knots = hostprep.draw_lambda_knots(3, 1.0, 0.2, 48)
     assert lam == want[0] and np.array_equal(hostprep.knots_array(knots, (48,)), want[1])
+
+
+def test_npdraw_cancels_wrong_guesses_and_survives_fork():
+    """The draw-ahead object guesses the next steps' keys (step + 1, + 2 with the same shape).  A
+    caller that jumps — another step, another shape, another alpha — makes it abandon the running
+    jobs (one polled flag per generator block) and draw inline; every result still equals numpy's.
+    A forked child has the object but not its threads: it must draw inline, not wait for them."""
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.pcgmix_npdraw_create(ctypes.byref(h), 3) == 0
+    lam, kp, hit = ctypes.c_double(), ctypes.c_void_p(), ctypes.c_int()
+
+    def draw(seed, alpha, sigma, n):
+        assert lib.pcgmix_npdraw_step(h, seed, alpha, sigma, n, None, ctypes.byref(lam), ctypes.byref(kp),
+                                      ctypes.byref(hit)) == 0
+        got = np.frombuffer((ctypes.c_double * n).from_address(kp.value), dtype=np.float64).copy() if n else None
+        np.random.seed(seed)
+        want_lam = np.random.beta(alpha, alpha)
+        want = np.random.normal(1.0, sigma, n) if n else None
+        assert lam.value == want_lam and (n == 0 or np.array_equal(got, want)), (seed, alpha, sigma, n)
+        return hit.value
+    rs = np.random.RandomState(2)
+    hits = 0
+    for i in range(60):                              # big blocks in flight, abandoned by the next call
+        hits += draw(int(rs.randint(0, 10 ** 6)), float(rs.choice([1.0, 0.5, 0.1])), 0.2,
+                     int(rs.choice([48, 6144, 200000, 2])))
+    for s in range(100, 130):                        # a regular sequence: everything but its head hits
+        hits += draw(s, 1.0, 0.2, 6144)
+    assert hits >= 27
+    # refused arguments leave the object usable
+    assert lib.pcgmix_npdraw_step(h, 1, 2.0, 0.2, 48, None, ctypes.byref(lam), ctypes.byref(kp), None) == 1
+    assert lib.pcgmix_npdraw_step(h, 1, 1.0, 0.2, 7, None, ctypes.byref(lam), ctypes.byref(kp), None) == 1
+    draw(5, 1.0, 0.2, 48)
+    pid = os.fork()
+    if pid == 0:                                     # child: no worker threads here
+        try:
+            for s in (131, 132, 7):
+                draw(s, 1.0, 0.2, 6144)
+            os._exit(0)
+        except BaseException:
+            os._exit(1)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+    draw(131, 1.0, 0.2, 6144)                        # the parent's workers are still there
+    lib.pcgmix_npdraw_destroy(h)
