@@ -747,7 +747,7 @@ void draw_partners(pcgmix_ctx* c, const int64_t* labels, int B, int64_t* mix_out
       const uint64_t j = rng.randbelow((uint64_t)(n - i));
       mix_out[c->idx[i]] = c->pool[j];
       if (mixp16) mixp16[c->idx[i]] = (int16_t)c->pool[j];
-      if (mixp) mixp[c->idx[i]] = (int32_t)c->pool[j];
+      else mixp[c->idx[i]] = (int32_t)c->pool[j];
       c->pool[j] = c->pool[n - i - 1];
     }
   }
@@ -1017,32 +1017,16 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   if (bad) return bad;                       // malformed boundaries: nothing else is enqueued
 
   // 4. partners: groups of equal label, each permuted by a fresh Random(step).sample
-  int16_t mix16[pcgmix::kPackB];
-  const bool small = knots && B <= pcgmix::kPackB && T <= 32767;
-  draw_partners(c, labels, B, mix_out, st + (size_t)B * 5, small ? mix16 : nullptr);
+  draw_partners(c, labels, B, mix_out, st + (size_t)B * 5);
   lap(4);
-  // 5. Small splice+warp batches (round 4): NO upload.  Boundaries and partners travel in the
-  //    launch's arguments (int16), and the kernel stages its sample's knots (and the step payload)
-  //    straight from this pinned slot — device-visible host memory, one 192-byte read per block —
-  //    instead of a fetch launch bringing 49 KB down in front of it (~4 us of the PCGmix+ step).
-  int err = pcgmix::kMixNoArgFrames;
-  if (small) {
-    int16_t fr16[pcgmix::kPackB * 5];
-    for (int i = 0; i < B * 5; ++i) fr16[i] = (int16_t)st[i];      // validated by pack_frames (bad == 0)
-    err = pcgmix::launch_mix_warp(x, y, nullptr, nullptr, nullptr, lam,
-                                  reinterpret_cast<const double*>(sl.pinned + n_int_pad * 4), op_dev,
-                                  n_knots, nullptr, B, C, T, s, sl.pinned + pay_off, c->payload_dst,
-                                  (int)(c->payload.size() / 16), nullptr, mix16, fr16);
-  }
-  if (err == pcgmix::kMixNoArgFrames) {
-    // one H2D copy, the launch, the slot's event behind it
-    if ((e = upload_slot(sl, nbytes, s)) != hipSuccess) return (int)e;
-    lap(5);
-    const int32_t* d = reinterpret_cast<const int32_t*>(sl.dev);
-    err = pcgmix::launch_mix_warp(x, y, d, d + (size_t)B * 5, nullptr, lam, knots_dev, op_dev,
-                                  knots ? n_knots : 0, nullptr, B, C, T, s, sl.dev + pay_off,
-                                  c->payload_dst, (int)(c->payload.size() / 16));
-  }
+  // 5. one H2D copy, the launch, the slot's event behind it
+  if ((e = upload_slot(sl, nbytes, s)) != hipSuccess) return (int)e;
+  lap(5);
+  const int32_t* d = reinterpret_cast<const int32_t*>(sl.dev);
+  const int err = pcgmix::launch_mix_warp(x, y, d, d + (size_t)B * 5, nullptr, lam, knots_dev, op_dev,
+                                          knots ? n_knots : 0, nullptr, B, C, T, s,
+                                          sl.dev + pay_off, c->payload_dst,
+                                          (int)(c->payload.size() / 16));
   if (err) return err;
   c->payload.clear();
   c->payload_dst = nullptr;

@@ -37,13 +37,7 @@ int launch_mix_warp(const float* x, float* y, const int32_t* frames, const int32
                     const int32_t* off, float lam, const double* knots, const double* spline_op,
                     int n_knots, const int32_t* zero_rect, int B, int C, int T, hipStream_t s,
                     const void* pay_src, void* pay_dst, int pay_n16,
-                    const float2* disp_part = nullptr, const int16_t* partners16 = nullptr,
-                    const int16_t* frames16 = nullptr);
-// frames16 (host, B x 5 int16; needs partners16, B <= kPackB, T <= 32767, no off / rectangles): the
-// boundaries travel in the launch's arguments too and `frames` may be null — with the knots read
-// from device-visible host memory the step then needs no upload at all.  Only the position-quad
-// splice+warp kernel has this form: any other variant returns kMixNoArgFrames and nothing is launched.
-constexpr int kMixNoArgFrames = -100;
+                    const float2* disp_part = nullptr, const int16_t* partners16 = nullptr);
 
 // pcgmix_mix.hip: the plain splice (no offsets, no warp, no rectangle) with its index block in
 // the kernel ARGUMENTS instead of device memory: frames (B,5) and partners (B) as int16 in host

@@ -37,10 +37,16 @@ struct StateMap {
 };
 
 // Boundaries of sample b and its partner -> blended ranges.  All inputs are block-uniform.
-__device__ __forceinline__ StateMap make_state_map_f(const int (&f1)[5], const int (&f2)[5],
-                                                     const int32_t* __restrict__ off, int b, int T,
-                                                     const float2* __restrict__ part) {
+__device__ __forceinline__ StateMap make_state_map(const int32_t* __restrict__ frames,
+                                                   const int32_t* __restrict__ off, int b, int m,
+                                                   int T, const float2* __restrict__ part = nullptr) {
   StateMap sm;
+  int f1[5], f2[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    f1[k] = frames[b * 5 + k];
+    f2[k] = frames[m * 5 + k];
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     int len1 = f1[k + 1] - f1[k];
@@ -77,38 +83,6 @@ __device__ __forceinline__ StateMap make_state_map_f(const int (&f1)[5], const i
     sm.delta[k] = s - a;
   }
   return sm;
-}
-
-__device__ __forceinline__ StateMap make_state_map(const int32_t* __restrict__ frames,
-                                                   const int32_t* __restrict__ off, int b, int m,
-                                                   int T, const float2* __restrict__ part = nullptr) {
-  int f1[5], f2[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    f1[k] = frames[b * 5 + k];
-    f2[k] = frames[m * 5 + k];
-  }
-  return make_state_map_f(f1, f2, off, b, T, part);
-}
-
-// Boundaries of up to kPackB samples as int16, BY VALUE in the kernel arguments (with the partners
-// in a PartnerPack: a splice+warp launch of a small batch then reads no index data from memory).
-struct FramesPack {
-  int32_t w[kPackB * 5 / 2];
-  int n;
-};
-__device__ __forceinline__ int frames_get(const FramesPack& p, int i) {
-  const int w = p.w[i >> 1];
-  return (i & 1) ? (w >> 16) : ((int)((unsigned)w << 16) >> 16);
-}
-__device__ __forceinline__ StateMap make_state_map(const FramesPack& fp, int b, int m, int T) {
-  int f1[5], f2[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    f1[k] = frames_get(fp, b * 5 + k);
-    f2[k] = frames_get(fp, m * 5 + k);
-  }
-  return make_state_map_f(f1, f2, nullptr, b, T, nullptr);
 }
 
 // Returns the partner-minus-own index shift for sample position t, or INT_MIN if t is not
@@ -356,7 +330,7 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
     const int32_t* __restrict__ mix_idx, const int32_t* __restrict__ off, float lam, float oml,
     const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots, int B, int C,
     int T, const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst, int pay_n16,
-    const float2* __restrict__ disp_part, const PartnerPack pk, const FramesPack fpk) {
+    const float2* __restrict__ disp_part, const PartnerPack pk) {
   extern __shared__ __align__(16) double lds[];  // C * (n_knots - 1) records, then thresholds
   if (pay_n16 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0)
     for (int i = threadIdx.x; i < pay_n16; i += kThreads) pay_dst[i] = pay_src[i];
@@ -364,7 +338,7 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
   if (b >= B) return;  // block-uniform
   int m = pk.n ? partner_get(pk, b) : mix_idx[b];
   m = (m < 0 || m >= B) ? b : m;
-  const StateMap sm = fpk.n ? make_state_map(fpk, b, m, T) : make_state_map(frames, off, b, m, T, disp_part);
+  const StateMap sm = make_state_map(frames, off, b, m, T, disp_part);
   const size_t own_base = (size_t)b * C * T, par_base = (size_t)m * C * T;
   const int rec_per_ch = (n_knots - 1) * kRec;
   int* thr = reinterpret_cast<int*>(lds + (size_t)C * rec_per_ch);
@@ -696,26 +670,16 @@ int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, con
                             const int32_t* off, float lam, const double* knots,
                             const double* spline_op, int n_knots, const int32_t* zero_rect, int B,
                             int C, int T, hipStream_t s, const void* pay_src_v, void* pay_dst_v,
-                            int pay_n16, const float2* disp_part, const int16_t* partners16,
-                            const int16_t* frames16) {
+                            int pay_n16, const float2* disp_part, const int16_t* partners16) {
   using namespace pcgmix;
   const uint4* pay_src = static_cast<const uint4*>(pay_src_v);
   uint4* pay_dst = static_cast<uint4*>(pay_dst_v);
-  FramesPack fpk;
-  fpk.n = 0;
-  if (frames16) {               // boundaries in the arguments: splice+warp (tq) launches only
-    if (!partners16 || B <= 0 || B > kPackB || T > 32767 || off || disp_part || zero_rect)
-      return hipErrorInvalidValue;
-    int16_t* f16 = reinterpret_cast<int16_t*>(fpk.w);
-    for (int i = 0; i < B * 5; ++i) f16[i] = frames16[i];
-    fpk.n = B;
-  }
   if (pay_n16 < 0 || (pay_n16 > 0 && (!pay_src || !pay_dst ||
                                       ((reinterpret_cast<uintptr_t>(pay_src) |
                                         reinterpret_cast<uintptr_t>(pay_dst)) & 15))))
     return hipErrorInvalidValue;
   const PartnerPack pk = make_partner_pack(partners16, B);
-  if (!x || !y || (!frames && !fpk.n) || (!mix_idx && !pk.n) || x == y) return hipErrorInvalidValue;
+  if (!x || !y || !frames || (!mix_idx && !pk.n) || x == y) return hipErrorInvalidValue;
   if (B < 0 || C <= 0 || T <= 0) return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
   const bool warp = knots != nullptr;
@@ -758,14 +722,13 @@ int pcgmix::launch_mix_warp(const float* x, float* y, const int32_t* frames, con
 #define PCGMIX_LAUNCH_TQ(CGV, UTV)                                                                  \
   hipLaunchKernelGGL((mix_warp_tq_kernel<CGV, UTV>), grid_tq, block, lds_tq, s, x, y, frames,        \
                      mix_idx, off, lam, oml, knots, spline_op, n_knots, B, C, T, pay_src, pay_dst,  \
-                     pay_n16, disp_part, pk, fpk)
+                     pay_n16, disp_part, pk)
     if (CG == 4) { if (UT == 2) PCGMIX_LAUNCH_TQ(4, 2); else PCGMIX_LAUNCH_TQ(4, 1); }
     else if (CG == 2) { if (UT == 2) PCGMIX_LAUNCH_TQ(2, 2); else PCGMIX_LAUNCH_TQ(2, 1); }
     else { if (UT == 2) PCGMIX_LAUNCH_TQ(1, 2); else PCGMIX_LAUNCH_TQ(1, 1); }
 #undef PCGMIX_LAUNCH_TQ
     return (int)hipGetLastError();
   }
-  if (fpk.n) return kMixNoArgFrames;     // only the position-quad kernel takes its boundaries by value
   if (vec4) {
     if (warp) PCGMIX_LAUNCH_U(true); else PCGMIX_LAUNCH_U(false);
   } else {
