@@ -184,7 +184,15 @@ def input_gradient_seeded(model: torch.nn.Module, data: torch.Tensor, seed: torc
     if m is not None:
         return _potes_input_gradient(m, data, seed)
     x = data.detach().requires_grad_(True)                 # shares storage; nothing writes to it
-    with torch.enable_grad():
+    # MIOpen's DETERMINISTIC algorithms for this frozen pass (ResNet9 saliency models): measured on
+    # the reference's recorded ResNet9-2D gradient (profiles/r4_sal2d_determinism.txt), the default
+    # selection is off by O(1) of the gradient's scale wherever the input is flat (the zero padding
+    # behind a cycle: ties in ReLU / max-pool routing, accumulation with atomics), 1e-6 .. 1e-3 inside
+    # the cycle, and moves from run to run; the deterministic selection is within 1e-6 of the
+    # reference's gradient everywhere and bit-reproducible.  The saliency maps follow: 4e-7 from the
+    # reference's instead of 3e-5 .. 2e-3.  (Training convolutions keep MIOpen's default choice.)
+    with torch.enable_grad(), torch.backends.cudnn.flags(enabled=True, benchmark=False,
+                                                         deterministic=True):
         out = model(x)
         (grad,) = torch.autograd.grad(out, x, seed)
     return grad.contiguous()
