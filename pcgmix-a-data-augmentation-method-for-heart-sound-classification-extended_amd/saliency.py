@@ -16,6 +16,7 @@ kernel, ``pcgmix_saliency_post_f32``.  Differences from the reference, all at th
 """
 from __future__ import annotations
 
+import contextlib
 import copy
 import ctypes
 import os
@@ -30,6 +31,7 @@ _INJECTED: Optional[torch.nn.Module] = None
 _LOADED: dict = {}          # checkpoint path -> (mtime, model)
 _GRAPHS: dict = {}          # (id(model), shape, classes, k) -> _SaliencyGraph
 USE_GRAPHS = True           # replay the frozen model's fwd+bwd+post-processing as one hipGraph
+DETERMINISTIC_FROZEN_PASS: Optional[bool] = None   # None: PCGMIX_SALIENCY_DETERMINISTIC decides (default off)
 CHAIN_EAGER = os.environ.get("PCGMIX_SAL_CHAIN_GRAPH") is None   # see _SaliencyGraph.__init__
 
 
@@ -184,15 +186,21 @@ def input_gradient_seeded(model: torch.nn.Module, data: torch.Tensor, seed: torc
     if m is not None:
         return _potes_input_gradient(m, data, seed)
     x = data.detach().requires_grad_(True)                 # shares storage; nothing writes to it
-    # MIOpen's DETERMINISTIC algorithms for this frozen pass (ResNet9 saliency models): measured on
-    # the reference's recorded ResNet9-2D gradient (profiles/r4_sal2d_determinism.txt), the default
-    # selection is off by O(1) of the gradient's scale wherever the input is flat (the zero padding
-    # behind a cycle: ties in ReLU / max-pool routing, accumulation with atomics), 1e-6 .. 1e-3 inside
-    # the cycle, and moves from run to run; the deterministic selection is within 1e-6 of the
-    # reference's gradient everywhere and bit-reproducible.  The saliency maps follow: 4e-7 from the
-    # reference's instead of 3e-5 .. 2e-3.  (Training convolutions keep MIOpen's default choice.)
-    with torch.enable_grad(), torch.backends.cudnn.flags(enabled=True, benchmark=False,
-                                                         deterministic=True):
+    # MIOpen's algorithm choice for this frozen pass (ResNet9 saliency models).  Default selection,
+    # as the reference runs it (it never asks cuDNN for determinism): measured on the reference's
+    # recorded ResNet9-2D gradient (profiles/r4_sal2d_determinism.txt) it is off by O(1) of the
+    # gradient's scale wherever the input is flat (the zero padding behind a cycle: ties in ReLU /
+    # max-pool routing, accumulation with atomics), 1e-6 .. 1e-3 inside the cycle, and moves from run
+    # to run -> maps 3e-5 .. 2e-3 from the reference's CPU maps.  The deterministic selection is
+    # within 1e-6 everywhere and bit-reproducible (maps 4e-7) but 40x (1D) / 77x (2D) slower at
+    # bs 256 (1427 vs 36 ms, 5970 vs 78 ms), so it is opt-in: PCGMIX_SALIENCY_DETERMINISTIC=1 or
+    # saliency.DETERMINISTIC_FROZEN_PASS = True (parity runs, the golden tests).
+    det = DETERMINISTIC_FROZEN_PASS
+    if det is None:
+        det = os.environ.get("PCGMIX_SALIENCY_DETERMINISTIC", "0") not in ("", "0")
+    algo = (torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True)
+            if det else contextlib.nullcontext())
+    with torch.enable_grad(), algo:
         out = model(x)
         (grad,) = torch.autograd.grad(out, x, seed)
     return grad.contiguous()
