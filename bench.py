@@ -509,6 +509,15 @@ def secondary_kernel_times(device, B=256, iters=50):
             timeit(lambda: saliency.optimal_displacements(sal, fr.data_ptr(), mix.data_ptr(), 0.37, mode, B, T,
                                                           max_len=int(np.diff(frames, axis=1).max()))),
             B * 8 * T)
+        # the same search with the host copies of the boundaries and partners handed over (the
+        # reference's situation: CPU arrays): blocks with candidates only, longest chain first
+        mix_np = np.random.RandomState(0).permutation(B).astype(np.int32)
+        fr_np = frames.astype(np.int32)
+        ml = int(np.diff(frames, axis=1).max())
+        out[f"salopt_disp_{name}_hosted_256x5000"] = entry(
+            timeit(lambda: saliency.optimal_displacements(sal, fr.data_ptr(), mix.data_ptr(), 0.37, mode, B, T,
+                                                          max_len=ml, frames_host=fr_np, mix_host=mix_np)),
+            B * 8 * T)
     spec, fs = frontend.logmel(x1, frames)
     tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)
     sc = StepCounter()

@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 14
+#define PCGMIX_ABI_VERSION 15
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -234,6 +234,17 @@ long long pcgmix_salopt_workspace_bytes(int B);
 int pcgmix_salopt_disp_f32(const float* sal, const int32_t* frames, const int32_t* mix_idx,
                            float lam, int mode, int32_t* disp, void* workspace, int max_len, int B,
                            int T, pcgmix_stream_t stream);
+/* The same search for a caller that ALSO holds the boundaries and the partners on the host — the
+ * reference's own situation: mixup_keepdur_multidim_tensors_salopt receives `frames` and the partner
+ * index as CPU arrays (augmentations.py:210-287).  frames_host (B,5) / mix_host (B): host copies of
+ * `frames` / `mix_idx` (same values: the device copies stay the ones the kernel reads).  With them
+ * (B <= 256) the launch holds only the blocks that have candidates, ordered by the length of their
+ * chain of sums, longest first, in the kernel arguments; either NULL: as pcgmix_salopt_disp_f32.
+ * Results are identical.                                                                        */
+int pcgmix_salopt_disp_hosted_f32(const float* sal, const int32_t* frames, const int32_t* mix_idx,
+                                  float lam, int mode, int32_t* disp, void* workspace, int max_len,
+                                  int B, int T, pcgmix_stream_t stream, const int32_t* frames_host,
+                                  const int32_t* mix_host);
 /* The saliency-guided splice — mixup_keepdur_multidim_tensors_salopt for the whole batch
  * (augmentations.py:210-287 with :60-128, the loop at :909-917, magnitude_warp :674-683) — in one
  * call: the search above, then pcgmix_mix_warp_f32's kernel, whose blocks reduce the search's

@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -45,6 +45,8 @@ SIGNATURES = {
     "pcgmix_salopt_workspace_bytes": (ctypes.c_longlong, [_c_int]),
     "pcgmix_salopt_disp_f32": (_c_int, [_ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _ptr, _c_int, _c_int,
                                         _c_int, _ptr]),
+    "pcgmix_salopt_disp_hosted_f32": (_c_int, [_ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _ptr, _c_int, _c_int,
+                                               _c_int, _ptr, _ptr, _ptr]),
     "pcgmix_salopt_mix_warp_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _ptr,
                                             _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_potes_head_saliency_f32": (_c_int, [_ptr] * 8 + [_c_int, _c_int, _c_int, _ptr]),

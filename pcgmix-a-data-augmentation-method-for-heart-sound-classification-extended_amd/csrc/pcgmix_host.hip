@@ -554,6 +554,8 @@ struct pcgmix_ctx {
   void* ws = nullptr;              // displacement-search workspace of the saliency-guided step
   size_t ws_cap = 0;
   int sal_B = 0, sal_max_len = 0;  // what pcgmix_ctx_salopt_begin saw
+  int32_t sal_frames_h[pcgmix::kPackB * 5];   // ... and the boundaries (B <= kPackB), for the search's plan
+  bool sal_frames_known = false;
 };
 
 // Host-to-device copy as a kernel launch (see fetch_kernel) for callers with their own pinned
@@ -1066,9 +1068,14 @@ extern "C" int pcgmix_ctx_salopt_begin(pcgmix_ctx* c, const int64_t* target_ohe_
         if (r[k + 1] - r[k] > longest) longest = r[k + 1] - r[k];
       }
       if (r[4] > T) bad16 = bad16 ? bad16 : -2;
-      for (int k = 0; k < 5; ++k) p16[b * 5 + k] = (int16_t)r[k];
+      for (int k = 0; k < 5; ++k) {
+        p16[b * 5 + k] = (int16_t)r[k];
+        c->sal_frames_h[b * 5 + k] = (int32_t)r[k];
+      }
     }
+    c->sal_frames_known = false;
     if (bad16) return bad16;
+    c->sal_frames_known = true;
     if ((e = labels_prepare(c, B, s)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(label_frames_kernel, dim3(1), dim3(256), 0, s, target_ohe_dev, num_classes, B,
                        c->lab, c->flag, c->token, seed_out, fp, frames_dst_dev);
@@ -1083,6 +1090,7 @@ extern "C" int pcgmix_ctx_salopt_begin(pcgmix_ctx* c, const int64_t* target_ohe_
   if ((e = slot_reserve(c, my_slot, (size_t)B * 20)) != hipSuccess) return (int)e;
   Slot& sl = c->slot[my_slot];
   int max_len = 0;
+  c->sal_frames_known = false;
   const int bad = pack_frames(frames, B, T, reinterpret_cast<int32_t*>(sl.pinned), &max_len);
   if (bad) return bad;
   if ((e = hipMemcpyAsync(frames_dst_dev, sl.pinned, (size_t)B * 20, hipMemcpyHostToDevice, s)) !=
@@ -1126,10 +1134,15 @@ extern "C" int pcgmix_ctx_salopt_begin_labels(pcgmix_ctx* c, const int64_t* labe
         if (r[k + 1] - r[k] > longest) longest = r[k + 1] - r[k];
       }
       if (r[4] > T) bad16 = bad16 ? bad16 : -2;
-      for (int k = 0; k < 5; ++k) p16[b * 5 + k] = (int16_t)r[k];
+      for (int k = 0; k < 5; ++k) {
+        p16[b * 5 + k] = (int16_t)r[k];
+        c->sal_frames_h[b * 5 + k] = (int32_t)r[k];
+      }
       p8[b] = (uint8_t)labels_host[b];
     }
+    c->sal_frames_known = false;
     if (bad16) return bad16;
+    c->sal_frames_known = true;
     int pay_n16 = 0;
     void* pay_dst = nullptr;
     if (!c->payload.empty() && c->payload.size() <= (size_t)pcgmix::kPackPayBytes) {
@@ -1153,6 +1166,7 @@ extern "C" int pcgmix_ctx_salopt_begin_labels(pcgmix_ctx* c, const int64_t* labe
   Slot& sl = c->slot[my_slot];
   int32_t* st = reinterpret_cast<int32_t*>(sl.pinned);
   int max_len = 0;
+  c->sal_frames_known = false;
   const int bad = pack_frames(frames, B, T, st, &max_len);
   if (bad) return bad;
   for (int b = 0; b < B; ++b) st[(size_t)B * 5 + b] = (int32_t)labels_host[b];
@@ -1230,10 +1244,17 @@ extern "C" int pcgmix_ctx_salopt_finish(pcgmix_ctx* c, const float* x, float* y,
       return (int)e;
     mix_dev = reinterpret_cast<const int32_t*>(sl.dev);
   }
+  // begin kept the boundaries (B <= kPackB): the search is launched as the list of its blocks that
+  // have candidates, longest chain first (plan_salopt_blocks) — host work beside the saliency pass
+  pcgmix::DispPlan plan;
+  plan.n = 0;
+  if (in_args && c->sal_frames_known && c->sal_B == B)
+    pcgmix::plan_salopt_blocks(c->sal_frames_h, nullptr, mix16, B, T, c->sal_max_len, &plan);
   int err = pcgmix::launch_salopt_search(sal, frames_dev, mix_dev, lam, mode, nullptr, c->ws,
                                          c->sal_B == B ? c->sal_max_len : 0, B, T, s,
                                          sl.pinned + n_mix_pad * 4, sl.dev + n_mix_pad * 4,
-                                         (int)(nk * sizeof(double) / 16), in_args ? mix16 : nullptr);
+                                         (int)(nk * sizeof(double) / 16), in_args ? mix16 : nullptr,
+                                         plan.n ? &plan : nullptr);
   if (err) return err;
   err = pcgmix::launch_mix_warp(x, y, frames_dev, mix_dev, nullptr, lam, knots_dev, op_dev,
                                 knots ? n_knots : 0, nullptr, B, C, T, s, nullptr, nullptr, 0,

@@ -77,10 +77,27 @@ int launch_mix_karg(const float* x, float* y, const int16_t* frames16, const int
 // the per-block results in `workspace` for launch_mix_warp's disp_part.
 // pay_*: pay_n16 16-byte words that one otherwise idle block copies from pay_src (device-readable
 // host memory) to pay_dst while the search runs.
+// plan != nullptr (plan->n > 0): the launch holds exactly the listed blocks, heaviest first
+// (plan_salopt_blocks), instead of the full (sample, slice, state) grid.
+constexpr int kDispPlanMax = 1408;   // with the PartnerPack still inside the 4 KB of kernel arguments
+struct DispPlan {
+  int n;                             // 0: no plan (natural grid)
+  uint16_t e[kDispPlanMax];          // (sample << 4) | (state << 2) | slice
+};
+struct DispNoPlan { int n; };
+// Host: the blocks of the search that have candidates — slice z of pair (b, k) holds the
+// displacements z*256 .. z*256+255, +1024, ... — ordered by the length of their chain of sums
+// (own state's length x passes), longest first, so that the dispatcher deals the long ones out
+// first and evenly; a pair without a search gets its slice 0 (which marks all four slices empty).
+// frames_h: (B,5) as the device copy; partners as int32 or int16 (one of them).  false: B too
+// large or more blocks than the plan holds — launch without a plan.
+bool plan_salopt_blocks(const int32_t* frames_h, const int32_t* mix_h, const int16_t* mix16, int B,
+                        int T, int max_len, DispPlan* out);
 int launch_salopt_search(const float* sal, const int32_t* frames, const int32_t* mix_idx, float lam,
                          int mode, int32_t* disp, void* workspace, int max_len, int B, int T,
                          hipStream_t s, const void* pay_src = nullptr, void* pay_dst = nullptr,
-                         int pay_n16 = 0, const int16_t* partners16 = nullptr);
+                         int pay_n16 = 0, const int16_t* partners16 = nullptr,
+                         const DispPlan* plan = nullptr);
 
 }  // namespace pcgmix
 #endif

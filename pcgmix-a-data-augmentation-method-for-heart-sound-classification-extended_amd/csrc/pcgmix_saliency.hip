@@ -10,6 +10,7 @@
 // so that a saliency-guided step needs no host round trip: the displacement table they produce is
 // consumed directly by pcgmix_mix_warp_f32 as its `off` argument.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 #include <stdint.h>
 
@@ -404,151 +405,6 @@ __device__ __forceinline__ float pw_sum(F elem, int n) {
   }
 }
 
-// ---- eight accumulator lanes per group of candidates (round 4) -----------------------------------
-// numpy's leaf sum keeps eight accumulators r[j] = a[j] + a[8+j] + a[16+j] + ... and folds them as
-// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)).  The MIDDLE sum of every candidate of a pair has the same
-// length (the shorter state), so its split tree — leaves, their order, the climbs — is the same for
-// all of them.  A group of eight lanes takes CG consecutive candidates d0 .. d0+CG-1; lane j owns
-// accumulator j of all of them: per step of 8 elements it reads l[d0 + i + j .. + CG-1] (ONE aligned
-// ds_read_b128 from copy j & 3 for CG = 4: the CG candidates' operands sit side by side) and the one
-// s[i + j] they share, and the fold is three DPP adds per candidate (lanes j^1, j^2, 7-j: float add
-// is commutative, so every lane ends with the same bits).  Against one lane per candidate: the LDS
-// floats per element-operation drop from 2 to (CG+1)/CG, a candidate's chain of dependent steps from
-// n to n*CG/8, and the tree bookkeeping is wave-uniform scalar code shared by all candidates.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-
-template <int MODE, int CG>     // MODE 0: max(l, s); 1: l + s on the pre-scaled segments
-struct GroupMid {
-  const float* lp;              // lng + (j&3)*cs + d0 + (j&~3):  lp[i + c] == l[d0 + c + i + j]
-  const float* sp;              // sht + j
-  const float* l0;              // lng + d0 (trailing elements: copy (e & 3))
-  const float* sht;
-  int cs;
-  __device__ __forceinline__ float op(float a, float b) const {
-    if (MODE == 0) {
-      float r;
-      asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // see SeqMid::op
-      return r;
-    }
-    return __fadd_rn(a, b);
-  }
-  static __device__ __forceinline__ void ld(const float* p, float (&a)[CG]) {
-    const f4al x = *reinterpret_cast<const f4al*>(p);
-    a[0] = x.x; a[1] = x.y; a[2] = x.z; a[3] = x.w;
-    if (CG == 8) {
-      const f4al y = *reinterpret_cast<const f4al*>(p + 4);
-      a[4] = y.x; a[5] = y.y; a[6] = y.z; a[7] = y.w;
-    }
-  }
-  __device__ __forceinline__ void leaf(int start, int n, float (&res)[CG]) const {
-    const int iend = start + (n & ~7);
-    if (n < 8) {
-#pragma unroll
-      for (int c = 0; c < CG; ++c) res[c] = 0.f;
-    } else {
-      float r[CG];
-      int i = start;
-      {
-        float a[CG];
-        ld(lp + i, a);
-        const float s = sp[i];
-#pragma unroll
-        for (int c = 0; c < CG; ++c) r[c] = op(a[c], s);
-        i += 8;
-      }
-      for (; i + 24 < iend; i += 32) {      // four steps' loads in flight per wait (cf. pw_leaf)
-        float a0[CG], a1[CG], a2[CG], a3[CG];
-        ld(lp + i, a0);
-        ld(lp + i + 8, a1);
-        ld(lp + i + 16, a2);
-        ld(lp + i + 24, a3);
-        const float s0 = sp[i], s1 = sp[i + 8], s2 = sp[i + 16], s3 = sp[i + 24];
-#pragma unroll
-        for (int c = 0; c < CG; ++c) r[c] = __fadd_rn(r[c], op(a0[c], s0));
-#pragma unroll
-        for (int c = 0; c < CG; ++c) r[c] = __fadd_rn(r[c], op(a1[c], s1));
-#pragma unroll
-        for (int c = 0; c < CG; ++c) r[c] = __fadd_rn(r[c], op(a2[c], s2));
-#pragma unroll
-        for (int c = 0; c < CG; ++c) r[c] = __fadd_rn(r[c], op(a3[c], s3));
-      }
-      for (; i < iend; i += 8) {
-        float a[CG];
-        ld(lp + i, a);
-        const float s = sp[i];
-#pragma unroll
-        for (int c = 0; c < CG; ++c) r[c] = __fadd_rn(r[c], op(a[c], s));
-      }
-#pragma unroll
-      for (int c = 0; c < CG; ++c) {
-        float v = r[c];
-        v = __fadd_rn(v, dpp_mov<0xB1>(v));     // quad_perm [1,0,3,2]: r0+r1 | r2+r3 | ...
-        v = __fadd_rn(v, dpp_mov<0x4E>(v));     // quad_perm [2,3,0,1]: (r0+r1)+(r2+r3) | ...
-        v = __fadd_rn(v, dpp_mov<0x141>(v));    // row_half_mirror: lane 7-j holds the other quad's sum
-        res[c] = v;
-      }
-    }
-    for (int e = iend; e < start + n; ++e) {    // numpy's trailing n % 8 elements, in order; every lane
-      float a[CG];                              // of the group adds the same values
-      ld(l0 + (e & 3) * cs + (e & ~3), a);
-      const float s = sht[e];
-#pragma unroll
-      for (int c = 0; c < CG; ++c) res[c] = __fadd_rn(res[c], op(a[c], s));
-    }
-  }
-};
-
-// pw_sum for CG sums with one common length: the walk is the one of pw_sum above, scalar and uniform.
-template <int DEPTH, int CG, class F>
-__device__ __forceinline__ void pw_sum_group(F f, int n, float (&out)[CG]) {
-  if (n <= 128) {
-    f.leaf(0, n, out);
-    return;
-  }
-  float acc[DEPTH][CG];
-#pragma unroll
-  for (int l = 0; l < DEPTH; ++l)
-#pragma unroll
-    for (int c = 0; c < CG; ++c) acc[l][c] = 0.f;
-  unsigned path = 0;
-  for (;;) {
-    int start = 0, len = n, depth = 0;
-#pragma unroll
-    for (int lvl = 0; lvl < DEPTH; ++lvl) {
-      if (len > 128) {
-        const int n2 = pw_split(len);
-        if ((path >> (DEPTH - 1 - lvl)) & 1u) { start += n2; len -= n2; } else { len = n2; }
-        depth = lvl + 1;
-      }
-    }
-    float v[CG];
-    f.leaf(start, len, v);
-    bool parked = false;
-#pragma unroll
-    for (int l = DEPTH; l >= 1; --l) {
-      if (l <= depth && !parked) {
-        if ((path >> (DEPTH - l)) & 1u) {
-#pragma unroll
-          for (int c = 0; c < CG; ++c) v[c] = __fadd_rn(acc[l - 1][c], v[c]);
-        } else {
-#pragma unroll
-          for (int c = 0; c < CG; ++c) acc[l - 1][c] = v[c];
-          parked = true;
-        }
-      }
-    }
-    if (!parked) {
-#pragma unroll
-      for (int c = 0; c < CG; ++c) out[c] = v[c];
-      return;
-    }
-    path += 1u << (DEPTH - depth);
-  }
-}
-
 // kDispSplit blocks of 256 threads per (state k, sample b): block z takes the candidates
 // d = 256 z + lane, + 1024, ...; a block without a candidate exits at once.  Round 1 ran ONE
 // 1024-thread block per pair with 2*T floats of LDS: two blocks per CU, and of their 32 waves
@@ -586,18 +442,28 @@ __device__ long long g_disp_clock[kDispClockBlocks * 8];
       g_disp_clock[lin_ * 8 + 7] = __builtin_amdgcn_s_getreg(0xF814);                               \
     }                                                                                               \
   } while (0)
+// shader clocks (s_memtime) across the scan, kept in the upper half of slot 7
+#define PCGMIX_DCLOCK_SH(var) const long long var = clock64()
+#define PCGMIX_DCLOCK_SH_END(var)                                                                   \
+  do {                                                                                              \
+    const unsigned lin_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;           \
+    if (threadIdx.x == 0 && lin_ < kDispClockBlocks)                                                \
+      g_disp_clock[lin_ * 8 + 7] |= (clock64() - var) << 8;                                         \
+  } while (0)
 #else
 #define PCGMIX_DCLOCK(i) do { } while (0)
 #define PCGMIX_DCLOCK_ID() do { } while (0)
+#define PCGMIX_DCLOCK_SH(var) do { } while (0)
+#define PCGMIX_DCLOCK_SH_END(var) do { } while (0)
 #endif
 
-// CG: 0 = one lane per candidate; 4 / 8 = eight accumulator lanes per CG candidates (COPIES only).
-template <int MODE, bool COPIES, int DEPTH, int CG = 0>  // MODE 0: envelope (max), 1: lambda-weighted sum
+// PLAN: the grid is the host's list of blocks (DispPlan, in the kernel arguments), heaviest first.
+template <int MODE, bool COPIES, int DEPTH, bool PLAN = false>  // MODE 0: envelope (max), 1: lambda-weighted sum
 __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
     const float* __restrict__ sal, const int32_t* __restrict__ frames,
     const int32_t* __restrict__ mix_idx, float lam, float oml, float2* __restrict__ part, int B,
     int T, int max_len, const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst,
-    int pay_n16, const PartnerPack pk) {
+    int pay_n16, const PartnerPack pk, const std::conditional_t<PLAN, DispPlan, DispNoPlan> plan) {
   extern __shared__ __align__(16) float smem[];
   PCGMIX_DCLOCK(0);
   PCGMIX_DCLOCK_ID();
@@ -606,7 +472,7 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   // device can read, e.g. the warp knots in the step context's pinned slot — to pay_dst.  The
   // splice kernel launched behind this one reads them from device memory; a hipMemcpyAsync of
   // this size (49 KB at bs 256) takes the SDMA path and stalls the stream for ~25 us.
-  if (pay_n16 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == 3)
+  if (pay_n16 && blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1 && blockIdx.z == gridDim.z - 1)
     for (int i = threadIdx.x; i < pay_n16; i += kDispThreads) pay_dst[i] = pay_src[i];
   __shared__ float best_v[kDispThreads / 64];
   __shared__ int best_d[kDispThreads / 64];
@@ -617,13 +483,24 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   // gridDim.x * 4 apart — a multiple of the CU count at the benchmark batch, i.e. the SAME CU,
   // whose LDS pipe the heaviest pair then saturates alone.  Rotating the sample index by a
   // z-dependent offset puts them on different CUs.
-  // (Round 4 tried handing the pairs over sorted by the length of one candidate's chain of sums —
-  // the own state's length —, heaviest first, in the kernel arguments: 35.3 us against 35.2 in this
-  // order, profiles/r4_disp_dispatch_order_null.txt.  The state-major order below is already a
-  // coarse longest-first and deals one long diastole block to every CU.)
-  const int z = blockIdx.y;   // launch order: sample, then slice, then state (see below)
-  const int b = (int)((blockIdx.x + (unsigned)z * (gridDim.x / kDispSplit + 3)) % gridDim.x);
-  const int k = (0x2013 >> (4 * blockIdx.z)) & 3;   // blockIdx.z 0,1,2,3 -> state 3,1,0,2
+  // (Round 4 first tried the PAIRS sorted by chain length with the slices still outermost: no gain,
+  // profiles/r4_disp_dispatch_order_null.txt — the per-block clock later showed why: what ends the
+  // launch are the slices z >= 1 of the long pairs, and they entered last in either order.)
+  // Launch order: sample, then slice, then state.  (Until round 4: sample, state, slice — the
+  // slices z >= 1 of the long diastole pairs, the blocks with the longest chains, then ENTERED
+  // 10-12 us into the launch, behind 2048 other blocks at ~60 dispatcher cycles each:
+  // profiles/r4_disp_phase_clock.txt.)
+  int z, b, k;
+  if constexpr (PLAN) {
+    const unsigned id = plan.e[blockIdx.x];
+    b = (int)(id >> 4);
+    k = (int)(id >> 2) & 3;
+    z = (int)id & 3;
+  } else {
+    z = blockIdx.y;
+    b = (int)((blockIdx.x + (unsigned)z * (gridDim.x / kDispSplit + 3)) % gridDim.x);
+    k = (0x2013 >> (4 * blockIdx.z)) & 3;   // blockIdx.z 0,1,2,3 -> state 3,1,0,2
+  }
   float2* out = part + ((size_t)b * 4 + k) * kDispSplit + z;
   int m = pk.n ? partner_get(pk, b) : mix_idx[b];
   m = (m < 0 || m >= B) ? b : m;
@@ -638,9 +515,12 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   const int n1 = e1 - a1, n2 = e2 - a2;
   const bool own_longer = n1 > n2;
   const int nL = own_longer ? n1 : n2, nS = own_longer ? n2 : n1;
-  static_assert(CG == 0 || (COPIES && (CG == 4 || CG == 8)), "group mode needs the shifted copies");
-  constexpr int kCandPerWave = CG ? 8 * CG : 64, kCandPerBlock = kCandPerWave * (kDispThreads / 64);
-  if (n1 == n2 || z * kCandPerBlock > nL - nS) {  // no search (:226-229) / no candidate for this block
+  if (PLAN && (n1 == n2 || (z + 1) * kDispThreads > nL - nS)) {
+    // the plan lists only slices with candidates: the last of them marks the rest of its pair empty
+    if ((int)threadIdx.x > z && threadIdx.x < kDispSplit)
+      out[(int)threadIdx.x - z] = float2{-INFINITY, __int_as_float(0x7fffffff)};
+  }
+  if (n1 == n2 || z * kDispThreads > nL - nS) {  // no search (:226-229) / no candidate for this block
     if (threadIdx.x == 0) *out = float2{-INFINITY, __int_as_float(0x7fffffff)};
     PCGMIX_DCLOCK(5);
     return;
@@ -695,48 +575,10 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
   }
   __syncthreads();
   PCGMIX_DCLOCK(2);
+  PCGMIX_DCLOCK_SH(sh0_);
 
   float bv = -INFINITY;
   int bd = 0x7fffffff;
-  if constexpr (CG > 0) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 7, g = lane >> 3;
-    // A ds_read_b128 is served 16 lanes = two groups at a time: their candidate bases must be 8
-    // apart for the 16 windows (copy j&3 at 16 (mod 64) floats, 4 floats each) to cover all banks once.
-    const int wb = CG == 4 ? 8 * (g & 3) + 4 * (g >> 2) : 8 * g;
-    const int Dm = nL - nS;                                   // last candidate
-    const int c = j % CG, job = j / CG;                       // CG = 4: lanes 0-3 head, 4-7 tail
-    for (int base = z * kCandPerBlock + wv * kCandPerWave; base <= Dm; base += kDispSplit * kCandPerBlock) {
-      int d0 = base + wb;
-      const int d = d0 + c;
-      const bool valid = d <= Dm;
-      d0 = d0 <= Dm ? d0 : (Dm & ~(CG - 1));                  // idle groups stay inside the copies
-      float mid[CG];
-      pw_sum_group<DEPTH, CG>(GroupMid<MODE, CG>{lng + (j & 3) * cs + d0 + (j & ~3), sht + j, lng + d0, sht, cs},
-                              nS, mid);
-      float cur = mid[0];
-#pragma unroll
-      for (int q = 1; q < CG; ++q) cur = c == q ? mid[q] : cur;
-      if (own_longer) {  // np.sum(s1[:d]) + np.sum(mid) + np.sum(s1[d+n2:])   (:76-78, :111-113)
-        const int t0 = d + nS;
-        constexpr bool kAl = !kPrescale;                      // mode 1: `raw` has no shifted copies
-        const float* hp = raw;
-        const float* tp = kPrescale ? raw + t0 : lng + (t0 & 3) * cs + (t0 & ~3);
-        if (CG == 8) {
-          const float head = pw_sum<DEPTH>(SeqPlain<kAl>{hp}, valid ? d : 0);
-          const float tail = pw_sum<DEPTH>(SeqPlain<kAl>{tp}, valid ? Dm - d : 0);
-          cur = __fadd_rn(__fadd_rn(head, cur), tail);
-        } else {  // one lane sums the head of candidate c, its neighbour four lanes up the tail
-          const float part_sum = pw_sum<DEPTH>(SeqPlain<kAl>{job ? tp : hp}, valid ? (job ? Dm - d : d) : 0);
-          const float tail = __shfl_down(part_sum, 4, 8);
-          cur = __fadd_rn(__fadd_rn(part_sum, cur), tail);
-        }
-      }
-      if (valid && job == 0 && cur > bv) {  // ascending d per lane: strict '>' keeps the first maximum
-        bv = cur;
-        bd = d;
-      }
-    }
-  } else {
   for (int d = z * kDispThreads + threadIdx.x; d <= nL - nS; d += kDispSplit * kDispThreads) {
     const float* win = COPIES ? lng + (d & 3) * cs + (d & ~3) : lng + d;
     float cur;
@@ -756,8 +598,8 @@ __global__ __launch_bounds__(kDispThreads) void salopt_disp_kernel(
       bd = d;
     }
   }
-  }
   PCGMIX_DCLOCK(3);       // thread 0's wave is done with its candidates
+  PCGMIX_DCLOCK_SH_END(sh0_);
   // arg-max across the block; ties go to the smallest d (= first strict maximum of the scan)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -912,11 +754,97 @@ extern "C" int pcgmix_salopt_mix_warp_f32(const float* x, float* y, const float*
   return (int)hipGetLastError();
 }
 
+namespace pcgmix {
+template <int MODE, bool COPIES, int DEPTH, bool PLAN>
+static int launch_disp_variant(unsigned long long* lds_ok, dim3 grid, dim3 block, size_t lds, hipStream_t s,
+                               const float* sal, const int32_t* frames, const int32_t* mix_idx, float lam,
+                               float oml, float2* part, int B, int T, int max_len, const uint4* pay_src,
+                               uint4* pay_dst, int pay_n16, const PartnerPack& pk, const DispPlan* plan) {
+  auto kern = salopt_disp_kernel<MODE, COPIES, DEPTH, PLAN>;
+  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(kern), lds_ok, 150 * 1024)) return (int)e;
+  if constexpr (PLAN)
+    hipLaunchKernelGGL(kern, grid, block, lds, s, sal, frames, mix_idx, lam, oml, part, B, T, max_len, pay_src,
+                       pay_dst, pay_n16, pk, *plan);
+  else
+    hipLaunchKernelGGL(kern, grid, block, lds, s, sal, frames, mix_idx, lam, oml, part, B, T, max_len, pay_src,
+                       pay_dst, pay_n16, pk, DispNoPlan{0});
+  return 0;
+}
+}  // namespace pcgmix
+
+bool pcgmix::plan_salopt_blocks(const int32_t* frames_h, const int32_t* mix_h, const int16_t* mix16,
+                                int B, int T, int max_len, DispPlan* out) {
+  out->n = 0;
+  if (!frames_h || (!mix_h && !mix16) || B <= 0 || B > kPackB || T <= 0) return false;
+  if (max_len <= 0 || max_len > T) max_len = T;
+  auto len = [&](int b, int k) {     // the kernel's clamps
+    int a = frames_h[b * 5 + k], e = frames_h[b * 5 + k + 1];
+    a = a < 0 ? 0 : (a > T ? T : a);
+    e = e < a ? a : (e > T ? T : e);
+    const int n = e - a;
+    return n > max_len ? max_len : n;
+  };
+  // counting sort by chain length (own state's length x passes of the busiest lane) in steps of 16
+  constexpr int kBuckets = 512;
+  uint16_t cnt[kBuckets + 1] = {};
+  uint16_t key[kPackB * 16];
+  uint16_t ids[kPackB * 16];
+  int n = 0;
+  for (int b = 0; b < B; ++b) {
+    int m = mix16 ? (int)mix16[b] : mix_h[b];
+    m = (m < 0 || m >= B) ? b : m;
+    for (int k = 0; k < 4; ++k) {
+      const int n1 = len(b, k), n2 = len(m, k);
+      const int dm = n1 > n2 ? n1 - n2 : n2 - n1;             // last candidate
+      const unsigned base = ((unsigned)b << 4) | ((unsigned)k << 2);
+      if (dm == 0) {
+        key[n] = 0;
+        ids[n++] = (uint16_t)base;
+        continue;
+      }
+      for (int z = 0; z < kDispSplit && z * kDispThreads <= dm; ++z) {
+        const int passes = (dm - z * kDispThreads) / (kDispSplit * kDispThreads) + 1;
+        int c = (n1 * passes) >> 4;
+        key[n] = (uint16_t)(c >= kBuckets ? kBuckets - 1 : c);
+        ids[n++] = (uint16_t)(base | (unsigned)z);
+      }
+    }
+  }
+  if (n > kDispPlanMax) return false;
+  for (int i = 0; i < n; ++i) ++cnt[kBuckets - 1 - key[i]];  // descending
+  int pos = 0;
+  for (int i = 0; i < kBuckets; ++i) {
+    const int c = cnt[i];
+    cnt[i] = (uint16_t)pos;
+    pos += c;
+  }
+  for (int i = 0; i < n; ++i) out->e[cnt[kBuckets - 1 - key[i]]++] = ids[i];
+  out->n = n;
+  return true;
+}
+
+// pcgmix_salopt_disp_f32 for a caller that also holds the boundaries and the partners on the HOST
+// (the reference's own situation: augmentations.py:210-287 receives them as CPU arrays): the
+// launch then consists of the blocks that have candidates, longest chain first.
+extern "C" int pcgmix_salopt_disp_hosted_f32(const float* sal, const int32_t* frames,
+                                             const int32_t* mix_idx, float lam, int mode,
+                                             int32_t* disp, void* workspace, int max_len, int B, int T,
+                                             pcgmix_stream_t stream, const int32_t* frames_host,
+                                             const int32_t* mix_host) {
+  if (!disp) return hipErrorInvalidValue;
+  pcgmix::DispPlan plan;
+  plan.n = 0;
+  if (frames_host && mix_host) pcgmix::plan_salopt_blocks(frames_host, mix_host, nullptr, B, T, max_len, &plan);
+  return pcgmix::launch_salopt_search(sal, frames, mix_idx, lam, mode, disp, workspace, max_len, B, T,
+                                      reinterpret_cast<hipStream_t>(stream), nullptr, nullptr, 0, nullptr,
+                                      plan.n ? &plan : nullptr);
+}
+
 // disp == nullptr: the per-block results stay in `workspace` (no finalize launch).
 int pcgmix::launch_salopt_search(const float* sal, const int32_t* frames, const int32_t* mix_idx,
                                  float lam, int mode, int32_t* disp, void* workspace, int max_len,
                                  int B, int T, hipStream_t s, const void* pay_src_v, void* pay_dst_v,
-                                 int pay_n16, const int16_t* partners16) {
+                                 int pay_n16, const int16_t* partners16, const DispPlan* plan) {
   using namespace pcgmix;
   const PartnerPack pk = make_partner_pack(partners16, B);
 
@@ -937,37 +865,29 @@ int pcgmix::launch_salopt_search(const float* sal, const int32_t* frames, const 
   const bool copies = lds <= 96 * 1024;              // longer segments: one copy, unaligned windows
   if (!copies) lds = sizeof(float) * 2 * seg;
   if (lds > 150 * 1024) return hipErrorInvalidValue;
-  // group mode (eight accumulator lanes per CG candidates) whenever the shifted copies fit
-  static const int cg_env = [] {
-    const char* e = getenv("PCGMIX_DISP_CG");
-    return e ? atoi(e) : 4;
-  }();
-  const int cg = copies ? cg_env : 0;
   const bool shallow = max_len <= kPwShallowN;
-  using Kern = void (*)(const float*, const int32_t*, const int32_t*, float, float, float2*, int, int, int,
-                        const uint4*, uint4*, int, const PartnerPack);
-  struct Entry { Kern k; unsigned long long ok; };
-  static Entry table[2][4][2] = {   // [mode][variant: no copies, copies, CG 4, CG 8][deep]
-      {{{salopt_disp_kernel<0, false, 4>, 0}, {salopt_disp_kernel<0, false, 8>, 0}},
-       {{salopt_disp_kernel<0, true, 4>, 0}, {salopt_disp_kernel<0, true, 8>, 0}},
-       {{salopt_disp_kernel<0, true, 4, 4>, 0}, {salopt_disp_kernel<0, true, 8, 4>, 0}},
-       {{salopt_disp_kernel<0, true, 4, 8>, 0}, {salopt_disp_kernel<0, true, 8, 8>, 0}}},
-      {{{salopt_disp_kernel<1, false, 4>, 0}, {salopt_disp_kernel<1, false, 8>, 0}},
-       {{salopt_disp_kernel<1, true, 4>, 0}, {salopt_disp_kernel<1, true, 8>, 0}},
-       {{salopt_disp_kernel<1, true, 4, 4>, 0}, {salopt_disp_kernel<1, true, 8, 4>, 0}},
-       {{salopt_disp_kernel<1, true, 4, 8>, 0}, {salopt_disp_kernel<1, true, 8, 8>, 0}}}};
-  Entry& ent = table[mode][!copies ? 0 : cg == 4 ? 2 : cg == 8 ? 3 : 1][shallow ? 0 : 1];
-  static const size_t lds_min = [] {           // experiment: fewer resident blocks per CU
-    const char* e = getenv("PCGMIX_DISP_LDS_MIN");
-    return e ? (size_t)atoi(e) : (size_t)0;
-  }();
-  if (lds < lds_min) lds = lds_min;
-  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(ent.k), &ent.ok, 150 * 1024)) return (int)e;
+  const bool planned = plan && plan->n > 0 && plan->n <= kDispPlanMax;
   const float oml = 1.0f - lam;
-  dim3 grid((unsigned)B, kDispSplit, 4), block(kDispThreads);
   float2* part = static_cast<float2*>(workspace);
-  hipLaunchKernelGGL(ent.k, grid, block, lds, s, sal, frames, mix_idx, lam, oml, part, B, T, max_len, pay_src,
-                     pay_dst, pay_n16, pk);
+  const dim3 block(kDispThreads);
+  const dim3 grid = planned ? dim3((unsigned)plan->n, 1, 1) : dim3((unsigned)B, kDispSplit, 4);
+  static unsigned long long lds_ok[16] = {};
+#define PCGMIX_DISP(M, CP, DP, PL, SLOT)                                                               \
+  do {                                                                                               \
+    if (int e_ = launch_disp_variant<M, CP, DP, PL>(&lds_ok[SLOT], grid, block, lds, s, sal, frames, mix_idx, \
+                                                    lam, oml, part, B, T, max_len, pay_src, pay_dst, \
+                                                    pay_n16, pk, plan))                              \
+      return e_;                                                                                     \
+  } while (0)
+#define PCGMIX_DISP_P(M, CP, DP, SLOT) \
+  do { if (planned) PCGMIX_DISP(M, CP, DP, true, SLOT + 8); else PCGMIX_DISP(M, CP, DP, false, SLOT); } while (0)
+#define PCGMIX_DISP_D(M, CP, SLOT) \
+  do { if (shallow) PCGMIX_DISP_P(M, CP, 4, SLOT); else PCGMIX_DISP_P(M, CP, 8, SLOT + 1); } while (0)
+  if (mode == 0) { if (copies) PCGMIX_DISP_D(0, true, 0); else PCGMIX_DISP_D(0, false, 2); }
+  else { if (copies) PCGMIX_DISP_D(1, true, 4); else PCGMIX_DISP_D(1, false, 6); }
+#undef PCGMIX_DISP_D
+#undef PCGMIX_DISP_P
+#undef PCGMIX_DISP
   if (disp)
     hipLaunchKernelGGL(salopt_finalize_kernel, dim3((unsigned)((B * 4 + 255) / 256)), dim3(256), 0, s,
                        part, disp, B * 4);

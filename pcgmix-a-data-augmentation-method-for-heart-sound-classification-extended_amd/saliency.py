@@ -386,10 +386,15 @@ def get_saliency_maps(args, device, data, target_ohe, frames, dim=1, gauss_k_n=1
 
 
 def optimal_displacements(saliency_maps: torch.Tensor, frames_dev_ptr: int, mix_dev_ptr: int,
-                          lam: float, mode: int, B: int, T: int, max_len: int = 0) -> torch.Tensor:
+                          lam: float, mode: int, B: int, T: int, max_len: int = 0,
+                          frames_host: Optional[np.ndarray] = None,
+                          mix_host: Optional[np.ndarray] = None) -> torch.Tensor:
     """Displacement of the shorter state inside the longer one for every (sample, state):
     int32 (B,4) on device (augmentations.py:60-128 via pcgmix_salopt_disp_f32).  ``max_len``: the
-    longest heart state of the batch in samples (from the host copy of ``frames``); 0 = unknown."""
+    longest heart state of the batch in samples (from the host copy of ``frames``); 0 = unknown.
+    ``frames_host`` (B,5) / ``mix_host`` (B): the host copies of the two index arrays (the reference
+    holds them as CPU arrays anyway) — with both the launch is planned on the host
+    (pcgmix_salopt_disp_hosted_f32: only blocks with candidates, longest chain first)."""
     if saliency_maps.shape != (B, T) or saliency_maps.dtype != torch.float32 \
             or not saliency_maps.is_contiguous() or not saliency_maps.is_cuda:
         raise ValueError("saliency maps must be a contiguous float32 (B, T) device tensor")
@@ -398,6 +403,18 @@ def optimal_displacements(saliency_maps: torch.Tensor, frames_dev_ptr: int, mix_
     ws = torch.empty(max(1, lib.pcgmix_salopt_workspace_bytes(B) // 8), dtype=torch.int64,
                      device=saliency_maps.device)
     stream = torch.cuda.current_stream(saliency_maps.device).cuda_stream
+    if frames_host is not None and mix_host is not None:
+        fh = np.ascontiguousarray(frames_host, dtype=np.int32)
+        mh = np.ascontiguousarray(mix_host, dtype=np.int32)
+        if fh.shape != (B, 5) or mh.shape != (B,):
+            raise ValueError("frames_host must be (B,5) and mix_host (B,)")
+        if max_len <= 0:
+            max_len = int(np.diff(fh, axis=1).max())
+        _lib.check(lib.pcgmix_salopt_disp_hosted_f32(
+            saliency_maps.data_ptr(), frames_dev_ptr, mix_dev_ptr, ctypes.c_float(lam), mode,
+            disp.data_ptr(), ws.data_ptr(), int(max_len), B, T, ctypes.c_void_p(stream),
+            fh.ctypes.data, mh.ctypes.data), "pcgmix_salopt_disp_hosted_f32")
+        return disp
     _lib.check(lib.pcgmix_salopt_disp_f32(saliency_maps.data_ptr(), frames_dev_ptr, mix_dev_ptr,
                                           ctypes.c_float(lam), mode, disp.data_ptr(), ws.data_ptr(),
                                           int(max_len), B, T, ctypes.c_void_p(stream)),

@@ -280,6 +280,49 @@ def test_graphed_saliency_equals_eager(device):
         saliency.set_saliency_model(None)
 
 
+def _index_batch(kind, B, T, rs):
+    """(frames, mix) for the planned-launch tests: 'bench' = the benchmark's synthetic cycles,
+    'equal' = every pair has equal state lengths (no search anywhere), 'wide' = gaps beyond 768
+    samples in every state pair (more blocks than a plan holds at B = 256)."""
+    from pcgmix_amd import synthetic
+    if kind == "bench":
+        frames = synthetic.make_index_data(B, T, sample_rate=2000, seed=3)[0]
+    elif kind == "equal":
+        frames = np.tile(np.array([0, 300, 1100, 1400, 2800]), (B, 1))
+    else:
+        a = np.array([0, 100, 200, 300, 400])
+        w = np.array([0, 1000, 2000, 3000, 4000])
+        frames = np.where((np.arange(B) % 2 == 0)[:, None], a, w)
+    mix = rs.permutation(B) if kind != "wide" else (np.arange(B) ^ 1)
+    return frames.astype(np.int64), mix.astype(np.int32)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("kind,B", [("bench", 256), ("bench", 37), ("equal", 64), ("wide", 256), ("wide", 64),
+                                    ("bench", 1), ("bench", 300)])
+def test_planned_search_equals_the_full_grid(kind, B, mode, device):
+    """pcgmix_salopt_disp_hosted_f32 (host copies of boundaries and partners: the launch is the
+    list of blocks with candidates, longest chain first) == pcgmix_salopt_disp_f32, bit for bit;
+    B = 300 and the 'wide' batch at B = 256 (4096 blocks > kDispPlanMax) fall back to the grid."""
+    T = 5000
+    rs = np.random.RandomState(11 + B)
+    frames, mix = _index_batch(kind, B, T, rs)
+    sal = torch.from_numpy(rs.rand(B, T).astype(np.float32)).to(device)
+    fr, mx = dev_i32(frames, device), dev_i32(mix, device)
+    ref = saliency.optimal_displacements(sal, fr.data_ptr(), mx.data_ptr(), 0.37, mode, B, T)
+    for ml in (0, int(np.diff(frames, axis=1).max())):
+        got = saliency.optimal_displacements(sal, fr.data_ptr(), mx.data_ptr(), 0.37, mode, B, T, max_len=ml,
+                                             frames_host=frames, mix_host=mix)
+        assert torch.equal(got, ref)
+    if kind == "bench" and B == 37:       # and against the oracle
+        lam_np = np.full((1, 1), 0.37, dtype=np.float32)
+        method = "(saloptenv)" if mode == 0 else "(saloptsum)"
+        s = sal.cpu().numpy()
+        want = np.stack([O.salopt_displacements(s[i], s[mix[i]], frames[i], frames[mix[i]], lam_np, method)
+                         for i in range(B)])
+        assert np.array_equal(got.cpu().numpy().astype(np.int64), want)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_displacements_long_gaps_vs_oracle(mode, device):
     """Length gaps beyond one pass of the candidate split (> 1024 candidates per state) and gaps
