@@ -497,8 +497,12 @@ def secondary_kernel_times(device, B=256, iters=50):
                       "measured_issue_rate_peak": 32.0,
                       "frac_of_measured_rate": lm_flop / lm["us"] / 1e6 / 32.0,
                       "flop_per_launch": lm_flop,
+                      "executed_flop_per_launch": B * 2 * (2.0 * 64 * 36 * 160),
                       "note": "peak = data-sheet FP64 matrix rate; the instruction's measured issue rate on "
-                              "this part is 32 TFLOP/s (profiles/probes/mfma_f64_rate.hip)"}
+                              "this part is 32 TFLOP/s (profiles/probes/mfma_f64_rate.hip).  flop_per_launch "
+                              "keeps rounds 1-3's definition (real-input fold, K = 68); since round 4 the "
+                              "kernel EXECUTES executed_flop_per_launch: even and odd bins as separate "
+                              "products with K = 36 (second fold, DESIGN.md §3.4) + 5 bins on the f64 VALU"}
     grad = torch.randn_like(data)
     out["saliency_post_256x4x5000"] = entry(timeit(lambda: saliency.saliency_post(grad, fr.data_ptr())),
                                             B * (4 * C * T + 4 * T))

@@ -295,6 +295,13 @@ int pcgmix_logmel_tables(int n_fft, int n_mels, float fmin, float fmax, float sr
 int pcgmix_logmel_f32(const float* x, const int32_t* frames, const void* tables, float* spec,
                       int32_t* frames_out, int B, int T, int n_fft, int hop, int n_mels,
                       float mean, float std, int W, int pad_mode, pcgmix_stream_t stream);
+/* The same for a caller that holds the boundaries on the host (as the reference does: numpy
+ * arrays, databuilder.ipynb cell 6:101): frames_host (B,5) int32 HOST memory.  B <= 1024 and
+ * T <= 32767: the cycle ends travel in the kernel arguments — no upload, no copy kernel in front
+ * of the launch; otherwise hipErrorInvalidValue (upload, then pcgmix_logmel_f32).               */
+int pcgmix_logmel_hostframes_f32(const float* x, const int32_t* frames_host, const void* tables,
+                                 float* spec, int B, int T, int n_fft, int hop, int n_mels,
+                                 float mean, float std, int W, int pad_mode, pcgmix_stream_t stream);
 
 /* Per-recording front end.  All pointers device.  The column bookkeeping (which is integer work
  * on a handful of numbers per cycle: n_frames = 1 + len/hop, Python round()) is the caller's; the

@@ -50,6 +50,8 @@ SIGNATURES = {
     "pcgmix_salopt_mix_warp_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _ptr,
                                             _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_potes_head_saliency_f32": (_c_int, [_ptr] * 8 + [_c_int, _c_int, _c_int, _ptr]),
+    "pcgmix_logmel_hostframes_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                              _c_float, _c_float, _c_int, _c_int, _ptr]),
     "pcgmix_logmel_tables_size": (ctypes.c_longlong, [_c_int, _c_int]),
     "pcgmix_logmel_tables": (_c_int, [_c_int, _c_int, _c_float, _c_float, _c_float, _ptr]),
     "pcgmix_logmel_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,

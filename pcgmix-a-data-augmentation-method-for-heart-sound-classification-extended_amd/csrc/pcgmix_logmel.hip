@@ -16,11 +16,20 @@
 //
 // The STFT is a GEMM and librosa evaluates it in float64 — so it runs on the f64 matrix cores
 // (v_mfma_f64_16x16x4_f64).  The input is real and the periodic Hann window is symmetric
-// (win[N-k] = win[k], win[0] = 0), so with k = 1..N/2
-//     re[bin][frame] = sum_k  win[k] cos(2 pi bin k / N) * (x[f*hop + k] + x[f*hop + N - k])
-//     im[bin][frame] = sum_k -win[k] sin(2 pi bin k / N) * (x[f*hop + k] - x[f*hop + N - k])
-// (the k = N/2 term carries weight 1/2 because its partner is itself): two GEMMs with M = bins,
-// N = frames and K = N/2 instead of one with K = N — half the matrix-core work.
+// (win[N-n] = win[n], win[0] = 0): with a[n] = x[n] + x[N-n], d[n] = x[n] - x[N-n] (exact in
+// float64), H = N/2,
+//     re[bin] = sum_{n=1..H}   g_n win[n] cos(2 pi bin n / N) a[n]        (g_H = 1/2, else 1)
+//     im[bin] = sum_{n=1..H-1}    -win[n] sin(2 pi bin n / N) d[n]
+// — K = N/2 instead of N (rounds 1-3).  Round 4 folds once more.  With the window applied on the
+// DATA side, u[n] = win[n] a[n], v[n] = win[n] d[n], the coefficient matrices are pure twiddles, and
+// n_fft = 4 hop makes H even: cos(theta(bin, H-n)) = s cos(theta(bin, n)), sin(theta(bin, H-n)) =
+// -s sin(theta(bin, n)) with s = (-1)^bin.  With Q = H/2 = hop:
+//     re[bin] =  sum_{n=0..Q} c_n cos(2 pi bin n / N) (u[n] + s u[H-n])    (c_0 = c_Q = 1/2, else 1)
+//     im[bin] = -sum_{n=0..Q} c_n sin(2 pi bin n / N) (v[n] - s v[H-n])
+// (the n = 0 column carries the old n = H term: u[0] = 0).  Even and odd bins are separate GEMMs
+// with K = Q + 1 = 35 instead of 68: 9 k-steps instead of 17, half the matrix instructions again —
+// the f64 matrix pipe (150 cycles per instruction and SIMD) is what bounds this kernel
+// (profiles/r4_logmel_phases.txt).  Tile mt holds the bins 2 (16 (mt >> 1) + row) + (mt & 1).
 // Everything that does not depend on the data (the windowed twiddle matrices already in MFMA
 // A-fragment order, the mel filter bank, each filter's non-zero span) is a constant table built
 // once on the host (pcgmix_logmel_tables) and read through L2.  One block per sample; LDS holds the reflect-padded row, the power spectrogram and
@@ -31,6 +40,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "pcgmix_kernels.h"
@@ -44,32 +54,39 @@ constexpr int kNGroup = 2;  // 16-frame tiles per work unit of a wave (re + im a
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // ---- constant tables (host-built blob) ---------------------------------------------------------
-//   [0]            double afrag[m_tiles][ksteps][2][64]   A operands (re, im), one double per lane:
-//                  lane l -> bin = 16*mt + (l & 15), k = 4*ks + (l >> 4) + 1  (k = 1 .. n_fft/2)
-//                  re:  win[k] * cos(2 pi bin k / n_fft) * (k == n_fft/2 ? 0.5 : 1)
-//                  im: -win[k] * sin(2 pi bin k / n_fft);   0 for padded bins / k > n_fft/2
+//   [0]            double afrag[m_mfma][ksteps][2][64]    A operands (re, im), one double per lane:
+//                  lane l -> row = l & 15, n = 4*ks + (l >> 4)  (n = 0 .. Q; beyond: 0),
+//                  bin = 2 (16 (mt >> 1) + row) + (mt & 1)
+//                  re:  c_n cos(2 pi bin n / n_fft);   im: -c_n sin(2 pi bin n / n_fft)
 //   [off_wts]      float  wts[n_mels][n_bins]             librosa.filters.mel, slaney, float32
 //   [off_krange]   int32  krange[n_mels][2]               first / last non-zero bin
-//   [off_left]     double left[n_left][n_fft/2][2]        (re, im) coefficients of the bins beyond
-//                  the last FULL 16-bin tile, k = 1 .. n_fft/2: those few rows (5 of 69 at
-//                  n_fft = 136) run on the float64 VALU instead of costing a whole matrix tile
-// m_tiles counts the 16-row tiles the power spectrogram has room for; m_mfma of them go through
-// the matrix cores (round 4: the f64 matrix instruction issues every ~150 cycles per SIMD, the
-// phase was 476 of them on the busiest SIMD — profiles/r4_logmel_sq_counters.json —, and a fifth
-// tile holding five real bins was a fifth of that).
+//   [off_left]     double left[n_left][n_fft/2][2]        (re, im) coefficients (window included,
+//                  single fold) of the bins beyond the last full PAIR of 16-bin tiles,
+//                  n = 1 .. n_fft/2: those few rows (5 of 69 at n_fft = 136: bins 64..68) run on the
+//                  float64 VALU instead of costing two more matrix tiles
+//   [off_win]      double win[n_fft/2 + 1]                periodic Hann
+// m_tiles counts the 16-row tiles the power spectrogram has room for; m_mfma = 2 * tpp of them (tpp
+// tile pairs: even bins, odd bins) go through the matrix cores.
 struct MelTables {
   int m_tiles, m_mfma, n_left, ksteps, n_bins;
-  size_t off_wts, off_krange, off_left, total;
+  size_t off_wts, off_krange, off_left, off_win, total;
 };
 __host__ __device__ inline MelTables mel_tables(int n_fft, int n_mels) {
   MelTables t;
   t.n_bins = n_fft / 2 + 1;
-  t.m_tiles = (t.n_bins + 15) / 16;
-  const int rem = t.n_bins % 16;
-  t.n_left = (rem > 0 && rem <= 8 && t.n_bins > 16) ? rem : 0;
-  t.m_mfma = t.n_left ? t.n_bins / 16 : t.m_tiles;
-  t.ksteps = (n_fft / 2 + 3) / 4;
-  size_t o = (size_t)t.m_tiles * t.ksteps * 2 * 64 * sizeof(double);
+  int tpp = t.n_bins / 32;
+  const int rem = t.n_bins - 32 * tpp;
+  if (tpp >= 1 && rem <= 8) {
+    t.n_left = rem;
+  } else {
+    tpp = (t.n_bins + 31) / 32;
+    t.n_left = 0;
+  }
+  t.m_mfma = 2 * tpp;
+  const int need_tiles = (t.n_bins + 15) / 16;
+  t.m_tiles = t.m_mfma > need_tiles ? t.m_mfma : need_tiles;
+  t.ksteps = (n_fft / 4 + 1 + 3) / 4;               // columns n = 0 .. n_fft/4
+  size_t o = (size_t)t.m_mfma * t.ksteps * 2 * 64 * sizeof(double);
   t.off_wts = o;
   o += (size_t)n_mels * t.n_bins * sizeof(float);
   o = (o + 7) & ~(size_t)7;
@@ -78,12 +95,14 @@ __host__ __device__ inline MelTables mel_tables(int n_fft, int n_mels) {
   o = (o + 7) & ~(size_t)7;
   t.off_left = o;
   o += (size_t)t.n_left * (n_fft / 2) * 2 * sizeof(double);
+  t.off_win = o;
+  o += (size_t)(n_fft / 2 + 1) * sizeof(double);
   t.total = (o + 15) & ~(size_t)15;
   return t;
 }
 
 struct MelLayout {  // byte offsets into dynamic LDS
-  int xrow, ps, img, melw, left, total;
+  int xrow, ps, img, melw, left, win, total;
   int nfp, xr;
 };
 // n_frames = frames one block transforms: 1 + T/hop of a heart-cycle item, or the tile size of
@@ -101,6 +120,7 @@ __host__ __device__ inline MelLayout mel_layout(int n_frames, int n_fft, int hop
   L.img = o;  o += (image ? n_mels * W : 0) * 4;  // dB image                            (float)
   L.melw = o; o += n_mels * 8 * 4;              // per band: klo, khi, 4 weights (+2 pad) (32 B)
   L.left = o; o += tb.n_left * (n_fft / 2) * 2 * 8;   // coefficients of the VALU bins       (double)
+  L.win = o;  o += (n_fft / 2 + 1) * 8;         // periodic Hann, n = 0 .. n_fft/2          (double)
   L.total = o;
   return L;
 }
@@ -115,6 +135,15 @@ __device__ __forceinline__ float power_db(float p) {
 }
 
 constexpr int kPadConstant = 0, kPadReflect = 1;
+// End of every cycle (frames[b][4]) as int16 in the kernel ARGUMENTS (pcgmix_logmel_hostframes_f32):
+// the only boundary the per-cycle kernel needs when the caller converts the others itself — no
+// upload, no copy kernel in front of the launch.  n == 0: not in use, the kernel reads `frames`.
+constexpr int kMelEndsMax = 1024;
+struct MelEnds {
+  int n;
+  int16_t v[kMelEndsMax];
+};
+struct MelNoEnds { int n; };
 constexpr int kTileFrames = 128;   // frames per block of the per-recording pass
 
 // RECORD = false: one block per heart-cycle item b of x (B, T); image to `spec`.
@@ -123,34 +152,39 @@ constexpr int kTileFrames = 128;   // frames per block of the per-recording pass
 //                 columns to the scratch `spec` (n_mels, scratch_cols), the tile's maximum mel
 //                 power folded into ref_pow[recording] (non-negative floats order like their bit
 //                 patterns, so an unsigned atomicMax is a float max).
-// KS > 0: the number of k-steps is the compile-time constant KS (17 at n_fft = 136; 9 <= KS <= 24)
-// and a wave keeps a ring of eight A fragments in registers (slot = k-step mod 8, 32 VGPRs): at step
-// ks it consumes slot ks % 8 and refills it with step ks + 8 of the same unit or, once that is past
-// the end, with step ks % 8 of the wave's NEXT unit — eight k-steps of distance throughout, also
-// across units.  KS == 0: any n_fft, one k-step of prefetch.  Round 4 (profiles/r4_logmel_phases.txt, wall_clock64 around the phases of
+// KS > 0: the number of k-steps is the compile-time constant KS (9 at n_fft = 136) and a wave keeps a
+// ring of kRing A fragments in registers (slot = k-step mod kRing): at step ks it consumes slot
+// ks % kRing and refills it with step ks + kRing of the same unit or, once that is past the end,
+// with step ks % kRing of the wave's NEXT unit — kRing k-steps of distance throughout, also across
+// units.  KS == 0: any n_fft, one k-step of prefetch.  Round 4 (profiles/r4_logmel_phases.txt, wall_clock64 around the phases of
 // one block): the matrix phase was 22-23 us of a 35 us block whether it held 476 or 340 matrix
 // instructions on its busiest SIMD — every k-step waited for its fragment's L2 round trip
 // (~650 ns, prefetch distance one k-step), 34 of them in a row on the waves with two units.
-// Probe builds only (-DPCGMIX_PHASE_CLOCK, profiles/probes/logmel_phase_clock.py): block 7 of the
-// per-cycle launch leaves wall_clock64 (100 MHz) at its phase boundaries in g_logmel_clock.
+// Probe builds only (-DPCGMIX_PHASE_CLOCK, profiles/probes/logmel_phase_clock.py): every block of the
+// per-cycle launch leaves wall_clock64 (100 MHz) at its phase boundaries (+ XCC_ID, HW_ID) in g_logmel_clock.
 #ifdef PCGMIX_PHASE_CLOCK
-__device__ long long g_logmel_clock[8];
+constexpr int kMelClockBlocks = 1024;
+__device__ long long g_logmel_clock[kMelClockBlocks * 8];
 #define PCGMIX_CLOCK(i)                                                          \
   do {                                                                           \
-    if (!RECORD && blockIdx.x == 7 && threadIdx.x == 0) g_logmel_clock[i] = wall_clock64(); \
+    if (!RECORD && blockIdx.x < kMelClockBlocks && threadIdx.x == 0) {           \
+      g_logmel_clock[blockIdx.x * 8 + (i)] = wall_clock64();                     \
+      if ((i) == 0) g_logmel_clock[blockIdx.x * 8 + 5] =                         \
+          ((long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | __builtin_amdgcn_s_getreg(0xF804); \
+    }                                                                            \
   } while (0)
 #else
 #define PCGMIX_CLOCK(i) do { } while (0)
 #endif
 
-template <bool RECORD, int KS>
+template <bool RECORD, int KS, bool ENDS = false>
 __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ frames,
     const long long* __restrict__ rec_off, const int32_t* __restrict__ rec_len,
     const int4* __restrict__ tiles, const unsigned char* __restrict__ tables,
     float* __restrict__ spec, unsigned* __restrict__ ref_pow, long long scratch_cols,
     int32_t* __restrict__ frames_out, int B, int T, int n_fft, int hop, int n_mels, float mean,
-    float stdv, int W, int pad_mode) {
+    float stdv, int W, int pad_mode, const std::conditional_t<ENDS, MelEnds, MelNoEnds> ends) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ float red[kMelWaves];
   const MelTables tb = mel_tables(n_fft, n_mels);
@@ -185,9 +219,12 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   float* img = reinterpret_cast<float*>(smem + L.img);
   float* melw = reinterpret_cast<float*>(smem + L.melw);
   double* leftc = reinterpret_cast<double*>(smem + L.left);
+  double* winl = reinterpret_cast<double*>(smem + L.win);
   {
     const double* lg = reinterpret_cast<const double*>(tables + tb.off_left);
     for (int i = tid; i < tb.n_left * (n_fft / 2) * 2; i += kMelThreads) leftc[i] = lg[i];
+    const double* wg = reinterpret_cast<const double*>(tables + tb.off_win);
+    for (int i = tid; i <= n_fft / 2; i += kMelThreads) winl[i] = wg[i];
   }
 
   // per-band filter span and its first 4 weights -> LDS (global latency overlaps the row copy)
@@ -273,11 +310,41 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   // 8 units on it either way).  Round r >= 1 hands unit 16 r + j to wave 5 j mod 16 — 0, 5, 10, 15,
   // 4, 9, ... — which spreads any prefix over both plausible mappings (wave mod 4 and wave / 4).
   auto unit_of = [&](int r) { return r == 0 ? wave : 16 * r + ((13 * wave) & 15); };
-  double fr_re[8], fr_im[8];                         // KS > 0: the fragment ring
+  // B operands of k-step ks for the frames 16*(kNGroup*ng + i) + col: column n = 4*ks + kq of the
+  // doubly folded transform (header): bs = u[n] + s u[H-n], bd = v[n] - s v[H-n] with
+  // u = win * (lo + hi), v = win * (lo - hi), s = sgn = +1 for an even-bin tile, -1 for an odd one.
+  // Columns beyond Q are padding (zero coefficients): they read column 0.  Column 0 pairs x[0]
+  // with itself (win[0] = 0 makes it vanish; x[N] is not part of the frame).
+  const int half = n_fft / 2, quarter = n_fft / 4;
+  auto b_operands = [&](int ks, int ng, double sgn, double (&bs)[kNGroup], double (&bd)[kNGroup]) {
+    int n = 4 * ks + kq;
+    // only the last k-step can hold padding columns and only the first one column 0: with ks a
+    // constant of the unrolled loop the other steps' addresses stay base + immediate
+    if (KS == 0 || ks == KS - 1) n = n > quarter ? 0 : n;
+    const int m = half - n;
+    const double wn = winl[n], wm = winl[m];
+    const int hi_n = ((KS == 0 || ks == 0 || ks == KS - 1) && n == 0) ? 0 : n_fft - n;
+#pragma unroll
+    for (int i = 0; i < kNGroup; ++i) {
+      const float* xf = xrow + (16 * (kNGroup * ng + i) + col) * hop;
+      const double lo = (double)xf[n], hi = (double)xf[hi_n];
+      const double lo2 = (double)xf[m], hi2 = (double)xf[half + n];
+      const double u = wn * (lo + hi), u2 = wm * (lo2 + hi2);      // the sums are exact in float64
+      const double v = wn * (lo - hi), v2 = wm * (lo2 - hi2);
+      bs[i] = __builtin_fma(sgn, u2, u);
+      bd[i] = __builtin_fma(-sgn, v2, v);
+    }
+  };
+  // KS > 0: the fragment ring.  Four slots at KS = 9 (a k-step is 4 matrix instructions = 600+ cycles
+  // of the SIMD's matrix pipe, which four or five waves share: four steps ahead covers the ~650 ns
+  // L2 round trip; eight slots spilled at the 128-VGPR budget of a 1024-thread block).
+  constexpr int kRing = KS >= 16 ? 8 : 4;
+  static_assert(KS == 0 || KS > kRing, "the ring must be shorter than a unit");
+  double fr_re[kRing], fr_im[kRing];
   if (KS > 0 && wave < n_units) {
     const double* ap0 = afrag + (size_t)(wave / n_groups) * KS * 128 + lane;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < kRing; ++ks) {
       fr_re[ks] = ap0[(size_t)ks * 128];
       fr_im[ks] = ap0[(size_t)ks * 128 + 64];
     }
@@ -288,36 +355,32 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
 #pragma unroll
     for (int i = 0; i < kNGroup; ++i) are[i] = aim[i] = d4{0.0, 0.0, 0.0, 0.0};
     const double* ap = afrag + (size_t)mt * tb.ksteps * 128 + lane;   // [ks][re|im][64]
-    // B operands: x[f*hop + k] +- x[f*hop + n_fft - k], frame f = 16*(kNGroup*ng + i) + col
-    const float* xlo = xrow + (16 * kNGroup * ng + col) * hop + kq + 1;
-    const float* xhi = xrow + (16 * kNGroup * ng + col) * hop + n_fft - kq - 1;
+    const double sgn = (mt & 1) ? -1.0 : 1.0;                          // (-1)^bin of this tile's bins
     if (KS > 0) {
       const int nxt = unit_of(round + 1);
       const bool more = nxt < n_units;                // wave-uniform
       const double* apn = afrag + (size_t)((more ? nxt : unit) / n_groups) * KS * 128 + lane;
 #pragma unroll
       for (int ks = 0; ks < (KS > 0 ? KS : 1); ++ks) {
-        const double cr = fr_re[ks & 7], ci = fr_im[ks & 7];
-        if (ks + 8 < KS) {                           // eight steps ahead in this unit
-          fr_re[ks & 7] = ap[(size_t)(ks + 8) * 128];
-          fr_im[ks & 7] = ap[(size_t)(ks + 8) * 128 + 64];
-        } else if (more && KS - ks <= 8) {           // ... or the next unit's step ks % 8
-          fr_re[ks & 7] = apn[(size_t)(ks & 7) * 128];
-          fr_im[ks & 7] = apn[(size_t)(ks & 7) * 128 + 64];
+        constexpr int kM = kRing - 1;
+        const double cr = fr_re[ks & kM], ci = fr_im[ks & kM];
+        if (ks + kRing < KS) {                       // kRing steps ahead in this unit
+          fr_re[ks & kM] = ap[(size_t)(ks + kRing) * 128];
+          fr_im[ks & kM] = ap[(size_t)(ks + kRing) * 128 + 64];
+        } else if (more && KS - ks <= kRing) {       // ... or the next unit's step ks % kRing
+          fr_re[ks & kM] = apn[(size_t)(ks & kM) * 128];
+          fr_im[ks & kM] = apn[(size_t)(ks & kM) * 128 + 64];
         }
         double bs[kNGroup], bd[kNGroup];
-#pragma unroll
-        for (int i = 0; i < kNGroup; ++i) {
-          const double lo = (double)xlo[(16 * i) * hop + 4 * ks];
-          const double hi = (double)xhi[(16 * i) * hop - 4 * ks];
-          bs[i] = lo + hi;                           // exact in float64
-          bd[i] = lo - hi;
-        }
+        b_operands(ks, ng, sgn, bs, bd);
 #pragma unroll
         for (int i = 0; i < kNGroup; ++i) {
           are[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(cr, bs[i], are[i], 0, 0, 0);
           aim[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(ci, bd[i], aim[i], 0, 0, 0);
         }
+        // keep the scheduler from hoisting several steps' operand loads above this step's matrix
+        // instructions (the fully unrolled loop spilled at 128 VGPRs without it)
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       double a_re = ap[0], a_im = ap[64];
@@ -328,13 +391,7 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
           a_im = ap[(size_t)(ks + 1) * 128 + 64];
         }
         double bs[kNGroup], bd[kNGroup];
-#pragma unroll
-        for (int i = 0; i < kNGroup; ++i) {
-          const double lo = (double)xlo[(16 * i) * hop + 4 * ks];
-          const double hi = (double)xhi[(16 * i) * hop - 4 * ks];
-          bs[i] = lo + hi;                           // exact in float64
-          bd[i] = lo - hi;
-        }
+        b_operands(ks, ng, sgn, bs, bd);
 #pragma unroll
         for (int i = 0; i < kNGroup; ++i) {
           are[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(cr, bs[i], are[i], 0, 0, 0);
@@ -349,7 +406,7 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
       for (int rr = 0; rr < 4; ++rr) {
         const float fr = (float)are[i][rr], fi = (float)aim[i][rr];  // complex64
         const float mag = hypotf(fr, fi);                             // np.abs
-        ps[(16 * mt + kq + 4 * rr) * L.nfp + fcol] = mag * mag;       // ** 2
+        ps[(2 * (16 * (mt >> 1) + kq + 4 * rr) + (mt & 1)) * L.nfp + fcol] = mag * mag;   // ** 2
       }
     }
   }
@@ -413,12 +470,14 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   int col_end = W;
   {
     // round(f * n_frames / len(y)) with Python's round-half-even (databuilder.ipynb cell 6:101)
-    const int f4 = frames[b * 5 + 4];
+    int f4;
+    if constexpr (ENDS) f4 = ends.v[b];
+    else f4 = frames[b * 5 + 4];
     const double v = (double)((long long)f4 * n_frames) / (double)T;
     const int c4 = (int)rint(v);
     col_end = c4 < 0 ? 0 : (c4 > W ? W : c4);
     if (col_end > n_frames) col_end = n_frames;
-    if (frames_out && tid < 5) {
+    if (!ENDS && frames_out && tid < 5) {
       const double vv = (double)((long long)frames[b * 5 + tid] * n_frames) / (double)T;
       frames_out[b * 5 + tid] = (int)rint(vv);
     }
@@ -521,20 +580,21 @@ static double mel_to_hz(double m) {
 }  // namespace pcgmix
 
 #ifdef PCGMIX_PHASE_CLOCK
-extern "C" int pcgmix_logmel_phase_clock(long long* out5) {
-  return (int)hipMemcpyFromSymbol(out5, HIP_SYMBOL(pcgmix::g_logmel_clock), 5 * sizeof(long long));
+extern "C" int pcgmix_logmel_phase_clock(long long* out, int n_blocks) {
+  if (n_blocks > pcgmix::kMelClockBlocks) return hipErrorInvalidValue;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcgmix::g_logmel_clock), (size_t)n_blocks * 8 * sizeof(long long));
 }
 #endif
 
 extern "C" long long pcgmix_logmel_tables_size(int n_fft, int n_mels) {
-  if (n_fft < 2 || (n_fft & 1) || n_mels < 1) return 0;
+  if (n_fft < 4 || (n_fft & 3) || n_mels < 1) return 0;
   return (long long)pcgmix::mel_tables(n_fft, n_mels).total;
 }
 
 extern "C" int pcgmix_logmel_tables(int n_fft, int n_mels, float fmin, float fmax, float sr,
                                     void* out) {
   using namespace pcgmix;
-  if (!out || n_fft < 2 || (n_fft & 1) || n_mels < 1 || !(fmax > fmin) || !(sr > 0))
+  if (!out || n_fft < 4 || (n_fft & 3) || n_mels < 1 || !(fmax > fmin) || !(sr > 0))
     return hipErrorInvalidValue;
   const MelTables tb = mel_tables(n_fft, n_mels);
   unsigned char* base = static_cast<unsigned char*>(out);
@@ -547,22 +607,26 @@ extern "C" int pcgmix_logmel_tables(int n_fft, int n_mels, float fmin, float fma
     win[j] = 0.5 - 0.5 * cs[j];
   }
   double* afrag = reinterpret_cast<double*>(base);
-  const int nh = n_fft / 2;
-  for (int mt = 0; mt < tb.m_tiles; ++mt)
+  const int nh = n_fft / 2, nq = n_fft / 4;
+  for (int mt = 0; mt < tb.m_mfma; ++mt)
     for (int ks = 0; ks < tb.ksteps; ++ks)
       for (int l = 0; l < 64; ++l) {
-        const int bin = 16 * mt + (l & 15), k = 4 * ks + (l >> 4) + 1;
+        const int bin = 2 * (16 * (mt >> 1) + (l & 15)) + (mt & 1), n = 4 * ks + (l >> 4);
         double vr = 0.0, vi = 0.0;
-        if (bin < tb.n_bins && k <= nh) {
-          const int idx = (int)(((long long)bin * k) % n_fft);
-          vr = win[k % n_fft] * cs[idx] * (k == nh ? 0.5 : 1.0);
-          vi = -win[k % n_fft] * sn[idx];
-          if (k == nh) vi = 0.0;                     // its partner is itself: x[k] - x[N-k] == 0
+        if (bin < tb.n_bins && n <= nq) {
+          const int idx = (int)(((long long)bin * n) % n_fft);
+          const double c = (n == 0 || n == nq) ? 0.5 : 1.0;
+          vr = c * cs[idx];
+          vi = -c * sn[idx];
         }
         double* dst = afrag + ((size_t)mt * tb.ksteps + ks) * 128;
         dst[l] = vr;
         dst[64 + l] = vi;
       }
+  {
+    double* wt = reinterpret_cast<double*>(base + tb.off_win);
+    for (int n = 0; n <= nh; ++n) wt[n] = win[n];
+  }
   {
     double* left = reinterpret_cast<double*>(base + tb.off_left);
     for (int lb = 0; lb < tb.n_left; ++lb)
@@ -602,37 +666,73 @@ extern "C" int pcgmix_logmel_tables(int n_fft, int n_mels, float fmin, float fma
   return hipSuccess;
 }
 
+namespace pcgmix {
+// The per-cycle launch; ends != nullptr: the cycle ends travel in the kernel arguments.
+static int launch_logmel_cycles(const float* x, const int32_t* frames, const MelEnds* ends, const void* tables,
+                                float* spec, int32_t* frames_out, int B, int T, int n_fft, int hop,
+                                int n_mels, float mean, float std, int W, int pad_mode, hipStream_t s) {
+  const MelLayout L = mel_layout(1 + T / hop, n_fft, hop, n_mels, W);
+  if (L.total > 158 * 1024) return hipErrorInvalidValue;
+  static unsigned long long lds_ok[4] = {0, 0, 0, 0};
+  const bool ks9 = mel_tables(n_fft, n_mels).ksteps == 9;      // the reference's n_fft = 136
+  const unsigned char* tb = static_cast<const unsigned char*>(tables);
+#define PCGMIX_MEL(KSV, EN, SLOT, ENDARG)                                                              \
+  do {                                                                                               \
+    auto kern = logmel_kernel<false, KSV, EN>;                                                       \
+    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(kern), &lds_ok[SLOT], 158 * 1024)) \
+      return (int)e;                                                                                 \
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kMelThreads), (size_t)L.total, s, x, frames, nullptr, \
+                       nullptr, nullptr, tb, spec, nullptr, 0LL, frames_out, B, T, n_fft, hop, n_mels, mean, \
+                       std, W, pad_mode, ENDARG);                                                    \
+  } while (0)
+  if (ends) {
+    if (ks9) PCGMIX_MEL(9, true, 2, *ends); else PCGMIX_MEL(0, true, 3, *ends);
+  } else {
+    if (ks9) PCGMIX_MEL(9, false, 0, MelNoEnds{0}); else PCGMIX_MEL(0, false, 1, MelNoEnds{0});
+  }
+#undef PCGMIX_MEL
+  return (int)hipGetLastError();
+}
+}  // namespace pcgmix
+
 extern "C" int pcgmix_logmel_f32(const float* x, const int32_t* frames, const void* tables,
                                  float* spec, int32_t* frames_out, int B, int T, int n_fft,
                                  int hop, int n_mels, float mean, float std, int W, int pad_mode,
                                  pcgmix_stream_t stream) {
   using namespace pcgmix;
   if (!x || !frames || !tables || !spec) return hipErrorInvalidValue;
-  if (B < 0 || T < 2 || n_fft < 2 || (n_fft & 1) || hop < 1 || n_mels < 1 || W < 1 ||
+  if (B < 0 || T < 2 || n_fft < 4 || (n_fft & 3) || hop < 1 || n_mels < 1 || W < 1 ||
       !(std != 0.f) || n_fft / 2 >= T || (pad_mode != kPadConstant && pad_mode != kPadReflect))
     return hipErrorInvalidValue;
   if (B == 0) return hipSuccess;
-  const MelLayout L = mel_layout(1 + T / hop, n_fft, hop, n_mels, W);
-  if (L.total > 158 * 1024) return hipErrorInvalidValue;
-  static unsigned long long lds_ok = 0, lds_ok17 = 0;
-  if (mel_tables(n_fft, n_mels).ksteps == 17) {      // the reference's n_fft = 136
-    if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(logmel_kernel<false, 17>),
-                                       &lds_ok17, 158 * 1024))
-      return (int)e;
-    hipLaunchKernelGGL((logmel_kernel<false, 17>), dim3((unsigned)B), dim3(kMelThreads),
-                       (size_t)L.total, reinterpret_cast<hipStream_t>(stream), x, frames, nullptr,
-                       nullptr, nullptr, static_cast<const unsigned char*>(tables), spec, nullptr, 0LL,
-                       frames_out, B, T, n_fft, hop, n_mels, mean, std, W, pad_mode);
-    return (int)hipGetLastError();
+  return launch_logmel_cycles(x, frames, nullptr, tables, spec, frames_out, B, T, n_fft, hop, n_mels, mean,
+                              std, W, pad_mode, reinterpret_cast<hipStream_t>(stream));
+}
+
+// pcgmix_logmel_f32 for a caller that holds the boundaries on the HOST (the reference cuts its
+// spectrograms from numpy arrays, databuilder.ipynb cell 6:101): frames_host (B,5) int32 in host
+// memory.  Up to 1024 items and T <= 32767 the cycle ends ride in the kernel arguments — no upload,
+// no copy kernel ahead of the launch; beyond that: hipErrorInvalidValue (upload and call
+// pcgmix_logmel_f32).  The boundaries in spectrogram columns are the caller's to compute
+// (frontend.spec_frames: round(f * n_frames / T), round-half-even).
+extern "C" int pcgmix_logmel_hostframes_f32(const float* x, const int32_t* frames_host, const void* tables,
+                                            float* spec, int B, int T, int n_fft, int hop, int n_mels,
+                                            float mean, float std, int W, int pad_mode,
+                                            pcgmix_stream_t stream) {
+  using namespace pcgmix;
+  if (!x || !frames_host || !tables || !spec) return hipErrorInvalidValue;
+  if (B < 0 || B > kMelEndsMax || T < 2 || T > 32767 || n_fft < 4 || (n_fft & 3) || hop < 1 || n_mels < 1 ||
+      W < 1 || !(std != 0.f) || n_fft / 2 >= T || (pad_mode != kPadConstant && pad_mode != kPadReflect))
+    return hipErrorInvalidValue;
+  if (B == 0) return hipSuccess;
+  MelEnds ends;
+  ends.n = B;
+  for (int b = 0; b < B; ++b) {
+    const int32_t f4 = frames_host[(size_t)b * 5 + 4];
+    ends.v[b] = (int16_t)(f4 < -32768 ? -32768 : (f4 > 32767 ? 32767 : f4));
   }
-  if (hipError_t e = allow_large_lds(reinterpret_cast<const void*>(logmel_kernel<false, 0>), &lds_ok,
-                                     158 * 1024))
-    return (int)e;
-  hipLaunchKernelGGL((logmel_kernel<false, 0>), dim3((unsigned)B), dim3(kMelThreads), (size_t)L.total,
-                     reinterpret_cast<hipStream_t>(stream), x, frames, nullptr, nullptr, nullptr,
-                     static_cast<const unsigned char*>(tables), spec, nullptr, 0LL, frames_out, B, T,
-                     n_fft, hop, n_mels, mean, std, W, pad_mode);
-  return (int)hipGetLastError();
+  return launch_logmel_cycles(x, nullptr, &ends, tables, spec, nullptr, B, T, n_fft, hop, n_mels, mean, std, W,
+                              pad_mode, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pcgmix_logmel_tile_frames(void) { return pcgmix::kTileFrames; }
@@ -646,15 +746,15 @@ extern "C" int pcgmix_logmel_recordings_f32(
   if (!y || !rec_off || !rec_len || !tiles || !cycles || !tables || !db_scratch || !ref_pow ||
       !spec)
     return hipErrorInvalidValue;
-  if (R < 1 || n_tiles < 1 || n_cycles < 0 || scratch_cols < 1 || n_fft < 2 || (n_fft & 1) ||
+  if (R < 1 || n_tiles < 1 || n_cycles < 0 || scratch_cols < 1 || n_fft < 4 || (n_fft & 3) ||
       hop < 1 || n_mels < 1 || W < 1 || !(std != 0.f) ||
       (pad_mode != kPadConstant && pad_mode != kPadReflect))
     return hipErrorInvalidValue;
   const MelLayout L = mel_layout(kTileFrames, n_fft, hop, n_mels, W, false);
   if (L.total > 158 * 1024) return hipErrorInvalidValue;
   static unsigned long long lds_ok = 0, lds_ok17 = 0;
-  const bool ks17 = mel_tables(n_fft, n_mels).ksteps == 17;
-  if (hipError_t e = ks17 ? allow_large_lds(reinterpret_cast<const void*>(logmel_kernel<true, 17>),
+  const bool ks17 = mel_tables(n_fft, n_mels).ksteps == 9;
+  if (hipError_t e = ks17 ? allow_large_lds(reinterpret_cast<const void*>(logmel_kernel<true, 9>),
                                             &lds_ok17, 158 * 1024)
                           : allow_large_lds(reinterpret_cast<const void*>(logmel_kernel<true, 0>),
                                             &lds_ok, 158 * 1024))
@@ -663,17 +763,17 @@ extern "C" int pcgmix_logmel_recordings_f32(
   hipLaunchKernelGGL(zero_u32_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, ref_pow, R);
   static_assert(sizeof(long long) == sizeof(int64_t), "rec_off is read as long long");
   if (ks17)
-    hipLaunchKernelGGL((logmel_kernel<true, 17>), dim3((unsigned)n_tiles), dim3(kMelThreads),
+    hipLaunchKernelGGL((logmel_kernel<true, 9>), dim3((unsigned)n_tiles), dim3(kMelThreads),
                        (size_t)L.total, s, y, nullptr, reinterpret_cast<const long long*>(rec_off),
                        rec_len, reinterpret_cast<const int4*>(tiles),
                        static_cast<const unsigned char*>(tables), db_scratch, ref_pow, scratch_cols,
-                       nullptr, n_tiles, 0, n_fft, hop, n_mels, mean, std, W, pad_mode);
+                       nullptr, n_tiles, 0, n_fft, hop, n_mels, mean, std, W, pad_mode, MelNoEnds{0});
   else
     hipLaunchKernelGGL((logmel_kernel<true, 0>), dim3((unsigned)n_tiles), dim3(kMelThreads),
                        (size_t)L.total, s, y, nullptr, reinterpret_cast<const long long*>(rec_off),
                        rec_len, reinterpret_cast<const int4*>(tiles),
                        static_cast<const unsigned char*>(tables), db_scratch, ref_pow, scratch_cols,
-                       nullptr, n_tiles, 0, n_fft, hop, n_mels, mean, std, W, pad_mode);
+                       nullptr, n_tiles, 0, n_fft, hop, n_mels, mean, std, W, pad_mode, MelNoEnds{0});
   if (n_cycles > 0)
     hipLaunchKernelGGL(logmel_slice_kernel, dim3((unsigned)n_cycles), dim3(256), 0, s, db_scratch,
                        scratch_cols, ref_pow, reinterpret_cast<const int4*>(cycles), spec, n_mels,

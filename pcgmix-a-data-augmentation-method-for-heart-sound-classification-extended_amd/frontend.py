@@ -105,13 +105,23 @@ def logmel(x: torch.Tensor, frames, sample_rate: int = 2000, n_mels: int = SPEC_
     lib = _lib.load()
     with torch.cuda.device(x.device):
         tables = logmel_tables(x.device, n_fft, n_mels, sample_rate)
-        fr = upload_array(frames_np.astype(np.int32), x.device)
         spec = torch.empty((B, 1, n_mels, width), dtype=torch.float32, device=x.device)
         stream = _raw_stream(x.device)
-        _lib.check(lib.pcgmix_logmel_f32(x.data_ptr(), fr.data_ptr(), tables.data_ptr(),
-                                         spec.data_ptr(), None, B, T, n_fft, hop, n_mels,
-                                         ctypes.c_float(mean), ctypes.c_float(std), width, pad_code,
-                                         ctypes.c_void_p(stream)), "pcgmix_logmel_f32")
+        fr32 = np.ascontiguousarray(frames_np, dtype=np.int32)
+        if fr32.shape != (B, 5):
+            raise ValueError("frames must be (B, 5)")
+        if B <= 1024 and T <= 32767:
+            # the cycle ends ride in the kernel arguments: no upload, no copy kernel before the launch
+            _lib.check(lib.pcgmix_logmel_hostframes_f32(
+                x.data_ptr(), fr32.ctypes.data, tables.data_ptr(), spec.data_ptr(), B, T, n_fft, hop,
+                n_mels, ctypes.c_float(mean), ctypes.c_float(std), width, pad_code,
+                ctypes.c_void_p(stream)), "pcgmix_logmel_hostframes_f32")
+        else:
+            fr = upload_array(fr32, x.device)
+            _lib.check(lib.pcgmix_logmel_f32(x.data_ptr(), fr.data_ptr(), tables.data_ptr(),
+                                             spec.data_ptr(), None, B, T, n_fft, hop, n_mels,
+                                             ctypes.c_float(mean), ctypes.c_float(std), width, pad_code,
+                                             ctypes.c_void_p(stream)), "pcgmix_logmel_f32")
     return spec, spec_frames(frames_np, T, hop)
 
 

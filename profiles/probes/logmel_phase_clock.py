@@ -24,12 +24,25 @@ x, frames, labels, wav = synthetic.make_batch(B, 1, T, sample_rate=2000, seed=0)
 x1 = torch.from_numpy(x[:, 0, :].copy()).to(dev)
 lib = _lib.load()
 raw = ctypes.CDLL(out)
-print("# wall_clock64 (100 MHz) around the phases of block 7, logmel_kernel<false, 17>, (256, 5000):")
+print("# wall_clock64 (100 MHz) around the phases of every block, logmel_kernel<false, 9>, (256, 5000):")
 print("#   staging | STFT (f64 matrix + leftover bins on the VALU) | mel + dB + max | reference, normalise, store")
 for it in range(6):
     frontend.logmel(x1, frames)
     torch.cuda.synchronize()
-    t = (ctypes.c_longlong * 5)()
-    raw.pcgmix_logmel_phase_clock(t)
-    t = np.array(list(t), dtype=np.int64)
-    print("us:", ((t[1:] - t[:-1]) / 100.0).round(2), "block total", (t[4] - t[0]) / 100.0)
+    buf = (ctypes.c_longlong * (B * 8))()
+    assert raw.pcgmix_logmel_phase_clock(buf, B) == 0
+    t = np.frombuffer(buf, dtype=np.int64).reshape(B, 8)
+    us = (t[:, :5] - t[:, 0].min()) / 100.0
+    ph = us[:, 1:] - us[:, :-1]
+    print("median block, us:", np.median(ph, axis=0).round(2), "block total median %.2f max %.2f" %
+          (np.median(us[:, 4] - us[:, 0]), (us[:, 4] - us[:, 0]).max()))
+    print("   slowest block's phases:", ph[np.argmax(us[:, 4] - us[:, 0])].round(2),
+          "| entry: median %.2f p90 %.2f max %.2f | exit: median %.2f max %.2f (= launch span)" %
+          (np.median(us[:, 0]), np.percentile(us[:, 0], 90), us[:, 0].max(), np.median(us[:, 4]), us[:, 4].max()))
+hw = t[:, 5] & 0xffffffff
+xcc = (t[:, 5] >> 32) & 0xf
+cu = (xcc << 12) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)
+u, cnt = np.unique(cu, return_counts=True)
+print("blocks per CU: %d CUs used, max %d blocks on one CU; blocks per XCC:" % (len(u), cnt.max()), np.bincount(xcc.astype(int)))
+late = np.argsort(us[:, 0])[::-1][:8]
+print("latest entries: block, entry us, CU id:", [(int(b), float(us[b, 0].round(1)), hex(int(cu[b]))) for b in late])

@@ -41,6 +41,37 @@ def test_logmel_matches_restatement(B, seed, pad_mode, device):
     assert (got[np.broadcast_to(cols, got.shape)] == 0).all()
 
 
+@pytest.mark.parametrize("sample_rate,T", [(2000, 5000), (1000, 2500), (1000, 1800)])
+def test_logmel_boundaries_in_arguments_equal_boundaries_in_memory(sample_rate, T, device):
+    """pcgmix_logmel_hostframes_f32 (cycle ends in the kernel arguments: what frontend.logmel calls)
+    == pcgmix_logmel_f32 (boundaries read from device memory, with frames_out), bit for bit, at
+    n_fft = 136 (nine k-steps, the register ring) and at 68 (the general loop); and both
+    against the restatement."""
+    import ctypes
+    from pcgmix_amd import _lib
+    from pcgmix_amd.augmentations import upload_array
+    B = 6
+    x, frames, _, _ = synthetic.make_batch(B, 1, T, sample_rate=sample_rate, seed=2)
+    xd = torch.from_numpy(x[:, 0].copy()).to(device)
+    spec, fs = frontend.logmel(xd, frames, sample_rate=sample_rate)
+    n_fft, hop = frontend.stft_params(sample_rate)
+    lib = _lib.load()
+    tables = frontend.logmel_tables(xd.device, n_fft, 128, sample_rate)
+    fr = upload_array(frames.astype(np.int32), xd.device)
+    spec2 = torch.empty_like(spec)
+    fo = torch.empty((B, 5), dtype=torch.int32, device=device)
+    _lib.check(lib.pcgmix_logmel_f32(xd.data_ptr(), fr.data_ptr(), tables.data_ptr(), spec2.data_ptr(),
+                                     fo.data_ptr(), B, T, n_fft, hop, 128, ctypes.c_float(frontend.TRAIN_MEAN),
+                                     ctypes.c_float(frontend.TRAIN_STD), 128, 0,
+                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "pcgmix_logmel_f32")
+    assert torch.equal(spec, spec2)
+    assert np.array_equal(fo.cpu().numpy().astype(np.int64), fs)
+    ref, fs_ref = O.logmel(x[:, 0], frames, n_fft=n_fft, hop=hop, sr=float(sample_rate))
+    assert np.array_equal(fs, fs_ref)
+    assert np.abs(spec.cpu().numpy()[:, 0] - ref).max() <= 1e-4
+
+
 def test_logmel_silence_and_bad_arguments(device):
     x = torch.zeros(2, 5000, device=device)
     frames = np.array([[0, 200, 600, 800, 1800]] * 2)
