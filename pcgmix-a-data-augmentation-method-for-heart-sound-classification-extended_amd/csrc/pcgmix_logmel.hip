@@ -418,31 +418,84 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   float pmax = 0.f;        // recording mode: max mel power of this tile's valid frames
   // wave -> mel band (its filter span and weights are wave-uniform, fetched once per band),
   // lane -> frame: the power-spectrogram reads and the image writes are unit-stride in LDS
+  // The band's record is wave-uniform but comes out of LDS: without readfirstlane the compiler treats
+  // the span as per-lane data and turns the taps into exec-masked branches, each with its own LDS
+  // read and s_waitcnt.  The NEXT band's record is fetched before this band's frames are walked, and
+  // up to three 64-frame passes of a band run side by side (independent read -> fma -> v_log ->
+  // store chains).  Phase: 7.0 -> 5.8 us of the block (profiles/r4_logmel_phases.txt).
+  struct BandRec { int klo, khi; float w[4]; };
+  auto fetch = [&](int m) {
+    BandRec r;
+    r.klo = reinterpret_cast<const int*>(melw)[8 * m];
+    r.khi = reinterpret_cast<const int*>(melw)[8 * m + 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.w[j] = melw[8 * m + 2 + j];
+    return r;
+  };
+  auto emit = [&](int m, int t, float acc) {
+    const float db = power_db(acc);                          // power_to_db, amin = 1e-10
+    if (RECORD) {
+      pmax = fmaxf(pmax, acc);
+      spec[(size_t)m * scratch_cols + out_col + t] = db;     // 256-byte runs per wave
+    } else {
+      vmax = fmaxf(vmax, db);
+      if (t < W) img[m * W + t] = db;
+    }
+  };
+  BandRec nxt = fetch(wave < n_mels ? wave : 0);
   for (int m = wave; m < n_mels; m += kMelWaves) {
-    const int klo = reinterpret_cast<const int*>(melw)[8 * m];
-    const int khi = reinterpret_cast<const int*>(melw)[8 * m + 1];
+    const int klo = __builtin_amdgcn_readfirstlane(nxt.klo), khi = __builtin_amdgcn_readfirstlane(nxt.khi);
     // triangular filters span a handful of bins: up to 4 weights come from the LDS record so that
-    // the frame loop never waits on a global load
+    // the frame loop never waits on a global load; weights beyond the span are 0 and their taps read
+    // the span's last row, so the taps are unconditional: fmaf(0, finite, acc) == acc, the sum is
+    // bit for bit the one over the span alone
     float w4[4];
+    int row[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w4[j] = melw[8 * m + 2 + j];
-    const bool small = khi - klo < 4;
-    for (int t = lane; t < n_frames; t += 64) {
-      float accm = 0.f;
-      if (small) {
+    for (int j = 0; j < 4; ++j) {
+      w4[j] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nxt.w[j])));
+      int r = klo + j <= khi ? klo + j : khi;
+      row[j] = (r < 0 ? 0 : r) * L.nfp;
+    }
+    if (m + kMelWaves < n_mels) nxt = fetch(m + kMelWaves);
+    const int span = khi - klo;       // 0 for 125 of the reference's 128 filters (one FFT bin)
+    if (span < 4) {
+      constexpr int kTP = 3;
+      for (int t0 = lane; t0 < n_frames; t0 += 64 * kTP) {
+        float acc[kTP];
+        if (span == 0) {
+          float pv[kTP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (klo + j <= khi) accm = fmaf(w4[j], ps[(klo + j) * L.nfp + t], accm);
-      } else {
-        for (int k = klo; k <= khi; ++k) accm = fmaf(wts[m * n_bins + k], ps[k * L.nfp + t], accm);
+          for (int u = 0; u < kTP; ++u) {
+            const int t = t0 + 64 * u;
+            pv[u] = ps[row[0] + (t < n_frames ? t : n_frames - 1)];       // clamped: unconditional
+          }
+#pragma unroll
+          for (int u = 0; u < kTP; ++u) acc[u] = fmaf(w4[0], pv[u], 0.f);
+        } else {
+          float pv[kTP][4];
+#pragma unroll
+          for (int u = 0; u < kTP; ++u) {
+            const int t = t0 + 64 * u, tc = t < n_frames ? t : n_frames - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pv[u][j] = ps[row[j] + tc];
+          }
+#pragma unroll
+          for (int u = 0; u < kTP; ++u) {
+            acc[u] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[u] = fmaf(w4[j], pv[u][j], acc[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kTP; ++u)
+          if (t0 + 64 * u < n_frames) emit(m, t0 + 64 * u, acc[u]);
       }
-      const float db = power_db(accm);                       // power_to_db, amin = 1e-10
-      if (RECORD) {
-        pmax = fmaxf(pmax, accm);
-        spec[(size_t)m * scratch_cols + out_col + t] = db;    // 256-byte runs per wave
-      } else {
-        vmax = fmaxf(vmax, db);
-        if (t < W) img[m * W + t] = db;
+    } else {
+      for (int t = lane; t < n_frames; t += 64) {
+        float accm = 0.f;
+        for (int k = klo; k <= khi; ++k) accm = fmaf(wts[m * n_bins + k], ps[k * L.nfp + t], accm);
+        emit(m, t, accm);
       }
     }
   }

@@ -10,7 +10,8 @@ out = os.path.join(ROOT, "build_probe", "libpcgmix_phase_clock.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 srcs = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")))
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-shared", "-std=c++17", "--offload-arch=gfx950",
-                "-ffp-contract=off", "-DPCGMIX_PHASE_CLOCK", "-I" + os.path.join(ROOT, "include"), "-o", out]
+                "-ffp-contract=off", "-DPCGMIX_PHASE_CLOCK"] + os.environ.get("PCGMIX_PROBE_DEFINES", "").split()
+               + ["-I" + os.path.join(ROOT, "include"), "-o", out]
                + srcs, check=True)
 import numpy as np
 import torch
