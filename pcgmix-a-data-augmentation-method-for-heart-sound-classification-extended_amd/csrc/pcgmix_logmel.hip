@@ -65,11 +65,14 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 //                  n = 1 .. n_fft/2: those few rows (5 of 69 at n_fft = 136: bins 64..68) run on the
 //                  float64 VALU instead of costing two more matrix tiles
 //   [off_win]      double win[n_fft/2 + 1]                periodic Hann
+//   [off_meta]     int32  n_left_used                     the VALU bins 16*m_mfma .. that at least one
+//                  mel filter has a non-zero weight on (the Nyquist bin 68 of the reference's bank
+//                  has none: 4 of the 5 rows are computed)
 // m_tiles counts the 16-row tiles the power spectrogram has room for; m_mfma = 2 * tpp of them (tpp
 // tile pairs: even bins, odd bins) go through the matrix cores.
 struct MelTables {
   int m_tiles, m_mfma, n_left, ksteps, n_bins;
-  size_t off_wts, off_krange, off_left, off_win, total;
+  size_t off_wts, off_krange, off_left, off_win, off_meta, total;
 };
 __host__ __device__ inline MelTables mel_tables(int n_fft, int n_mels) {
   MelTables t;
@@ -97,6 +100,8 @@ __host__ __device__ inline MelTables mel_tables(int n_fft, int n_mels) {
   o += (size_t)t.n_left * (n_fft / 2) * 2 * sizeof(double);
   t.off_win = o;
   o += (size_t)(n_fft / 2 + 1) * sizeof(double);
+  t.off_meta = o;                                   // int32 n_left_used: VALU bins that some filter reads
+  o += 8;
   t.total = (o + 15) & ~(size_t)15;
   return t;
 }
@@ -271,10 +276,15 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   const int n_units = tb.m_mfma * (L.nfp / (16 * kNGroup));
   const int n_groups = L.nfp / (16 * kNGroup);
   const int col = lane & 15, kq = lane >> 4;
-  // The bins beyond the last full tile on the float64 VALU, one (bin, frame) per lane, k ascending,
-  // by the waves that get one matrix unit fewer than the others (or by all of them): it runs
-  // beside the other waves' matrix instructions, which occupy a different pipe.
-  if (tb.n_left) {
+  // The bins beyond the last full tile pair on the float64 VALU (single fold, window in the
+  // coefficients), one (bin, frame) per lane, k ascending, by the waves that get one matrix unit
+  // fewer than the others (or by all of them).  Only the rows some mel filter reads (n_left_used: 4
+  // of 5 at the reference's bank — 640 outputs, ONE pass of the twelve waves instead of two).
+  // Measured alternatives, all slower or equal (profiles/r4_logmel_phases.txt): the pass behind the
+  // unit loop; the bins fused into the matrix units' k loop on their doubly folded operands; one
+  // frame per lane with the k range in quarters.  Without these rows the phase is 12.7 us.
+  const int n_left_used = tb.n_left ? *reinterpret_cast<const int32_t*>(tables + tb.off_meta) : 0;
+  if (n_left_used > 0) {
     // waves whose LAST round is empty (see unit_of below) take the VALU work; all of them if the
     // rounds are full
     const int spare = n_units % kMelWaves;         // units in the last, partial round (0: none)
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
     const int n_idle = spare == 0 ? kMelWaves : kMelWaves - spare;
     const int my = spare == 0 ? wave : jw - spare;               // rank among the idle waves
     if (idle) {
-      const int nh = n_fft / 2, n_out = tb.n_left * L.nfp;
+      const int nh = n_fft / 2, n_out = n_left_used * L.nfp;
       for (int o = my * 64 + lane; o < n_out; o += n_idle * 64) {
         const int lb = o / L.nfp, f = o - lb * L.nfp;
         const float* xl = xrow + f * hop;
@@ -715,6 +725,15 @@ extern "C" int pcgmix_logmel_tables(int n_fft, int n_mels, float fmin, float fma
     }
     krange[2 * m] = lo;
     krange[2 * m + 1] = hi;
+  }
+  {
+    int top = -1;                                   // highest bin any filter reads
+    for (int m = 0; m < n_mels; ++m) top = krange[2 * m + 1] > top ? krange[2 * m + 1] : top;
+    int used = top - 16 * tb.m_mfma + 1;
+    used = used < 0 ? 0 : (used > tb.n_left ? tb.n_left : used);
+    int32_t* meta = reinterpret_cast<int32_t*>(base + tb.off_meta);
+    meta[0] = used;
+    meta[1] = 0;
   }
   return hipSuccess;
 }
