@@ -29,7 +29,8 @@
 // (the n = 0 column carries the old n = H term: u[0] = 0).  Even and odd bins are separate GEMMs
 // with K = Q + 1 = 35 instead of 68: 9 k-steps instead of 17, half the matrix instructions again —
 // the f64 matrix pipe (150 cycles per instruction and SIMD) is what bounds this kernel
-// (profiles/r4_logmel_phases.txt).  Tile mt holds the bins 2 (16 (mt >> 1) + row) + (mt & 1).
+// (profiles/r4_logmel_phases.txt).  Tile pair t holds the bins bin_lo + 2 (16 t + row) (+ 1), bin_lo = the
+// lowest bin any mel filter reads, rounded down to even (2 at the reference's bank).
 // Everything that does not depend on the data (the windowed twiddle matrices already in MFMA
 // A-fragment order, the mel filter bank, each filter's non-zero span) is a constant table built
 // once on the host (pcgmix_logmel_tables) and read through L2.  One block per sample; LDS holds the reflect-padded row, the power spectrogram and
@@ -49,25 +50,27 @@ namespace pcgmix {
 
 constexpr int kMelThreads = 1024;
 constexpr int kMelWaves = kMelThreads / 64;
-constexpr int kNGroup = 2;  // 16-frame tiles per work unit of a wave (re + im accumulators: 4 x v4f64)
+constexpr int kLeftPad = 8;    // zero columns behind their coefficient rows (k parts need not divide n_fft/2)
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // ---- constant tables (host-built blob) ---------------------------------------------------------
-//   [0]            double afrag[m_mfma][ksteps][2][64]    A operands (re, im), one double per lane:
+//   [0]            double afrag[tpp][ksteps][4][64]       A operands of tile pair t (even re, even im,
+//                  odd re, odd im), one double per lane:
 //                  lane l -> row = l & 15, n = 4*ks + (l >> 4)  (n = 0 .. Q; beyond: 0),
-//                  bin = 2 (16 (mt >> 1) + row) + (mt & 1)
+//                  even bin = bin_lo + 2 (16 t + row), odd bin = even bin + 1
 //                  re:  c_n cos(2 pi bin n / n_fft);   im: -c_n sin(2 pi bin n / n_fft)
 //   [off_wts]      float  wts[n_mels][n_bins]             librosa.filters.mel, slaney, float32
 //   [off_krange]   int32  krange[n_mels][2]               first / last non-zero bin
-//   [off_left]     double left[n_left][n_fft/2][2]        (re, im) coefficients (window included,
+//   [off_left]     double left[n_left][n_fft/2 + 8][2]    (re, im) coefficients (window included,
 //                  single fold) of the bins beyond the last full PAIR of 16-bin tiles,
 //                  n = 1 .. n_fft/2: those few rows (5 of 69 at n_fft = 136: bins 64..68) run on the
 //                  float64 VALU instead of costing two more matrix tiles
 //   [off_win]      double win[n_fft/2 + 1]                periodic Hann
-//   [off_meta]     int32  n_left_used                     the VALU bins 16*m_mfma .. that at least one
-//                  mel filter has a non-zero weight on (the Nyquist bin 68 of the reference's bank
-//                  has none: 4 of the 5 rows are computed)
+//   [off_meta]     int32  n_left_used, bin_lo             the matrix tiles start at bin_lo (bins 0 and 1
+//                  of the reference's bank carry no filter weight: the 64 tile rows are bins 2..65)
+//                  and of the VALU rows bin_lo + 16*m_mfma + lb only the first n_left_used are read by
+//                  a filter (66, 67; the Nyquist bin 68 carries no weight either)
 // m_tiles counts the 16-row tiles the power spectrogram has room for; m_mfma = 2 * tpp of them (tpp
 // tile pairs: even bins, odd bins) go through the matrix cores.
 struct MelTables {
@@ -97,17 +100,17 @@ __host__ __device__ inline MelTables mel_tables(int n_fft, int n_mels) {
   o += (size_t)n_mels * 2 * sizeof(int32_t);
   o = (o + 7) & ~(size_t)7;
   t.off_left = o;
-  o += (size_t)t.n_left * (n_fft / 2) * 2 * sizeof(double);
+  o += (size_t)t.n_left * (n_fft / 2 + kLeftPad) * 2 * sizeof(double);
   t.off_win = o;
   o += (size_t)(n_fft / 2 + 1) * sizeof(double);
-  t.off_meta = o;                                   // int32 n_left_used: VALU bins that some filter reads
+  t.off_meta = o;                                   // int32 n_left_used, bin_lo
   o += 8;
   t.total = (o + 15) & ~(size_t)15;
   return t;
 }
 
 struct MelLayout {  // byte offsets into dynamic LDS
-  int xrow, ps, img, melw, left, win, total;
+  int xrow, ps, img, melw, left, win, part, part_bytes, total;
   int nfp, xr;
 };
 // n_frames = frames one block transforms: 1 + T/hop of a heart-cycle item, or the tile size of
@@ -116,7 +119,7 @@ __host__ __device__ inline MelLayout mel_layout(int n_frames, int n_fft, int hop
                                                 int W, bool image = true) {
   const MelTables tb = mel_tables(n_fft, n_mels);
   MelLayout L;
-  L.nfp = ((n_frames + 16 * kNGroup - 1) / (16 * kNGroup)) * (16 * kNGroup);  // frames, padded
+  L.nfp = ((n_frames + 31) / 32) * 32;          // frames, padded: whole 16-frame groups, rows 128-byte aligned
   L.xr = (L.nfp - 1) * hop + n_fft + 8;      // padded-row samples the GEMM may touch
   L.xr = (L.xr + 3) & ~3;
   int o = 0;
@@ -124,8 +127,20 @@ __host__ __device__ inline MelLayout mel_layout(int n_frames, int n_fft, int hop
   L.ps = o;   o += tb.m_tiles * 16 * L.nfp * 4; // power spectrogram [bin][frame]        (float)
   L.img = o;  o += (image ? n_mels * W : 0) * 4;  // dB image                            (float)
   L.melw = o; o += n_mels * 8 * 4;              // per band: klo, khi, 4 weights (+2 pad) (32 B)
-  L.left = o; o += tb.n_left * (n_fft / 2) * 2 * 8;   // coefficients of the VALU bins       (double)
+  L.left = o; o += tb.n_left * (n_fft / 2 + kLeftPad) * 2 * 8;   // coefficients of the VALU bins (double)
   L.win = o;  o += (n_fft / 2 + 1) * 8;         // periodic Hann, n = 0 .. n_fft/2          (double)
+  // partial sums of the VALU bins [wave job][bin][lane][re, im] (double): over the dB image, which
+  // is written only after they are consumed, when that is large enough; else on their own
+  // (the kernel takes as many k parts as fit: one wave job = n_left_used rows x 64 lanes x 16 bytes)
+  if (image) {
+    L.part = L.img;
+    L.part_bytes = n_mels * W * 4;
+  } else {
+    o = (o + 15) & ~15;
+    L.part = o;
+    L.part_bytes = kMelWaves * tb.n_left * 64 * 16;
+    o += L.part_bytes;
+  }
   L.total = o;
   return L;
 }
@@ -178,7 +193,14 @@ __device__ long long g_logmel_clock[kMelClockBlocks * 8];
           ((long long)__builtin_amdgcn_s_getreg(0xF814) << 32) | __builtin_amdgcn_s_getreg(0xF804); \
     }                                                                            \
   } while (0)
+__device__ long long g_logmel_wave_clock[16 * 4];
+#define PCGMIX_WCLOCK(i)                                                         \
+  do {                                                                           \
+    if (!RECORD && blockIdx.x == 7 && (threadIdx.x & 63) == 0)                   \
+      g_logmel_wave_clock[(threadIdx.x >> 6) * 4 + (i)] = wall_clock64();        \
+  } while (0)
 #else
+#define PCGMIX_WCLOCK(i) do { } while (0)
 #define PCGMIX_CLOCK(i) do { } while (0)
 #endif
 
@@ -193,6 +215,9 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ float red[kMelWaves];
   const MelTables tb = mel_tables(n_fft, n_mels);
+  // (read here, used behind the staging barrier: a load issued there costs the phase its ~1.5 us)
+  const int n_left_used = tb.n_left ? reinterpret_cast<const int32_t*>(tables + tb.off_meta)[0] : 0;
+  const int bin_lo = reinterpret_cast<const int32_t*>(tables + tb.off_meta)[1];
   PCGMIX_CLOCK(0);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_bins = tb.n_bins, pad = n_fft / 2;
@@ -225,9 +250,10 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   float* melw = reinterpret_cast<float*>(smem + L.melw);
   double* leftc = reinterpret_cast<double*>(smem + L.left);
   double* winl = reinterpret_cast<double*>(smem + L.win);
+  double* lpart = reinterpret_cast<double*>(smem + L.part);
   {
     const double* lg = reinterpret_cast<const double*>(tables + tb.off_left);
-    for (int i = tid; i < tb.n_left * (n_fft / 2) * 2; i += kMelThreads) leftc[i] = lg[i];
+    for (int i = tid; i < tb.n_left * (n_fft / 2 + kLeftPad) * 2; i += kMelThreads) leftc[i] = lg[i];
     const double* wg = reinterpret_cast<const double*>(tables + tb.off_win);
     for (int i = tid; i <= n_fft / 2; i += kMelThreads) winl[i] = wg[i];
   }
@@ -273,46 +299,94 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   // C layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4*reg, col = lane&15.  The re and the
   // im GEMM use the same row -> bin map, so a lane holds re and im of the same (bin, frame) in
   // the same register slot of its two accumulators: |.|^2 needs no cross-lane traffic.
-  const int n_units = tb.m_mfma * (L.nfp / (16 * kNGroup));
-  const int n_groups = L.nfp / (16 * kNGroup);
+  // A work unit is one PAIR of tiles (the even bins and the odd bins next to them) times one group
+  // of 16 frames: the four B operands of a k-step — u[n] +- u[H-n], v[n] -+ v[H-n] — come from the
+  // same four samples, two window values and sixteen float64 VALU operations, and feed four matrix
+  // instructions.  (Until the units were paired an even tile and an odd tile each prepared their
+  // own operands for two frame groups: 36 per four matrix instructions.  The phase is bound by the
+  // instructions a SIMD issues, matrix and other, one after the other — profiles/r4_logmel_phases.txt.)
+  const int tpp = tb.m_mfma >> 1;
+  const int n_groups = L.nfp / 16;
+  const int n_units = tpp * n_groups;
   const int col = lane & 15, kq = lane >> 4;
   // The bins beyond the last full tile pair on the float64 VALU (single fold, window in the
-  // coefficients), one (bin, frame) per lane, k ascending, by the waves that get one matrix unit
-  // fewer than the others (or by all of them).  Only the rows some mel filter reads (n_left_used: 4
-  // of 5 at the reference's bank — 640 outputs, ONE pass of the twelve waves instead of two).
-  // Measured alternatives, all slower or equal (profiles/r4_logmel_phases.txt): the pass behind the
-  // unit loop; the bins fused into the matrix units' k loop on their doubly folded operands; one
-  // frame per lane with the k range in quarters.  Without these rows the phase is 12.7 us.
-  const int n_left_used = tb.n_left ? *reinterpret_cast<const int32_t*>(tables + tb.off_meta) : 0;
-  if (n_left_used > 0) {
-    // waves whose LAST round is empty (see unit_of below) take the VALU work; all of them if the
-    // rounds are full
-    const int spare = n_units % kMelWaves;         // units in the last, partial round (0: none)
-    const int last_r = n_units / kMelWaves;
-    const int jw = last_r == 0 ? wave : ((13 * wave) & 15);      // this wave's slot in that round
-    const bool idle = spare == 0 || jw >= spare;
-    const int n_idle = spare == 0 ? kMelWaves : kMelWaves - spare;
-    const int my = spare == 0 ? wave : jw - spare;               // rank among the idle waves
-    if (idle) {
-      const int nh = n_fft / 2, n_out = n_left_used * L.nfp;
-      for (int o = my * 64 + lane; o < n_out; o += n_idle * 64) {
-        const int lb = o / L.nfp, f = o - lb * L.nfp;
-        const float* xl = xrow + f * hop;
-        const float* xh = xrow + f * hop + n_fft;
-        const double* cf = leftc + (size_t)lb * nh * 2;
-        double re = 0.0, im = 0.0;
-#pragma unroll 4
-        for (int k = 1; k <= nh; ++k) {
+  // coefficients), by ALL waves, with barriers around them; only the rows some mel filter reads
+  // (n_left_used: bins 66, 67 at the reference's bank).  A lane takes one FRAME, a wave one part of
+  // the k range for 64 frames: the sample pair of a k is read, converted, added and subtracted once
+  // for all rows, the coefficients are wave-uniform, nothing is clamped or masked (the rows end in
+  // zero columns); the parts meet in LDS and are added in a fixed order.  Per-wave stamps
+  // (profiles/r4_logmel_phases.txt) showed what the older form cost: one (bin, frame) per lane over
+  // the whole k range, by the waves without a second unit, "beside" the first matrix units — those
+  // waves came out of it 4 to 13 us into the phase: the pass is bound by its instruction count, and
+  // every instruction it issues is a slot the matrix waves of the same SIMD do not get.
+  if (n_left_used > 0) {                             // block-uniform
+    const int nh = n_fft / 2, ncol = nh + kLeftPad;
+    const int n_fg = (L.nfp + 63) / 64;              // 64-frame groups
+    int parts = kMelWaves / n_fg;                    // k parts, one wave each per frame group
+    const int fit = L.part_bytes / (n_left_used * 64 * 16) / n_fg;   // ... as far as their sums fit
+    parts = parts > fit ? fit : parts;
+    parts = parts < 1 ? 1 : (parts > kLeftPad ? kLeftPad : parts);
+    const int kper = (nh + parts - 1) / parts;       // parts * kper <= nh + parts - 1 < nh + kLeftPad
+    // the row count as a compile-time constant: straight-line code per k (with a run-time count every
+    // row became its own branch with its own LDS wait)
+    auto rows_pass = [&](auto nr_tag) {
+      constexpr int NR = decltype(nr_tag)::value;
+      for (int job = wave; job < n_fg * parts; job += kMelWaves) {
+        const int fg = job % n_fg, part = job / n_fg;
+        const int f = fg * 64 + lane, fc = f < L.nfp ? f : L.nfp - 1;
+        const float* xl = xrow + fc * hop;
+        const float* xh = xrow + fc * hop + n_fft;
+        const int k0 = 1 + part * kper;
+        double re[NR], im[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) re[r] = im[r] = 0.0;
+#pragma unroll 2
+        for (int k = k0; k < k0 + kper; ++k) {
           const double lo = (double)xl[k], hi = (double)xh[-k];
-          re = fma(cf[2 * (k - 1)], lo + hi, re);
-          im = fma(cf[2 * (k - 1) + 1], lo - hi, im);
+          const double sm = lo + hi, df = lo - hi;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const double* cf = leftc + ((size_t)r * ncol + (k - 1)) * 2;
+            re[r] = fma(cf[0], sm, re[r]);
+            im[r] = fma(cf[1], df, im[r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          double* dst = lpart + (((size_t)job * NR + r) * 64 + lane) * 2;
+          dst[0] = re[r];
+          dst[1] = im[r];
+        }
+      }
+    };
+    switch (n_left_used) {
+      case 1: rows_pass(std::integral_constant<int, 1>{}); break;
+      case 2: rows_pass(std::integral_constant<int, 2>{}); break;
+      case 3: rows_pass(std::integral_constant<int, 3>{}); break;
+      case 4: rows_pass(std::integral_constant<int, 4>{}); break;
+      case 5: rows_pass(std::integral_constant<int, 5>{}); break;
+      case 6: rows_pass(std::integral_constant<int, 6>{}); break;
+      case 7: rows_pass(std::integral_constant<int, 7>{}); break;
+      default: rows_pass(std::integral_constant<int, 8>{}); break;
+    }
+    PCGMIX_WCLOCK(3);      // this wave's part of the VALU rows summed
+    __syncthreads();
+    for (int o = tid; o < n_left_used * L.nfp; o += kMelThreads) {
+        const int r = o / L.nfp, f = o - r * L.nfp;
+        const int fg = f >> 6, ln = f & 63;
+        double re = 0.0, im = 0.0;
+        for (int part = 0; part < parts; ++part) {
+          const double* src = lpart + (((size_t)(part * n_fg + fg) * n_left_used + r) * 64 + ln) * 2;
+          re += src[0];
+          im += src[1];
         }
         const float fr = (float)re, fi = (float)im;
         const float mag = hypotf(fr, fi);
-        ps[(16 * tb.m_mfma + lb) * L.nfp + f] = mag * mag;
+        ps[(bin_lo + 16 * tb.m_mfma + r) * L.nfp + f] = mag * mag;
       }
-    }
+    __syncthreads();   // the partial sums may lie over the dB image: consumed before anything else starts
   }
+  PCGMIX_WCLOCK(0);      // VALU rows done (or nothing to do)
   // Units are dealt in rounds of 16.  In a round that is not full the waves that get a unit must
   // sit on different SIMDs, and how a block's 16 waves map to the CU's four SIMDs is not something
   // to rely on: with `unit = wave + 16 r` the four second-round units of the 20 went to waves 0-3,
@@ -320,13 +394,14 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
   // 8 units on it either way).  Round r >= 1 hands unit 16 r + j to wave 5 j mod 16 — 0, 5, 10, 15,
   // 4, 9, ... — which spreads any prefix over both plausible mappings (wave mod 4 and wave / 4).
   auto unit_of = [&](int r) { return r == 0 ? wave : 16 * r + ((13 * wave) & 15); };
-  // B operands of k-step ks for the frames 16*(kNGroup*ng + i) + col: column n = 4*ks + kq of the
-  // doubly folded transform (header): bs = u[n] + s u[H-n], bd = v[n] - s v[H-n] with
-  // u = win * (lo + hi), v = win * (lo - hi), s = sgn = +1 for an even-bin tile, -1 for an odd one.
+  const int half = n_fft / 2, quarter = n_fft / 4;
+  // B operands of k-step ks for the frames 16*ng + col: column n = 4*ks + kq of the doubly folded
+  // transform (header) with u = win * (lo + hi), v = win * (lo - hi):
+  //   bo[0] = u[n] + u[H-n] (even re)   bo[1] = v[n] - v[H-n] (even im)
+  //   bo[2] = u[n] - u[H-n] (odd re)    bo[3] = v[n] + v[H-n] (odd im)
   // Columns beyond Q are padding (zero coefficients): they read column 0.  Column 0 pairs x[0]
   // with itself (win[0] = 0 makes it vanish; x[N] is not part of the frame).
-  const int half = n_fft / 2, quarter = n_fft / 4;
-  auto b_operands = [&](int ks, int ng, double sgn, double (&bs)[kNGroup], double (&bd)[kNGroup]) {
+  auto b_operands = [&](int ks, int ng, double (&bo)[4]) {
     int n = 4 * ks + kq;
     // only the last k-step can hold padding columns and only the first one column 0: with ks a
     // constant of the unrolled loop the other steps' addresses stay base + immediate
@@ -334,91 +409,90 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
     const int m = half - n;
     const double wn = winl[n], wm = winl[m];
     const int hi_n = ((KS == 0 || ks == 0 || ks == KS - 1) && n == 0) ? 0 : n_fft - n;
-#pragma unroll
-    for (int i = 0; i < kNGroup; ++i) {
-      const float* xf = xrow + (16 * (kNGroup * ng + i) + col) * hop;
-      const double lo = (double)xf[n], hi = (double)xf[hi_n];
-      const double lo2 = (double)xf[m], hi2 = (double)xf[half + n];
-      const double u = wn * (lo + hi), u2 = wm * (lo2 + hi2);      // the sums are exact in float64
-      const double v = wn * (lo - hi), v2 = wm * (lo2 - hi2);
-      bs[i] = __builtin_fma(sgn, u2, u);
-      bd[i] = __builtin_fma(-sgn, v2, v);
-    }
+    const float* xf = xrow + (16 * ng + col) * hop;
+    const double lo = (double)xf[n], hi = (double)xf[hi_n];
+    const double lo2 = (double)xf[m], hi2 = (double)xf[half + n];
+    const double u = wn * (lo + hi), u2 = wm * (lo2 + hi2);      // the sums are exact in float64
+    const double v = wn * (lo - hi), v2 = wm * (lo2 - hi2);
+    bo[0] = u + u2;
+    bo[1] = v - v2;
+    bo[2] = u - u2;
+    bo[3] = v + v2;
   };
-  // KS > 0: the fragment ring.  Four slots at KS = 9 (a k-step is 4 matrix instructions = 600+ cycles
-  // of the SIMD's matrix pipe, which four or five waves share: four steps ahead covers the ~650 ns
-  // L2 round trip; eight slots spilled at the 128-VGPR budget of a 1024-thread block).
-  constexpr int kRing = KS >= 16 ? 8 : 4;
+  // KS > 0: the fragment ring.  Two slots of four fragments at KS = 9: a k-step is 4 matrix
+  // instructions plus ~60 others, and four or five waves share the SIMD, so two steps ahead covers
+  // the ~650 ns L2 round trip within the 128-VGPR budget of a 1024-thread block.
+  constexpr int kRing = KS >= 16 ? 4 : 2;
   static_assert(KS == 0 || KS > kRing, "the ring must be shorter than a unit");
-  double fr_re[kRing], fr_im[kRing];
+  double fr[kRing][4];
   if (KS > 0 && wave < n_units) {
-    const double* ap0 = afrag + (size_t)(wave / n_groups) * KS * 128 + lane;
+    const double* ap0 = afrag + (size_t)(wave / n_groups) * KS * 256 + lane;
 #pragma unroll
-    for (int ks = 0; ks < kRing; ++ks) {
-      fr_re[ks] = ap0[(size_t)ks * 128];
-      fr_im[ks] = ap0[(size_t)ks * 128 + 64];
-    }
+    for (int ks = 0; ks < kRing; ++ks)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fr[ks][q] = ap0[(size_t)ks * 256 + 64 * q];
   }
   for (int round = 0, unit = wave; unit < n_units; ++round, unit = unit_of(round)) {
-    const int mt = unit / n_groups, ng = unit - mt * n_groups;
-    d4 are[kNGroup], aim[kNGroup];
+    const int tp = unit / n_groups, ng = unit - tp * n_groups;
+    d4 acc[4];                                        // even re, even im, odd re, odd im
 #pragma unroll
-    for (int i = 0; i < kNGroup; ++i) are[i] = aim[i] = d4{0.0, 0.0, 0.0, 0.0};
-    const double* ap = afrag + (size_t)mt * tb.ksteps * 128 + lane;   // [ks][re|im][64]
-    const double sgn = (mt & 1) ? -1.0 : 1.0;                          // (-1)^bin of this tile's bins
+    for (int q = 0; q < 4; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+    const double* ap = afrag + (size_t)tp * tb.ksteps * 256 + lane;   // [ks][even re|even im|odd re|odd im][64]
     if (KS > 0) {
       const int nxt = unit_of(round + 1);
       const bool more = nxt < n_units;                // wave-uniform
-      const double* apn = afrag + (size_t)((more ? nxt : unit) / n_groups) * KS * 128 + lane;
+      const double* apn = afrag + (size_t)((more ? nxt : unit) / n_groups) * KS * 256 + lane;
 #pragma unroll
       for (int ks = 0; ks < (KS > 0 ? KS : 1); ++ks) {
         constexpr int kM = kRing - 1;
-        const double cr = fr_re[ks & kM], ci = fr_im[ks & kM];
-        if (ks + kRing < KS) {                       // kRing steps ahead in this unit
-          fr_re[ks & kM] = ap[(size_t)(ks + kRing) * 128];
-          fr_im[ks & kM] = ap[(size_t)(ks + kRing) * 128 + 64];
-        } else if (more && KS - ks <= kRing) {       // ... or the next unit's step ks % kRing
-          fr_re[ks & kM] = apn[(size_t)(ks & kM) * 128];
-          fr_im[ks & kM] = apn[(size_t)(ks & kM) * 128 + 64];
-        }
-        double bs[kNGroup], bd[kNGroup];
-        b_operands(ks, ng, sgn, bs, bd);
+        double cf[4];
 #pragma unroll
-        for (int i = 0; i < kNGroup; ++i) {
-          are[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(cr, bs[i], are[i], 0, 0, 0);
-          aim[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(ci, bd[i], aim[i], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) cf[q] = fr[ks & kM][q];
+        if (ks + kRing < KS) {                       // kRing steps ahead in this unit
+#pragma unroll
+          for (int q = 0; q < 4; ++q) fr[ks & kM][q] = ap[(size_t)(ks + kRing) * 256 + 64 * q];
+        } else if (more && KS - ks <= kRing) {       // ... or the next unit's step ks % kRing
+#pragma unroll
+          for (int q = 0; q < 4; ++q) fr[ks & kM][q] = apn[(size_t)(ks & kM) * 256 + 64 * q];
         }
+        double bo[4];
+        b_operands(ks, ng, bo);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[q], bo[q], acc[q], 0, 0, 0);
         // keep the scheduler from hoisting several steps' operand loads above this step's matrix
         // instructions (the fully unrolled loop spilled at 128 VGPRs without it)
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      double a_re = ap[0], a_im = ap[64];
-      for (int ks = 0; ks < tb.ksteps; ++ks) {
-        const double cr = a_re, ci = a_im;
-        if (ks + 1 < tb.ksteps) {                    // prefetch the next k-step's A fragments
-          a_re = ap[(size_t)(ks + 1) * 128];
-          a_im = ap[(size_t)(ks + 1) * 128 + 64];
-        }
-        double bs[kNGroup], bd[kNGroup];
-        b_operands(ks, ng, sgn, bs, bd);
+      double cn[4];
 #pragma unroll
-        for (int i = 0; i < kNGroup; ++i) {
-          are[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(cr, bs[i], are[i], 0, 0, 0);
-          aim[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(ci, bd[i], aim[i], 0, 0, 0);
+      for (int q = 0; q < 4; ++q) cn[q] = ap[64 * q];
+      for (int ks = 0; ks < tb.ksteps; ++ks) {
+        double cf[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cf[q] = cn[q];
+        if (ks + 1 < tb.ksteps) {                    // prefetch the next k-step's A fragments
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cn[q] = ap[(size_t)(ks + 1) * 256 + 64 * q];
         }
+        double bo[4];
+        b_operands(ks, ng, bo);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(cf[q], bo[q], acc[q], 0, 0, 0);
       }
     }
+    const int fcol = 16 * ng + col;
 #pragma unroll
-    for (int i = 0; i < kNGroup; ++i) {
-      const int fcol = 16 * (kNGroup * ng + i) + col;
+    for (int par = 0; par < 2; ++par)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const float fr = (float)are[i][rr], fi = (float)aim[i][rr];  // complex64
-        const float mag = hypotf(fr, fi);                             // np.abs
-        ps[(2 * (16 * (mt >> 1) + kq + 4 * rr) + (mt & 1)) * L.nfp + fcol] = mag * mag;   // ** 2
+        const float fre = (float)acc[2 * par][rr], fim = (float)acc[2 * par + 1][rr];   // complex64
+        const float mag = hypotf(fre, fim);                                            // np.abs
+        ps[(bin_lo + 2 * (16 * tp + kq + 4 * rr) + par) * L.nfp + fcol] = mag * mag;   // ** 2
       }
-    }
+#ifdef PCGMIX_PHASE_CLOCK
+    if (round == 0) PCGMIX_WCLOCK(1); else PCGMIX_WCLOCK(2);
+#endif
   }
   __syncthreads();
 
@@ -643,6 +717,9 @@ static double mel_to_hz(double m) {
 }  // namespace pcgmix
 
 #ifdef PCGMIX_PHASE_CLOCK
+extern "C" int pcgmix_logmel_wave_clock(long long* out64) {
+  return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(pcgmix::g_logmel_wave_clock), 64 * sizeof(long long));
+}
 extern "C" int pcgmix_logmel_phase_clock(long long* out, int n_blocks) {
   if (n_blocks > pcgmix::kMelClockBlocks) return hipErrorInvalidValue;
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcgmix::g_logmel_clock), (size_t)n_blocks * 8 * sizeof(long long));
@@ -668,37 +745,6 @@ extern "C" int pcgmix_logmel_tables(int n_fft, int n_mels, float fmin, float fma
     cs[j] = std::cos(ang);
     sn[j] = std::sin(ang);
     win[j] = 0.5 - 0.5 * cs[j];
-  }
-  double* afrag = reinterpret_cast<double*>(base);
-  const int nh = n_fft / 2, nq = n_fft / 4;
-  for (int mt = 0; mt < tb.m_mfma; ++mt)
-    for (int ks = 0; ks < tb.ksteps; ++ks)
-      for (int l = 0; l < 64; ++l) {
-        const int bin = 2 * (16 * (mt >> 1) + (l & 15)) + (mt & 1), n = 4 * ks + (l >> 4);
-        double vr = 0.0, vi = 0.0;
-        if (bin < tb.n_bins && n <= nq) {
-          const int idx = (int)(((long long)bin * n) % n_fft);
-          const double c = (n == 0 || n == nq) ? 0.5 : 1.0;
-          vr = c * cs[idx];
-          vi = -c * sn[idx];
-        }
-        double* dst = afrag + ((size_t)mt * tb.ksteps + ks) * 128;
-        dst[l] = vr;
-        dst[64 + l] = vi;
-      }
-  {
-    double* wt = reinterpret_cast<double*>(base + tb.off_win);
-    for (int n = 0; n <= nh; ++n) wt[n] = win[n];
-  }
-  {
-    double* left = reinterpret_cast<double*>(base + tb.off_left);
-    for (int lb = 0; lb < tb.n_left; ++lb)
-      for (int k = 1; k <= nh; ++k) {
-        const int bin = 16 * tb.m_mfma + lb;
-        const int idx = (int)(((long long)bin * k) % n_fft);
-        left[((size_t)lb * nh + (k - 1)) * 2] = win[k % n_fft] * cs[idx] * (k == nh ? 0.5 : 1.0);
-        left[((size_t)lb * nh + (k - 1)) * 2 + 1] = k == nh ? 0.0 : -win[k % n_fft] * sn[idx];
-      }
   }
   // librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax, htk=False, norm='slaney', dtype=float32)
   std::vector<double> melf(n_mels + 2);
@@ -726,14 +772,61 @@ extern "C" int pcgmix_logmel_tables(int n_fft, int n_mels, float fmin, float fma
     krange[2 * m] = lo;
     krange[2 * m + 1] = hi;
   }
+  // The matrix tiles start at the lowest bin a filter reads, rounded down to even (every bin a filter
+  // reads must stay covered by the tiles plus the VALU rows, and the rows must exist in `ps`).
+  int bin_lo = 0, used = 0;
   {
-    int top = -1;                                   // highest bin any filter reads
-    for (int m = 0; m < n_mels; ++m) top = krange[2 * m + 1] > top ? krange[2 * m + 1] : top;
-    int used = top - 16 * tb.m_mfma + 1;
-    used = used < 0 ? 0 : (used > tb.n_left ? tb.n_left : used);
+    int low = tb.n_bins, top = -1;
+    for (int m = 0; m < n_mels; ++m) {
+      if (krange[2 * m + 1] < krange[2 * m]) continue;           // empty filter
+      low = krange[2 * m] < low ? krange[2 * m] : low;
+      top = krange[2 * m + 1] > top ? krange[2 * m + 1] : top;
+    }
+    if (top >= 0) {
+      bin_lo = low & ~1;
+      const int cover = 16 * tb.m_mfma + tb.n_left;              // bins the tiles + VALU rows span
+      if (bin_lo + cover > 16 * tb.m_tiles) bin_lo = (16 * tb.m_tiles - cover) & ~1;
+      if (bin_lo < 0 || bin_lo + cover <= top) bin_lo = 0;       // cannot shift: the plain layout
+      used = top - (bin_lo + 16 * tb.m_mfma) + 1;
+      used = used < 0 ? 0 : (used > tb.n_left ? tb.n_left : used);
+    }
     int32_t* meta = reinterpret_cast<int32_t*>(base + tb.off_meta);
     meta[0] = used;
-    meta[1] = 0;
+    meta[1] = bin_lo;
+  }
+  double* afrag = reinterpret_cast<double*>(base);
+  const int nh = n_fft / 2, nq = n_fft / 4;
+  for (int tp = 0; tp < tb.m_mfma / 2; ++tp)
+    for (int ks = 0; ks < tb.ksteps; ++ks)
+      for (int par = 0; par < 2; ++par)
+        for (int l = 0; l < 64; ++l) {
+          const int bin = bin_lo + 2 * (16 * tp + (l & 15)) + par, n = 4 * ks + (l >> 4);
+          double vr = 0.0, vi = 0.0;
+          if (bin < tb.n_bins && n <= nq) {
+            const int idx = (int)(((long long)bin * n) % n_fft);
+            const double c = (n == 0 || n == nq) ? 0.5 : 1.0;
+            vr = c * cs[idx];
+            vi = -c * sn[idx];
+          }
+          double* dst = afrag + ((size_t)tp * tb.ksteps + ks) * 256 + 128 * par;
+          dst[l] = vr;
+          dst[64 + l] = vi;
+        }
+  {
+    double* wt = reinterpret_cast<double*>(base + tb.off_win);
+    for (int n = 0; n <= nh; ++n) wt[n] = win[n];
+  }
+  {
+    double* left = reinterpret_cast<double*>(base + tb.off_left);
+    const int ncol = nh + kLeftPad;
+    for (int lb = 0; lb < tb.n_left; ++lb)
+      for (int k = 1; k <= ncol; ++k) {
+        const int bin = bin_lo + 16 * tb.m_mfma + lb;
+        const bool real = bin < tb.n_bins && k <= nh;             // zero columns behind the row
+        const int idx = (int)(((long long)bin * (k <= nh ? k : 0)) % n_fft);
+        left[((size_t)lb * ncol + (k - 1)) * 2] = real ? win[k % n_fft] * cs[idx] * (k == nh ? 0.5 : 1.0) : 0.0;
+        left[((size_t)lb * ncol + (k - 1)) * 2 + 1] = (!real || k == nh) ? 0.0 : -win[k % n_fft] * sn[idx];
+      }
   }
   return hipSuccess;
 }

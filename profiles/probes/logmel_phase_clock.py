@@ -47,3 +47,13 @@ u, cnt = np.unique(cu, return_counts=True)
 print("blocks per CU: %d CUs used, max %d blocks on one CU; blocks per XCC:" % (len(u), cnt.max()), np.bincount(xcc.astype(int)))
 late = np.argsort(us[:, 0])[::-1][:8]
 print("latest entries: block, entry us, CU id:", [(int(b), float(us[b, 0].round(1)), hex(int(cu[b]))) for b in late])
+
+wbuf = (ctypes.c_longlong * 64)()
+assert raw.pcgmix_logmel_wave_clock(wbuf) == 0
+w = np.frombuffer(wbuf, dtype=np.int64).reshape(16, 4)
+t7 = t[7]
+print("block 7, per wave (us after the staging barrier): VALU rows done | first unit done | second unit done")
+for i in range(16):
+    r = [(w[i, j] - t7[1]) / 100.0 if w[i, j] >= t7[1] else float("nan") for j in range(4)]
+    print("  wave %2d: %6.2f %6.2f %6.2f   (VALU rows started %.2f)" % (i, r[0], r[1], r[2], r[3]))
+print("  matrix phase of block 7: %.2f us" % ((t7[2] - t7[1]) / 100.0))
