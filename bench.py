@@ -494,12 +494,13 @@ def secondary_kernel_times(device, B=256, iters=50):
     lm = out["logmel_256x5000"]
     lm["roofline"] = {"bound": "mfma_f64", "achieved": lm_flop / lm["us"] / 1e6, "unit": "TFLOP/s",
                       "peak": 78.6, "frac": lm_flop / lm["us"] / 1e6 / 78.6,
-                      "measured_issue_rate_peak": 32.0,
-                      "frac_of_measured_rate": lm_flop / lm["us"] / 1e6 / 32.0,
+                      "measured_issue_rate_peak": 64.0,
+                      "frac_of_measured_rate": lm_flop / lm["us"] / 1e6 / 64.0,
                       "flop_per_launch": lm_flop,
                       "executed_flop_per_launch": B * 2 * (2.0 * 64 * 36 * 160),
                       "note": "peak = data-sheet FP64 matrix rate; the instruction's measured issue rate on "
-                              "this part is 32 TFLOP/s (profiles/probes/mfma_f64_rate.hip).  flop_per_launch "
+                              "this part is 64 TFLOP/s with four waves per SIMD feeding it (profiles/probes/f64_valu_rate.hip; "
+                              "32 with one dependent chain per wave, profiles/probes/mfma_f64_rate.hip).  flop_per_launch "
                               "keeps rounds 1-3's definition (real-input fold, K = 68); since round 4 the "
                               "kernel EXECUTES executed_flop_per_launch: even and odd bins as separate "
                               "products with K = 36 (second fold, DESIGN.md §3.4) + 5 bins on the f64 VALU"}
