@@ -508,6 +508,18 @@ int pcgmix_potes_head_bwd_f32(const float* dlogits, const float* z, const uint8_
 int pcgmix_potes_head_saliency_f32(const float* x, const float* w1, const float* b1, const float* w2,
                                    const float* seed, float* partial, float* dz, float* dx, int B,
                                    int K, int C, pcgmix_stream_t stream);
+/* The whole saliency pass of a frozen CNN_potes (saliency.py:26-91 with models.py:444-465 as the
+ * model) in one call: the six launches of pcgmix_potes_stack_fwd_save_f32 ->
+ * pcgmix_potes_head_saliency_f32 -> pcgmix_potes_stack_input_grad_mask_f32 ->
+ * pcgmix_saliency_post_f32 back to back.  x (B,4,T); c*: conv stack weights; h*: head weights
+ * (hb1 may be NULL); h2, m2, s1, partial, dz, gfeat, gx: the intermediate buffers of those entry
+ * points (sizes as documented there); frames (B,5) device; sal (B,T) out.            [device]   */
+int pcgmix_potes_saliency_pass_f32(const float* x, const float* cw1, const float* cb1, const float* cw2,
+                                   const float* cb2, float* h2, uint8_t* m2, uint8_t* s1,
+                                   const float* hw1, const float* hb1, const float* hw2,
+                                   const float* seed, float* partial, float* dz, float* gfeat, float* gx,
+                                   const int32_t* frames, float* sal, int ksize, double sigma, int B,
+                                   int T, int K, int n_classes, pcgmix_stream_t stream);
 long long pcgmix_potes_head_loss_workspace_floats(int B);
 int pcgmix_potes_head_loss_fwd_f32(const float* x, const uint8_t* mask1, float scale1, int thr1,
                                    int bits1, const float* w1, const float* b1, const uint8_t* mask2,

@@ -42,6 +42,8 @@ SIGNATURES = {
                                           _c_int, _ptr]),
     "pcgmix_saliency_post2d_f32": (_c_int, [_ptr, _ptr, _ptr, _c_int, ctypes.c_double, _c_int, _c_int,
                                             _c_int, _ptr]),
+    "pcgmix_potes_saliency_pass_f32": (_c_int, [_ptr] * 18 + [_c_int, ctypes.c_double, _c_int, _c_int, _c_int, _c_int,
+                                                 _ptr]),
     "pcgmix_salopt_workspace_bytes": (ctypes.c_longlong, [_c_int]),
     "pcgmix_salopt_disp_f32": (_c_int, [_ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _ptr, _c_int, _c_int,
                                         _c_int, _ptr]),

@@ -1263,6 +1263,29 @@ extern "C" int pcgmix_ctx_salopt_finish(pcgmix_ctx* c, const float* x, float* y,
   return (int)slot_commit(c, my_slot, s);
 }
 
+// The frozen CNN_potes saliency pass in ONE call: conv stack forward saving its routing -> head
+// (split-K product, dz = (z > 0) * (seed W2), dx = dz W1) -> input gradient from the routing ->
+// post-processing.  The same six launches as the four entry points it strings together
+// (pcgmix_potes_stack_fwd_save_f32, pcgmix_potes_head_saliency_f32,
+// pcgmix_potes_stack_input_grad_mask_f32, pcgmix_saliency_post_f32), without a trip through the
+// binding between them: the GPU idled 4-5 us in front of the input gradient and of the forward
+// while Python assembled the next call (profiles/r4_cfg3_step_timeline.txt).
+extern "C" int pcgmix_potes_saliency_pass_f32(
+    const float* x, const float* cw1, const float* cb1, const float* cw2, const float* cb2, float* h2,
+    uint8_t* m2, uint8_t* s1, const float* hw1, const float* hb1, const float* hw2, const float* seed,
+    float* partial, float* dz, float* gfeat, float* gx, const int32_t* frames, float* sal, int ksize,
+    double sigma, int B, int T, int K, int n_classes, pcgmix_stream_t stream) {
+  if (B <= 0 || T <= 0) return hipErrorInvalidValue;
+  int err = pcgmix_potes_stack_fwd_save_f32(x, cw1, cb1, cw2, cb2, h2, m2, s1, B * 4, T, nullptr, 0, nullptr, 0,
+                                            stream);
+  if (err) return err;
+  err = pcgmix_potes_head_saliency_f32(h2, hw1, hb1, hw2, seed, partial, dz, gfeat, B, K, n_classes, stream);
+  if (err) return err;
+  err = pcgmix_potes_stack_input_grad_mask_f32(gfeat, m2, s1, cw1, cw2, gx, B * 4, T, stream);
+  if (err) return err;
+  return pcgmix_saliency_post_f32(gx, frames, sal, ksize, sigma, B, 4, T, stream);
+}
+
 // Diagnostic: mean host nanoseconds per call spent in the 8 phases of pcgmix_augment_plain_f32
 // since the last query (label kernel launch | slot reserve | pack + seed | label wait | grouping +
 // permutation | H2D enqueue | kernel launch | event record); resets the accumulators.

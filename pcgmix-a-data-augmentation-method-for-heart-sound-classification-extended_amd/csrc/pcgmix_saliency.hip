@@ -50,6 +50,17 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
 // reference's 101 taps, instead of one ds_read_b32 per multiply-add): 25 -> ~10 us at bs=256.
 // KS == 0: any odd ksize <= 255, one output per thread per round.  Taps are applied in ascending
 // order either way.
+// Probe builds only (-DPCGMIX_PHASE_CLOCK, profiles/probes/salpost_phase_clock.py).
+#ifdef PCGMIX_PHASE_CLOCK
+__device__ long long g_salpost_clock[1024 * 8];
+#define PCGMIX_SCLOCK(i)                                                                     \
+  do {                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_salpost_clock[blockIdx.x * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define PCGMIX_SCLOCK(i) do { } while (0)
+#endif
+
 template <int KS>
 __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
     const float* __restrict__ grad, const int32_t* __restrict__ frames, float* __restrict__ sal,
@@ -61,6 +72,7 @@ __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
   const int a_len = (T + ksize - 1 + 8 + 3) & ~3;   // +8: the last window may start up to 7 past T
   float* a = smem;                  // a[half + t]
   float* s = smem + a_len;          // s[t]
+  PCGMIX_SCLOCK(0);
   int f4 = frames[b * 5 + 4];
   f4 = f4 < 0 ? 0 : (f4 > T ? T : f4);
 
@@ -101,6 +113,7 @@ __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
     }
   }
   __syncthreads();
+  PCGMIX_SCLOCK(1);
 
   float lmin = INFINITY;
   if (KS > 0) {
@@ -138,7 +151,9 @@ __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
       lmin = fminf(lmin, acc);
     }
   }
+  PCGMIX_SCLOCK(2);
   const float rmin = block_reduce(lmin, red, false);
+  PCGMIX_SCLOCK(3);
   float lmax = -INFINITY;
   for (int t = threadIdx.x; t < T; t += kSalThreads) {
     const float v = __fsub_rn(s[t], rmin);  // saliency.py:83
@@ -146,11 +161,13 @@ __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
     lmax = fmaxf(lmax, v);
   }
   const float rmax = block_reduce(lmax, red, true);
+  PCGMIX_SCLOCK(4);
   for (int t = threadIdx.x; t < T; t += kSalThreads) {
     float v = __fdiv_rn(s[t], rmax);  // saliency.py:84; 0/0 -> NaN -> 0 (saliency.py:87)
     if (v != v) v = 0.f;
     sal[(size_t)b * T + t] = v;
   }
+  PCGMIX_SCLOCK(5);
 }
 
 // Spectrogram saliency (saliency.py:93-113, dim = 2): |grad| of a (F, W) image -> zero the columns
@@ -648,6 +665,10 @@ __global__ void salopt_finalize_kernel(const float2* __restrict__ part, int32_t*
 }  // namespace pcgmix
 
 #ifdef PCGMIX_PHASE_CLOCK
+extern "C" int pcgmix_salpost_phase_clock(long long* out, int n_blocks) {
+  if (n_blocks > 1024) return hipErrorInvalidValue;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcgmix::g_salpost_clock), (size_t)n_blocks * 8 * sizeof(long long));
+}
 extern "C" int pcgmix_disp_phase_clock(long long* out, int n_blocks) {
   if (n_blocks > pcgmix::kDispClockBlocks) return hipErrorInvalidValue;
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcgmix::g_disp_clock), (size_t)n_blocks * 8 * sizeof(long long));

@@ -137,6 +137,32 @@ class _PotesChain:
         self.s1 = torch.empty(lib.pcgmix_potes_mask_bytes(self.N, T, 1), **u8)
         self.partial = torch.empty((lib.pcgmix_skinny_linear_splits(B, self.K), B, 20), **f32)
         self.dz, self.gfeat = torch.empty((B, 20), **f32), torch.empty((B, self.K), **f32)
+        self._pass_args = None      # pointer block of pass_into(), built on first use
+
+    def pass_into(self, data: torch.Tensor, seed: torch.Tensor, frames_dev_ptr: int, gauss_k_n: int,
+                  sal: torch.Tensor, gx: torch.Tensor) -> None:
+        """forward + backward + post-processing as ONE library call (pcgmix_potes_saliency_pass_f32)
+        into ``sal`` (B,T); ``gx`` (B,4,T) receives the input gradient.  The model is frozen
+        (saliency.py:26-51): its weight pointers are looked up once."""
+        B, C, T = self.shape
+        if tuple(data.shape) != self.shape or data.dtype != torch.float32 or not data.is_contiguous():
+            raise ValueError("batch does not match the saliency chain's shape")
+        if self._pass_args is None:
+            m = self.m
+            w1, b1, w2, b2 = self._weights()
+            W1, W2 = m.dimreduc.weight.detach().contiguous(), m.linear.weight.detach().contiguous()
+            bh = m.dimreduc.bias.detach().contiguous() if m.dimreduc.bias is not None else None
+            self._keep = (w1, b1, w2, b2, W1, W2, bh)          # the storages behind the pointers
+            self._pass_args = (w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                               self.h2.data_ptr(), self.m2.data_ptr(), self.s1.data_ptr(), W1.data_ptr(),
+                               bh.data_ptr() if bh is not None else None, W2.data_ptr())
+        a = self._pass_args
+        stream = ctypes.c_void_p(torch.cuda.current_stream(data.device).cuda_stream)
+        _lib.check(_lib.load().pcgmix_potes_saliency_pass_f32(
+            data.data_ptr(), a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], seed.data_ptr(),
+            self.partial.data_ptr(), self.dz.data_ptr(), self.gfeat.data_ptr(), gx.data_ptr(),
+            frames_dev_ptr, sal.data_ptr(), gauss_k_n, ctypes.c_double((12 / 101) * gauss_k_n), B, T,
+            self.K, self.ncls, stream), "pcgmix_potes_saliency_pass_f32")
 
     def _weights(self):
         m = self.m
@@ -284,8 +310,10 @@ class _SaliencyGraph:
         self.eager = self.chain is not None and CHAIN_EAGER
         if self.eager:
             self.graph = None
-            self.chain.forward(self.x)
-            self.sal = self._run()
+            # one library call per pass into buffers owned here (valid until the next pass)
+            self.sal = torch.empty((B, T), dtype=torch.float32, device=device)
+            self.gx = torch.empty((B, C, T), dtype=torch.float32, device=device)
+            self.chain.pass_into(self.x, self.seed, self.fr.data_ptr(), self.k, self.sal, self.gx)
             return
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -306,14 +334,14 @@ class _SaliencyGraph:
         return saliency_post(grad, self.fr.data_ptr(), self.k)
 
     def _enqueue(self, data):
+        if self.eager:
+            self.chain.pass_into(data.detach(), self.seed, self.fr.data_ptr(), self.k, self.sal, self.gx)
+            return
         if self.chain is not None:
             self.chain.forward(data.detach())
         else:
             self.x.copy_(data, non_blocking=True)
-        if self.eager:
-            self.sal = self._run()
-        else:
-            self.graph.replay()
+        self.graph.replay()
 
     def replay(self, data):
         """``seed`` and ``fr`` are in place (``pcgmix_ctx_salopt_begin`` on this stream): run the
