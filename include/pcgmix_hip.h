@@ -245,6 +245,14 @@ int pcgmix_salopt_disp_hosted_f32(const float* sal, const int32_t* frames, const
                                   float lam, int mode, int32_t* disp, void* workspace, int max_len,
                                   int B, int T, pcgmix_stream_t stream, const int32_t* frames_host,
                                   const int32_t* mix_host);
+/* Host only: that launch plan, for inspection and tests.  ids_out receives up to `cap` block ids
+ * ((sample << 4) | (state << 2) | slice: slice z of pair (sample, state) holds the displacements
+ * 256 z .. 256 z + 255, + 1024, ...) in launch order — longest chain of sums first; a pair without a
+ * search (equal lengths) is represented by its slice 0.  Returns the number of blocks, 0 when no plan
+ * is made for this shape (B > 256 or more than 1408 blocks: the full grid is launched), < 0 for
+ * bad arguments.                                                                        [host]   */
+int pcgmix_salopt_plan(const int32_t* frames_host, const int32_t* mix_host, int B, int T, int max_len,
+                       uint16_t* ids_out, int cap);
 /* The saliency-guided splice — mixup_keepdur_multidim_tensors_salopt for the whole batch
  * (augmentations.py:210-287 with :60-128, the loop at :909-917, magnitude_warp :674-683) — in one
  * call: the search above, then pcgmix_mix_warp_f32's kernel, whose blocks reduce the search's

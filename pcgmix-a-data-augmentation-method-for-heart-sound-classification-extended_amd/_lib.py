@@ -49,6 +49,7 @@ SIGNATURES = {
                                         _c_int, _ptr]),
     "pcgmix_salopt_disp_hosted_f32": (_c_int, [_ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _ptr, _c_int, _c_int,
                                                _c_int, _ptr, _ptr, _ptr]),
+    "pcgmix_salopt_plan": (_c_int, [_ptr, _ptr, _c_int, _c_int, _c_int, _ptr, _c_int]),
     "pcgmix_salopt_mix_warp_f32": (_c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _c_float, _c_int, _ptr, _ptr,
                                             _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_potes_head_saliency_f32": (_c_int, [_ptr] * 8 + [_c_int, _c_int, _c_int, _ptr]),

@@ -844,6 +844,20 @@ bool pcgmix::plan_salopt_blocks(const int32_t* frames_h, const int32_t* mix_h, c
   return true;
 }
 
+// Host only: the launch plan of pcgmix_salopt_disp_hosted_f32 for inspection and tests.  ids_out
+// receives up to `cap` block ids ((sample << 4) | (state << 2) | slice) in launch order; returns
+// their number, 0 when no plan is made for this shape (B > 256, more blocks than a plan holds),
+// or a negative value for bad arguments.
+extern "C" int pcgmix_salopt_plan(const int32_t* frames_host, const int32_t* mix_host, int B, int T,
+                                  int max_len, uint16_t* ids_out, int cap) {
+  if (!frames_host || !mix_host || !ids_out || B <= 0 || T <= 0 || cap < 0) return -1;
+  pcgmix::DispPlan plan;
+  if (!pcgmix::plan_salopt_blocks(frames_host, mix_host, nullptr, B, T, max_len, &plan)) return 0;
+  const int n = plan.n < cap ? plan.n : cap;
+  for (int i = 0; i < n; ++i) ids_out[i] = plan.e[i];
+  return plan.n;
+}
+
 // pcgmix_salopt_disp_f32 for a caller that also holds the boundaries and the partners on the HOST
 // (the reference's own situation: augmentations.py:210-287 receives them as CPU arrays): the
 // launch then consists of the blocks that have candidates, longest chain first.

@@ -396,3 +396,43 @@ def test_npdraw_cancels_wrong_guesses_and_survives_fork():
     assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
     draw(131, 1.0, 0.2, 6144)                        # the parent's workers are still there
     lib.pcgmix_npdraw_destroy(h)
+
+
+def test_salopt_launch_plan_covers_every_slice_longest_first():
+    """pcgmix_salopt_plan (host): the planned launch of the displacement search lists exactly the
+    slices that have candidates — slice z of a pair holds d = 256 z .. 256 z + 255 (+ 1024 ...) of
+    d = 0 .. |n1 - n2| — plus slice 0 of every pair without a search, ordered by the length of the
+    block's chain of sums (own state's length x passes) in steps of 16, longest first; no plan
+    beyond 256 samples or 1408 blocks."""
+    import ctypes
+    from pcgmix_amd import _lib, synthetic
+    lib = _lib.load()
+    for B, seed in ((256, 0), (37, 3), (1, 5)):
+        frames = synthetic.make_index_data(B, 5000, sample_rate=2000, seed=seed)[0].astype(np.int32)
+        mix = np.random.RandomState(seed).permutation(B).astype(np.int32)
+        ids = np.zeros(4096, dtype=np.uint16)
+        n = lib.pcgmix_salopt_plan(frames.ctypes.data, mix.ctypes.data, B, 5000, 0, ids.ctypes.data, len(ids))
+        L = np.diff(frames, axis=1)
+        want, cost = set(), {}
+        for b in range(B):
+            for k in range(4):
+                n1, n2 = int(L[b, k]), int(L[mix[b], k])
+                dm = abs(n1 - n2)
+                zs = [0] if dm == 0 else [z for z in range(4) if z * 256 <= dm]
+                for z in zs:
+                    bid = (b << 4) | (k << 2) | z
+                    want.add(bid)
+                    cost[bid] = 0 if dm == 0 else min((n1 * ((dm - z * 256) // 1024 + 1)) >> 4, 511)
+        assert n == len(want) and set(ids[:n].tolist()) == want
+        c = [cost[i] for i in ids[:n].tolist()]
+        assert c == sorted(c, reverse=True)
+    # too many samples / too many blocks: no plan
+    frames = synthetic.make_index_data(300, 5000, sample_rate=2000, seed=0)[0].astype(np.int32)
+    mix = np.arange(300, dtype=np.int32)[::-1].copy()
+    ids = np.zeros(8, dtype=np.uint16)
+    assert lib.pcgmix_salopt_plan(frames.ctypes.data, mix.ctypes.data, 300, 5000, 0, ids.ctypes.data, 8) == 0
+    wide = np.where((np.arange(256) % 2 == 0)[:, None], np.array([0, 100, 200, 300, 400]),
+                    np.array([0, 1000, 2000, 3000, 4000])).astype(np.int32)
+    mixw = (np.arange(256) ^ 1).astype(np.int32)
+    assert lib.pcgmix_salopt_plan(wide.ctypes.data, mixw.ctypes.data, 256, 5000, 0, ids.ctypes.data, 8) == 0
+    assert lib.pcgmix_salopt_plan(None, mixw.ctypes.data, 256, 5000, 0, ids.ctypes.data, 8) < 0
