@@ -436,3 +436,85 @@ def test_salopt_launch_plan_covers_every_slice_longest_first():
     mixw = (np.arange(256) ^ 1).astype(np.int32)
     assert lib.pcgmix_salopt_plan(wide.ctypes.data, mixw.ctypes.data, 256, 5000, 0, ids.ctypes.data, 8) == 0
     assert lib.pcgmix_salopt_plan(None, mixw.ctypes.data, 256, 5000, 0, ids.ctypes.data, 8) < 0
+
+
+def _mel_table_layout(n_fft, n_mels):
+    """The blob layout of pcgmix_logmel_tables (pcgmix_logmel.hip: mel_tables)."""
+    n_bins = n_fft // 2 + 1
+    tpp = n_bins // 32
+    rem = n_bins - 32 * tpp
+    if tpp >= 1 and rem <= 8:
+        n_left = rem
+    else:
+        tpp, n_left = (n_bins + 31) // 32, 0
+    ksteps = (n_fft // 4 + 1 + 3) // 4
+    o = 2 * tpp * ksteps * 2 * 64 * 8
+    off_wts = o
+    o = (o + n_mels * n_bins * 4 + 7) & ~7
+    off_kr = o
+    o = (o + n_mels * 8 + 7) & ~7
+    off_left = o
+    o += n_left * (n_fft // 2 + 8) * 16
+    off_win = o
+    o += (n_fft // 2 + 1) * 8
+    return dict(n_bins=n_bins, tpp=tpp, n_left=n_left, ksteps=ksteps, off_wts=off_wts, off_kr=off_kr,
+                off_left=off_left, off_win=off_win, off_meta=o, total=(o + 8 + 15) & ~15)
+
+
+@pytest.mark.parametrize("sr,n_fft", [(2000.0, 136), (1000.0, 68), (4000.0, 272)])
+def test_logmel_tables_are_the_windowed_transform(sr, n_fft):
+    """pcgmix_logmel_tables (host): the doubly folded twiddle fragments (window on the data side,
+    even / odd bins, columns n = 0 .. n_fft/4 with weights 1/2 at both ends), the single-fold rows of
+    the bins beyond the tiles, the window and bin_lo / n_left_used, evaluated in numpy exactly as the
+    kernel evaluates them, give rfft(hann * frame) for every bin a mel filter reads."""
+    import ctypes
+    from pcgmix_amd import _lib
+    lib = _lib.load()
+    n_mels = 128
+    lay = _mel_table_layout(n_fft, n_mels)
+    assert lib.pcgmix_logmel_tables_size(n_fft, n_mels) == lay["total"]
+    blob = np.zeros(lay["total"], dtype=np.uint8)
+    assert lib.pcgmix_logmel_tables(n_fft, n_mels, ctypes.c_float(25.0), ctypes.c_float(sr / 2),
+                                    ctypes.c_float(sr), blob.ctypes.data) == 0
+    N, H, Q = n_fft, n_fft // 2, n_fft // 4
+    tpp, ks, n_bins = lay["tpp"], lay["ksteps"], lay["n_bins"]
+    afrag = blob[:lay["off_wts"]].view(np.float64).reshape(tpp, ks, 4, 64)
+    kr = blob[lay["off_kr"]:lay["off_kr"] + n_mels * 8].view(np.int32).reshape(n_mels, 2)
+    left = blob[lay["off_left"]:lay["off_win"]].view(np.float64).reshape(lay["n_left"], H + 8, 2)
+    win = blob[lay["off_win"]:lay["off_meta"]].view(np.float64)
+    used, bin_lo = blob[lay["off_meta"]:lay["off_meta"] + 8].view(np.int32)
+    assert np.allclose(win, 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(H + 1) / N), atol=1e-15)
+    nonempty = kr[:, 1] >= kr[:, 0]
+    lo_bin, hi_bin = int(kr[nonempty, 0].min()), int(kr[nonempty, 1].max())
+    assert bin_lo % 2 == 0 and 0 <= bin_lo <= lo_bin and hi_bin < bin_lo + 32 * tpp + lay["n_left"]
+    rs = np.random.RandomState(n_fft)
+    x = rs.randn(N + 1).astype(np.float32).astype(np.float64)          # x[N] is not part of the frame
+    ref = np.fft.rfft(0.5 * (1 - np.cos(2 * np.pi * np.arange(N) / N)) * x[:N])
+    # the kernel's B operands, column n = 0 .. Q (column 0 pairs x[0] with itself)
+    n = np.arange(Q + 1)
+    hi_n = np.where(n == 0, 0, N - n)
+    u, v = win[n] * (x[n] + x[hi_n]), win[n] * (x[n] - x[hi_n])
+    m = H - n
+    u2, v2 = win[m] * (x[m] + x[H + n]), win[m] * (x[m] - x[H + n])
+    ops = [u + u2, v - v2, u - u2, v + v2]                              # even re, even im, odd re, odd im
+    got = {}
+    for tp in range(tpp):
+        for row in range(16):
+            for par in range(2):
+                b = bin_lo + 2 * (16 * tp + row) + par
+                lanes = row + 16 * np.arange(4)                       # lane = row + 16 * (n & 3), k-step n >> 2
+                coef = lambda q: np.array([afrag[tp, nn >> 2, q, lanes[nn & 3]] for nn in range(4 * ks)])
+                cre, cim = coef(2 * par), coef(2 * par + 1)
+                assert (cre[Q + 1:] == 0).all() and (cim[Q + 1:] == 0).all()
+                if b < n_bins:
+                    got[b] = complex(np.dot(cre[:Q + 1], ops[2 * par]), np.dot(cim[:Q + 1], ops[2 * par + 1]))
+    k = np.arange(1, H + 1)
+    for lb in range(lay["n_left"]):
+        b = bin_lo + 32 * tpp + lb
+        assert (left[lb, H:] == 0).all()                               # the zero columns behind the row
+        if b < n_bins:
+            got[b] = complex(np.dot(left[lb, :H, 0], x[k] + x[N - k]), np.dot(left[lb, :H, 1], x[k] - x[N - k]))
+    for b in range(lo_bin, hi_bin + 1):
+        assert b in got, b
+        assert abs(got[b] - ref[b]) <= 1e-12 * max(1.0, np.abs(ref).max()), (b, got[b], ref[b])
+    assert used == max(0, min(lay["n_left"], hi_bin - (bin_lo + 32 * tpp) + 1))
