@@ -237,10 +237,17 @@ __device__ __forceinline__ void mix_body(
         if (hit[e] && (clamped || d[e] != dsel)) mask |= 16 << e;
       }
       own[q] = *reinterpret_cast<const float4_a*>(x + own_base + ii);
-      // the zero-padded tail and the unmatched part of longer states never touch the partner
-      float4_u pz = {0.f, 0.f, 0.f, 0.f};
-      if (mask & 0xf) pz = *reinterpret_cast<const float4_u*>(x + par_base + (size_t)c * T + src0);
-      par[q] = pz;
+      // The zero-padded tail and the unmatched part of longer states never touch the partner row —
+      // but the load is NOT predicated: `if (mask & 0xf) pz = *p` compiles to a branch around the load
+      // with an `s_waitcnt vmcnt(0)` inside it, so a lane's second own/partner pair was issued only
+      // after its first had come back (two memory round trips per lane in the kernel that bounds the
+      // strict-signature step).  A quad without a blended element re-reads its own quad instead: the
+      // line is in flight already, no byte more leaves memory, and all 2 U loads are in flight together.
+      size_t poff = (mask & 0xf) ? par_base + (size_t)c * T + src0 : own_base + ii;
+      asm volatile("" : "+v"(poff));  // opaque (the OFFSET, so that the access stays a global load): otherwise the
+                                      // compiler reuses the own quad's RESULT for the fallback and predicates the
+                                      // partner load again, behind a wait for the own one
+      par[q] = *reinterpret_cast<const float4_u*>(x + poff);
       t0s[q] = t0;
       cs[q] = c;
       masks[q] = mask;
@@ -378,9 +385,10 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
       for (int cc = 0; cc < CG; ++cc) {
         const size_t row = (size_t)(c0 + cc) * T;
         own[q][cc] = *reinterpret_cast<const float4_a*>(x + own_base + row + t0s[q]);
-        float4_u pz = {0.f, 0.f, 0.f, 0.f};
-        if (masks[q] & 0xf) pz = *reinterpret_cast<const float4_u*>(x + par_base + row + src0s[q]);
-        par[q][cc] = pz;
+        // unpredicated, as in mix_body: a quad without a blended element re-reads its own quad
+        size_t poff = (masks[q] & 0xf) ? par_base + row + src0s[q] : own_base + row + t0s[q];
+        asm volatile("" : "+v"(poff));
+        par[q][cc] = *reinterpret_cast<const float4_u*>(x + poff);
       }
   };
   issue_loads(0);
@@ -508,11 +516,24 @@ __global__ __launch_bounds__(kThreads) void mix_warp_karg_kernel(
   if (b >= B) return;
   int m = pack_get(pack, kPackB * 5 + b);
   m = (m < 0 || m >= B) ? b : m;
+  // five boundaries = five consecutive halfwords = three consecutive dwords from (5 b) >> 1: fetched as
+  // three INDEPENDENT scalar loads per sample (own ones beside the partner index, the partner's behind
+  // it) and taken apart with shifts — one pack_get per boundary was a chain of eleven dependent loads
   int f1[5], f2[5];
+  {
+    const int j1 = (b * 5) >> 1, j2 = (m * 5) >> 1;
+    const int o1 = (b * 5) & 1, o2 = (m * 5) & 1;
+    const int a0 = pack.w[j1], a1 = pack.w[j1 + 1], a2 = pack.w[j1 + 2];
+    const int c0 = pack.w[j2], c1 = pack.w[j2 + 1], c2 = pack.w[j2 + 2];
+    auto half = [](int w0, int w1, int w2, int h) {       // halfword h (0..5) of three dwords, signed
+      const int w = h < 2 ? w0 : (h < 4 ? w1 : w2);
+      return (h & 1) ? (w >> 16) : ((int)((unsigned)w << 16) >> 16);
+    };
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    f1[k] = pack_get(pack, b * 5 + k);
-    f2[k] = pack_get(pack, m * 5 + k);
+    for (int k = 0; k < 5; ++k) {
+      f1[k] = half(a0, a1, a2, k + o1);
+      f2[k] = half(c0, c1, c2, k + o2);
+    }
   }
   StateMap sm;
 #pragma unroll
