@@ -87,18 +87,22 @@ __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
 #pragma unroll
       for (int u = 0; u < kPer; ++u) {
         const int t = base + u * kSalThreads + (int)threadIdx.x - half;
-        const bool in = t >= 0 && t < f4;      // saliency.py:66-67 zeroes t >= f[-1] before the sum
-        const float* g = grad + ((size_t)b * 4) * T + (in ? t : 0);
+        // clamped address, UNCONDITIONAL load, zero applied below: `in ? g[..] : 0` compiles to a branch
+        // around every load with an s_waitcnt inside it (31 of them in this loop's ISA)
+        const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        const float* g = grad + ((size_t)b * 4) * T + tc;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[u][c] = in ? g[(size_t)c * T] : 0.f;
+        for (int c = 0; c < 4; ++c) v[u][c] = g[(size_t)c * T];
       }
 #pragma unroll
       for (int u = 0; u < kPer; ++u) {
         const int i = base + u * kSalThreads + (int)threadIdx.x;
+        const int t = i - half;
+        const bool in = t >= 0 && t < f4;      // saliency.py:66-67 zeroes t >= f[-1] before the sum
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc = __fadd_rn(acc, fabsf(v[u][c]));
-        if (i < a_len) a[i] = acc;
+        if (i < a_len) a[i] = in ? acc : 0.f;
       }
     }
   } else {
