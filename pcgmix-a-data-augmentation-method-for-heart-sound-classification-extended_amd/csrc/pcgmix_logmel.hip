@@ -263,9 +263,17 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
     const int klo = krange[2 * m], khi = krange[2 * m + 1];
     reinterpret_cast<int*>(melw)[8 * m] = klo;
     reinterpret_cast<int*>(melw)[8 * m + 1] = khi;
+    // (clamped index, unconditional loads, zero applied behind them: a predicated load is a branch with
+    // its own wait — four memory round trips in a row in front of the staging barrier)
+    float wv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      melw[8 * m + 2 + j] = (klo + j <= khi) ? wts[m * n_bins + klo + j] : 0.f;
+    for (int j = 0; j < 4; ++j) {
+      int k = klo + j <= khi ? klo + j : khi;
+      k = k < 0 ? 0 : (k >= n_bins ? n_bins - 1 : k);
+      wv[j] = wts[m * n_bins + k];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) melw[8 * m + 2 + j] = (klo + j <= khi) ? wv[j] : 0.f;
   }
   // The padded row: LDS index i holds signal sample s = s0 + i.  Outside [0, len): zero
   // (numpy.pad 'constant') or the mirror image about the edge sample (numpy.pad 'reflect': the
