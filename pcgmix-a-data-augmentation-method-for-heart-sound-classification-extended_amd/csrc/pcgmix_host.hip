@@ -413,7 +413,6 @@ struct Slot {
   char* dev = nullptr;
   size_t cap = 0;
   hipEvent_t ev = nullptr;
-  hipEvent_t side_ev = nullptr;    // the slot's fetch on the context's side stream (fetch_ahead)
   bool busy = false;
 };
 
@@ -557,7 +556,6 @@ struct pcgmix_ctx {
   int sal_B = 0, sal_max_len = 0;  // what pcgmix_ctx_salopt_begin saw
   int32_t sal_frames_h[pcgmix::kPackB * 5];   // ... and the boundaries (B <= kPackB), for the search's plan
   bool sal_frames_known = false;
-  hipStream_t side = nullptr;      // fetch_ahead: a staging slot's fetch runs here, beside the caller's stream
 };
 
 // Host-to-device copy as a kernel launch (see fetch_kernel) for callers with their own pinned
@@ -609,9 +607,7 @@ extern "C" void pcgmix_ctx_destroy(pcgmix_ctx* c) {
     if (s.pinned) (void)hipHostFree(s.pinned);
     if (s.dev) (void)hipFree(s.dev);
     if (s.ev) (void)hipEventDestroy(s.ev);
-    if (s.side_ev) (void)hipEventDestroy(s.side_ev);
   }
-  if (c->side) (void)hipStreamDestroy(c->side);
   if (c->lab) (void)hipHostFree(c->lab);
   if (c->flag) (void)hipHostFree(c->flag);
   if (c->ws) (void)hipFree(c->ws);
@@ -706,25 +702,6 @@ hipError_t upload_slot(const Slot& sl, size_t nbytes, hipStream_t s) {
   hipLaunchKernelGGL(fetch_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                      reinterpret_cast<const uint4*>(sl.pinned), reinterpret_cast<uint4*>(sl.dev), n16);
   return hipGetLastError();
-}
-
-// The same fetch on the context's SIDE stream, with `s` made to wait for it: when the host is ahead
-// of the GPU (a captured training step: every input of the index block is host data, nothing is
-// read back) the fetch runs beside the previous step's kernels instead of in front of this step's
-// splice — 49 KB of warp knots are a 4 us launch on the critical path otherwise.  Blocks small
-// enough for the blit copy stay on `s`.  PCGMIX_FETCH_AHEAD=0 restores the in-stream fetch.
-hipError_t upload_slot_ahead(pcgmix_ctx* c, Slot& sl, size_t nbytes, hipStream_t s) {
-  static const bool on = [] {
-    const char* env = getenv("PCGMIX_FETCH_AHEAD");
-    return !env || atoi(env) != 0;
-  }();
-  if (!on || nbytes <= 16384) return upload_slot(sl, nbytes, s);
-  hipError_t e;
-  if (!c->side && (e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) return e;
-  if (!sl.side_ev && (e = hipEventCreateWithFlags(&sl.side_ev, hipEventDisableTiming)) != hipSuccess) return e;
-  if ((e = upload_slot(sl, nbytes, c->side)) != hipSuccess) return e;
-  if ((e = hipEventRecord(sl.side_ev, c->side)) != hipSuccess) return e;
-  return hipStreamWaitEvent(s, sl.side_ev, 0);
 }
 
 // Boundaries (int64 (B,5), host) validated against the signal length and packed as int32.
@@ -1044,10 +1021,12 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   // 4. partners: groups of equal label, each permuted by a fresh Random(step).sample
   draw_partners(c, labels, B, mix_out, st + (size_t)B * 5);
   lap(4);
-  // 5. one H2D copy (beside the stream's earlier work when nothing was read back), the launch, the
-  //    slot's event behind it
-  if ((e = readback ? upload_slot(sl, nbytes, s) : upload_slot_ahead(c, sl, nbytes, s)) != hipSuccess)
-    return (int)e;
+  // 5. one H2D copy, the launch, the slot's event behind it.  (Round 4 tried the fetch on a side
+  //    stream of the context, beside the previous step's kernels: PCGmix+ train step 129.0 -> 128.0 us,
+  //    but the extra HIP stream can share a hardware queue with the stream a PIPELINED step augments on
+  //    and serialise it — cfg3 train 229 -> 282 us inside the full bench; removed,
+  //    profiles/r4_magwarp_fetch_ahead.txt.)
+  if ((e = upload_slot(sl, nbytes, s)) != hipSuccess) return (int)e;
   lap(5);
   const int32_t* d = reinterpret_cast<const int32_t*>(sl.dev);
   const int err = pcgmix::launch_mix_warp(x, y, d, d + (size_t)B * 5, nullptr, lam, knots_dev, op_dev,
