@@ -89,6 +89,7 @@ def settle_heap():
     gc.freeze()
 
 
+HOST_AFFINITY = None
 STAMPS = [0.0] * 4096     # preallocated: per-call host clock reads of a traced region
 
 _SPIN = {}
@@ -722,6 +723,12 @@ def main():
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    # Host placement: this process (and the library's draw-ahead threads, created later) on a few CPUs
+    # of the NUMA node the GPU hangs off — what a launcher's numactl would do; disclosed in
+    # config.host_affinity.  PCGMIX_BENCH_NO_AFFINITY=1 leaves placement to the scheduler.
+    global HOST_AFFINITY
+    HOST_AFFINITY = ("left to the scheduler (PCGMIX_BENCH_NO_AFFINITY)" if os.environ.get("PCGMIX_BENCH_NO_AFFINITY")
+                     else hostprep.bind_host_threads(local, int(os.environ.get("LOCAL_RANK", "0"))))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -791,6 +798,7 @@ def main():
                                f"({B},{C},{T}) float32 per GPU (BASELINE.json configs[1])",
                    "batch_per_gpu": B, "channels": C, "sig_len": T, "method": a.method,
                    "parallelism": f"dp{world}",
+                   "host_affinity": HOST_AFFINITY,
                    "pre_settle": "before the W warm-up steps of every leg: heap collected + frozen, then 40 ms of "
                                  "neutral GPU work (GEMM + streaming add) to reach loaded clocks, see "
                                  "bench.settle_clocks"},

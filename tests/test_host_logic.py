@@ -518,3 +518,13 @@ def test_logmel_tables_are_the_windowed_transform(sr, n_fft):
         assert b in got, b
         assert abs(got[b] - ref[b]) <= 1e-12 * max(1.0, np.abs(ref).max()), (b, got[b], ref[b])
     assert used == max(0, min(lay["n_left"], hi_bin - (bin_lo + 32 * tpp) + 1))
+
+
+def test_bind_host_threads_is_a_noop_where_the_topology_is_unreadable():
+    """No GPU here: the helper must leave the mask alone and say why (bench.py prints the string)."""
+    import os
+    from pcgmix_amd import hostprep
+    before = os.sched_getaffinity(0)
+    msg = hostprep.bind_host_threads(0)
+    assert os.sched_getaffinity(0) == before
+    assert "pinned" not in msg and msg
