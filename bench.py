@@ -90,6 +90,7 @@ def settle_heap():
 
 
 HOST_AFFINITY = None
+ORIGINAL_CPUS = None   # the job's CPU mask before main() pinned the process
 STAMPS = [0.0] * 4096     # preallocated: per-call host clock reads of a traced region
 
 _SPIN = {}
@@ -284,7 +285,38 @@ def kernel_back_to_back_ms(method, B, C, T, rate, device, iters=200, per_launch=
     return float(np.median([a.elapsed_time(b) for a, b in pairs])), interval
 
 
+class _EveryAllowedCpu:
+    """The CPU baseline gets the whole host back: every thread of this process (torch's intra-op
+    pool may exist already, pinned with the rest in main()) on the mask the job started with for
+    the duration, each thread's own mask restored afterwards."""
+
+    def __enter__(self):
+        self.saved = {}
+        if ORIGINAL_CPUS is None or not hasattr(os, "sched_setaffinity"):
+            return self
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                self.saved[int(tid)] = os.sched_getaffinity(int(tid))
+                os.sched_setaffinity(int(tid), ORIGINAL_CPUS)
+            except OSError:
+                pass
+        return self
+
+    def __exit__(self, *exc):
+        for tid, mask in self.saved.items():
+            try:
+                os.sched_setaffinity(tid, mask)
+            except OSError:
+                pass
+        return False
+
+
 def cpu_baseline(method, B, C, T, rate, budget_s=12.0):
+    with _EveryAllowedCpu():
+        return _cpu_baseline(method, B, C, T, rate, budget_s)
+
+
+def _cpu_baseline(method, B, C, T, rate, budget_s):
     """CPU oracle on the host cores of this box: whole batches of the benchmark workload until
     about ``budget_s`` seconds of CPU work have been timed.  torch's intra-op thread count is
     first probed (1, 8, all cores; 3 batches each) and the fastest setting is used, so the
@@ -726,7 +758,8 @@ def main():
     # Host placement: this process (and the library's draw-ahead threads, created later) on a few CPUs
     # of the NUMA node the GPU hangs off — what a launcher's numactl would do; disclosed in
     # config.host_affinity.  PCGMIX_BENCH_NO_AFFINITY=1 leaves placement to the scheduler.
-    global HOST_AFFINITY
+    global HOST_AFFINITY, ORIGINAL_CPUS
+    ORIGINAL_CPUS = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     HOST_AFFINITY = ("left to the scheduler (PCGMIX_BENCH_NO_AFFINITY)" if os.environ.get("PCGMIX_BENCH_NO_AFFINITY")
                      else hostprep.bind_host_threads(local, int(os.environ.get("LOCAL_RANK", "0"))))
     dist = None
