@@ -384,26 +384,47 @@ def make_plan(method: str, labels, frames: np.ndarray, wav: Sequence[str], step:
     return plan
 
 
+def _gpu_numa_node(torch, index):
+    pr = torch.cuda.get_device_properties(index)
+    bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    with open("/sys/bus/pci/devices/%s/numa_node" % bus) as f:
+        return bus, int(f.read())
+
+
+def _slice_for(cpus, ordinal, n_cpus):
+    """``n_cpus`` of a node's CPU list for the ``ordinal``-th GPU of that node.  The first half of
+    the list are the physical cores where SMT siblings are listed behind them; the node's first
+    eight CPUs (interrupts, housekeeping) are left alone when there is room."""
+    phys = cpus[:max(2, len(cpus) // 2)]
+    n = max(2, min(n_cpus, len(phys)))
+    usable = phys[8:] if len(phys) - 8 >= n else phys
+    slot = ordinal % max(1, len(usable) // n)
+    return usable[slot * n:(slot + 1) * n]
+
+
 def bind_host_threads(device_index: int = 0, local_rank: int = 0, n_cpus: int = 8) -> str:
-    """Pin the calling process to ``n_cpus`` CPUs of the NUMA node its GPU hangs off (one slice per
-    local rank), and say what was done.  Threads created afterwards — the draw-ahead workers of
-    §3.6 — inherit the mask.  The strict-signature step is a host loop with one device->host hand-over
-    per call: left to the scheduler on a two-socket box the process migrates between 256 CPUs and
-    the step is 22.7-24.4 us; on four CPUs next to the GPU 20.4-20.5 us, on the remote socket 22.6-22.7
-    (MI355X box, ``profiles/r4_host_affinity.txt``).  The reference does not pin anything; a launcher
-    would normally do this (``numactl``), ``torch.distributed.run`` does not.  No-op (with the reason
-    in the returned string) wherever the topology cannot be read or leaves fewer than two CPUs."""
+    """Pin the calling process to ``n_cpus`` CPUs of the NUMA node its GPU hangs off (a slice of its
+    own for each GPU of that node), and say what was done.  Threads created afterwards — the
+    draw-ahead workers of §3.6 — inherit the mask.  The strict-signature step is a host loop with one
+    device->host hand-over per call: left to the scheduler on a two-socket box the process migrates
+    between 256 CPUs and the step is 22.7-24.4 us; on four CPUs next to the GPU 20.4-20.5 us, on the
+    remote socket 22.6-22.7 (MI355X box, ``profiles/r4_host_affinity.txt``).  The reference does not
+    pin anything; a launcher would normally do this (``numactl``), ``torch.distributed.run`` does
+    not.  ``local_rank`` only breaks ties where the other GPUs' nodes cannot be read.  No-op (with
+    the reason in the returned string) wherever the topology cannot be read or leaves fewer than two
+    CPUs."""
     import os
     if not hasattr(os, "sched_setaffinity"):
         return "no affinity API"
     try:
         import torch
-        pr = torch.cuda.get_device_properties(device_index)
-        bus = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
-        with open("/sys/bus/pci/devices/%s/numa_node" % bus) as f:
-            node = int(f.read())
+        bus, node = _gpu_numa_node(torch, device_index)
         if node < 0:
             return "GPU %s reports no NUMA node" % bus
+        try:        # which of this node's GPUs am I (device properties only: no context is created)
+            ordinal = sum(1 for j in range(device_index) if _gpu_numa_node(torch, j)[1] == node)
+        except Exception:
+            ordinal = local_rank
         with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
             cpus = []
             for part in f.read().strip().split(","):
@@ -418,12 +439,6 @@ def bind_host_threads(device_index: int = 0, local_rank: int = 0, n_cpus: int = 
     cpus = [c for c in cpus if c in allowed]
     if len(cpus) < 2:
         return "fewer than two CPUs of node %d allowed" % node
-    # the first half of a node's list are its physical cores where SMT siblings are listed behind
-    # them; leave the node's first CPUs (interrupts, housekeeping) alone when there is room
-    phys = cpus[:max(2, len(cpus) // 2)]
-    n = max(2, min(n_cpus, len(phys)))
-    skip = 8 if len(phys) >= 8 + n * (local_rank + 1) else 0
-    start = (skip + local_rank * n) % max(1, len(phys) - n + 1)
-    chosen = phys[start:start + n]
+    chosen = _slice_for(cpus, ordinal, n_cpus)
     os.sched_setaffinity(0, chosen)
     return "GPU %s on NUMA node %d: pinned to CPUs %d-%d" % (bus, node, chosen[0], chosen[-1])

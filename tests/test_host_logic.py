@@ -528,3 +528,19 @@ def test_bind_host_threads_is_a_noop_where_the_topology_is_unreadable():
     msg = hostprep.bind_host_threads(0)
     assert os.sched_getaffinity(0) == before
     assert "pinned" not in msg and msg
+
+
+def test_cpu_slices_of_one_node_do_not_overlap():
+    """Eight ranks of an 8-GPU host (four GPUs per socket, 64 cores + 64 SMT siblings per node):
+    every GPU of a node gets its own eight physical cores, none of them the node's first eight."""
+    from pcgmix_amd import hostprep
+    node1 = list(range(64, 128)) + list(range(192, 256))
+    seen = set()
+    for ordinal in range(4):
+        got = hostprep._slice_for(node1, ordinal, 8)
+        assert len(got) == 8 and not (set(got) & seen) and min(got) >= 72 and max(got) < 128
+        seen |= set(got)
+    assert hostprep._slice_for(node1, 0, 8) == list(range(72, 80))
+    # a small cgroup: whatever is there, at least two CPUs, never an empty mask
+    assert hostprep._slice_for([3, 4, 5, 6], 5, 8) == [3, 4]
+    assert hostprep._slice_for(list(range(16)), 1, 8) == list(range(8))
