@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 15
+#define PCGMIX_ABI_VERSION 16
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -698,6 +698,19 @@ int pcgmix_augment_plain_f32(pcgmix_ctx* ctx, const float* x, float* y,
                              const int64_t* labels_host, const int64_t* frames, uint64_t step,
                              float lam, const double* knots, int n_knots, int64_t* mix_out,
                              int B, int C, int T, pcgmix_stream_t stream);
+
+/* The armed plain step.  With target_ohe_dev given (the reference's signature: labels on the device,
+ * augmentations.py:501), no warp, B <= 256, T <= 32767, T % 4 == 0 and 16-byte aligned x, y,
+ * pcgmix_augment_plain_f32 enqueues ONE kernel at the start of the call: its first block does the
+ * label arg-max, its other blocks wait for the index records the host writes into host-mapped
+ * memory once it has drawn the partners (csrc/pcgmix_kernels.h, ArmedArgs).  Same output as the
+ * two-launch path (PCGMIX_NO_ARMED=1), bit for bit.  The waiting blocks give up `timeout_ticks`
+ * (100 MHz; default 1 s) after the kernel started; the call notices (records written later than
+ * 0.4 s after the launch: stream synchronisation, abort word) and launches the splice again.
+ * stats: out3 = steps armed | of them checked after a stream synchronisation | of them relaunched.
+ * debug (tests): the relays' timeout and a host stall in front of the record write; 0, 0 = defaults. */
+int pcgmix_ctx_armed_stats(pcgmix_ctx* ctx, long long* out3);
+int pcgmix_ctx_armed_debug(pcgmix_ctx* ctx, unsigned long long timeout_ticks, int stall_ms);
 
 /* Diagnostic: mean host nanoseconds per pcgmix_augment_plain_f32 call since the last query, by
  * phase: label kernel launch | slot reserve | pack + seed | label wait | grouping + permutation |

@@ -73,6 +73,55 @@ int launch_mix_karg(const float* x, float* y, const int16_t* frames16, const int
                     int B, int C, int T, hipStream_t s, const void* pay = nullptr, int pay_bytes = 0,
                     void* pay_dst = nullptr);
 
+// The plain splice launched BEFORE its index block exists ("armed"): a strict-signature step is the
+// chain  previous splice -> label arg-max -> host (labels -> partners) -> splice,  and with two
+// launches the host's reaction includes a launch (3 us) and the time the command processor takes to
+// start it (3-4 us).  Armed, ONE kernel is enqueued at the start of the call: its block (0,0) does
+// the label arg-max (labels under the step's token to host-mapped memory), then every
+// sample's first block polls that sample's 64-byte RECORD in host-mapped memory until the host has
+// written it, relays it to device memory, and the sample's other blocks pick it up there.
+// A record is six 8-byte words, each = (stamp << 32) | two int16 values; the stamp is the step's
+// sequence number, so a word is valid by itself (8-byte aligned loads and stores are single-copy
+// atomic on both sides): no flag, no ordering between words, no torn record.  Values: own
+// boundaries f[0..4], partner index, the partner's boundaries f[0..4], 0.
+// stamp | kArmedAbort in a record = "give up": written by the host (bad input after the launch) or
+// by a relay that saw nothing within timeout_ticks of the 100 MHz clock (then also *abort_h = seq);
+// every wave leaves without touching y.
+constexpr uint32_t kArmedAbort = 0x80000000u;
+constexpr int kArmedRecWords = 8;            // 64 bytes per sample, six words used
+struct ArmedArgs {
+  const int64_t* ohe;                        // (B, K) one-hot on the device
+  int K;
+  unsigned long long* lab64;                 // host-mapped: 64 words = (token << 32) | labels of rows 4l .. 4l+3,
+  uint32_t token;                            //   one byte each (K <= 256)
+  const unsigned long long* rec_h;           // host-mapped records (kPackB x kArmedRecWords)
+  unsigned long long* rec_d;                 // device relay of the same shape
+  uint32_t* abort_h;                         // host-mapped
+  uint32_t seq;                              // 1 .. 0x7fffffff
+  unsigned long long timeout_ticks;
+};
+int launch_mix_armed(const float* x, float* y, const ArmedArgs& a, float lam, int B, int C, int T,
+                     hipStream_t s, const void* pay = nullptr, int pay_bytes = 0,
+                     void* pay_dst = nullptr);
+// first maximum of row b of a (B, K) int64 one-hot matrix (torch.max / np.argmax, augmentations.py:501)
+__device__ __forceinline__ int onehot_argmax(const int64_t* __restrict__ ohe, int K, int b) {
+  const int64_t* row = ohe + (size_t)b * K;
+  if (K == 2 && !(reinterpret_cast<uintptr_t>(ohe) & 15)) {
+    // two classes (the reference's data sets): the row is ONE 16-byte load; the loop below is a load,
+    // a wait and a compare per class — two memory round trips in the kernel the host waits for
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    const ll2 v = *reinterpret_cast<const ll2*>(row);
+    return v.y > v.x ? 1 : 0;
+  }
+  int best = 0;
+  int64_t bv = row[0];
+  for (int c = 1; c < K; ++c) {
+    const int64_t v = row[c];
+    if (v > bv) { bv = v; best = c; }
+  }
+  return best;
+}
+
 // pcgmix_saliency.hip: the displacement search of pcgmix_salopt_disp_f32; disp == nullptr leaves
 // the per-block results in `workspace` for launch_mix_warp's disp_part.
 // pay_*: pay_n16 16-byte words that one otherwise idle block copies from pay_src (device-readable

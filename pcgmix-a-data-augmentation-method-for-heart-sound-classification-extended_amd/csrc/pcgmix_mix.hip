@@ -156,7 +156,7 @@ __device__ __forceinline__ void mix_body(
     const float* __restrict__ x, float* __restrict__ y, float lam, float oml,
     const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots,
     const int32_t* __restrict__ zero_rect, int C, int T, int epb, int b, int m, const StateMap& sm,
-    double* lds) {
+    double* lds, int chunk = (int)blockIdx.x) {
   // optional zeroed rectangle (rows = index along C, columns = index along T), block-uniform
   int zr0 = 0, zr1 = 0, zc0 = 0, zc1 = 0;
   if (zero_rect) {
@@ -167,7 +167,7 @@ __device__ __forceinline__ void mix_body(
   }
 
   const int plane = C * T;
-  const int chunk0 = blockIdx.x * epb;
+  const int chunk0 = chunk * epb;
   const size_t own_base = (size_t)b * plane;
   const size_t par_base = (size_t)m * plane;
 
@@ -552,6 +552,110 @@ __global__ __launch_bounds__(kThreads) void mix_warp_karg_kernel(
   mix_body<4, WARP, U>(x, y, lam, oml, knots, spline_op, n_knots, nullptr, C, T, epb, b, m, sm, lds);
 }
 
+// The plain splice armed before its index block exists (pcgmix_kernels.h, ArmedArgs).
+#ifdef PCGMIX_PHASE_CLOCK
+// probe build: per launch parity (seq & 1) and sample: block (0,b) entry | relay saw the host's record |
+// block (1,b) saw the relayed record | block (1,b) done; [..][kPackB] = block (0,0): entry | labels flagged
+__device__ long long g_armed_clock[2][kPackB + 1][4];
+#define PCGMIX_ACLOCK(b, i) g_armed_clock[a.seq & 1][b][i] = (long long)wall_clock64()
+#else
+#define PCGMIX_ACLOCK(b, i)
+#endif
+template <int U>
+__global__ __launch_bounds__(kThreads) void mix_armed_kernel(
+    const float* __restrict__ x, float* __restrict__ y, const ArmedArgs a, float lam, float oml,
+    int B, int C, int T, int epb, int chunks, const PayPack pay, uint4* __restrict__ pay_dst) {
+  extern __shared__ __align__(16) double lds[];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  if ((blockIdx.x | blockIdx.y) == 0) {
+    if (threadIdx.x == 0) { PCGMIX_ACLOCK(kPackB, 0); }
+    if (pay.n16 && (int)threadIdx.x < pay.n16) pay_dst[threadIdx.x] = pay.w[threadIdx.x];
+    // labels: ONE wave, lane l = rows 4l .. 4l+3, one byte each under the step's token in ONE 8-byte
+    // word — valid by itself like the records, so neither a fence nor a flag (and no wait for the
+    // stores to be acknowledged across the link) stands between the arg-max and the host
+    if (threadIdx.x < 64) {
+      unsigned long long w = (unsigned long long)a.token << 32;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * lane + j;
+        const int best = onehot_argmax(a.ohe, a.K, r < B ? r : B - 1);
+        w |= (unsigned long long)(r < B ? best & 0xff : 0) << (8 * j);
+      }
+      __hip_atomic_store(a.lab64 + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (threadIdx.x == 0) { PCGMIX_ACLOCK(kPackB, 1); }
+    }
+  }
+  if (b >= B) return;
+  const unsigned long long t0 = wall_clock64();
+  const uint32_t go = a.seq, stop = a.seq | kArmedAbort;
+  const int word = lane < 6 ? lane : 5;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { PCGMIX_ACLOCK(b, 0); }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {     // this sample's relay: host record -> device record
+    const unsigned long long* src = a.rec_h + (size_t)b * kArmedRecWords + word;
+    unsigned long long w;
+    bool aborted = false;
+    for (;;) {
+      w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const uint32_t st = (uint32_t)(w >> 32);
+      if (__all(st == go)) break;
+      if (__any(st == stop) || wall_clock64() - t0 > a.timeout_ticks) { aborted = true; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (aborted) {
+      w = (unsigned long long)stop << 32;
+      if (lane == 0) __hip_atomic_store(a.abort_h, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (lane < 6)
+      __hip_atomic_store(a.rec_d + (size_t)b * kArmedRecWords + lane, w, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) { PCGMIX_ACLOCK(b, 1); }
+  }
+  unsigned long long w;
+  {                                              // every wave: the sample's record on the device
+    const unsigned long long* src = a.rec_d + (size_t)b * kArmedRecWords + word;
+    for (;;) {
+      w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t st = (uint32_t)(w >> 32);
+      if (__all(st == go)) break;
+      if (__any(st == stop) || wall_clock64() - t0 > 2 * a.timeout_ticks) return;
+      __builtin_amdgcn_s_sleep(12);
+    }
+  }
+  if (blockIdx.x == 1 && threadIdx.x == 0) { PCGMIX_ACLOCK(b, 2); }
+  const int lo = (int)(uint32_t)w;
+  int f1[5], f2[5], m;
+  {
+    const int w0 = __builtin_amdgcn_readlane(lo, 0), w1 = __builtin_amdgcn_readlane(lo, 1),
+              w2 = __builtin_amdgcn_readlane(lo, 2), w3 = __builtin_amdgcn_readlane(lo, 3),
+              w4 = __builtin_amdgcn_readlane(lo, 4), w5 = __builtin_amdgcn_readlane(lo, 5);
+    auto lo16 = [](int v) { return (int)((unsigned)v << 16) >> 16; };
+    f1[0] = lo16(w0); f1[1] = w0 >> 16; f1[2] = lo16(w1); f1[3] = w1 >> 16; f1[4] = lo16(w2);
+    m = w2 >> 16;
+    f2[0] = lo16(w3); f2[1] = w3 >> 16; f2[2] = lo16(w4); f2[3] = w4 >> 16; f2[4] = lo16(w5);
+  }
+  m = (m < 0 || m >= B) ? b : m;
+  StateMap sm;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {          // make_state_map without offsets, as mix_warp_karg_kernel
+    const int a0 = f1[k], s = f2[k];
+    const int len1 = f1[k + 1] - a0, len2 = f2[k + 1] - s;
+    int n = len1 < len2 ? len1 : len2;
+    if (a0 < 0 || s < 0) n = 0;
+    if (n > T - a0) n = T - a0;
+    if (n > T - s) n = T - s;
+    if (n < 0) n = 0;
+    sm.a[k] = a0;
+    sm.n[k] = n;
+    sm.delta[k] = s - a0;
+  }
+  // two chunks of the sample per block: (256,4,5000) is 2,560 chunks, more blocks than the chip holds at
+  // once (2,048 of four waves) — the last fifth would start, and begin to wait, when the first ones leave
+  for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x)
+    mix_body<4, false, U>(x, y, lam, oml, nullptr, nullptr, 0, nullptr, C, T, epb, b, m, sm, lds, chunk);
+  if (blockIdx.x == 1 && threadIdx.x == 0) { PCGMIX_ACLOCK(b, 3); }
+}
+
 // Elements of one sample's plane per block: 1024 * U.  Fatter blocks amortise the block
 // prologue (dependent index loads, spline records) and keep more loads in flight per lane;
 // thinner ones waste fewer lanes on the last chunk of a short plane.  Chosen from measurements
@@ -684,6 +788,51 @@ int pcgmix::launch_mix_karg(const float* x, float* y, const int16_t* frames16, c
   else
     hipLaunchKernelGGL((mix_warp_karg_kernel<false, 1>), grid, block, 0, s, x, y, pack, lam, oml,
                        nullptr, nullptr, 0, B, C, T, epb, pay, static_cast<uint4*>(pay_dst));
+  return (int)hipGetLastError();
+}
+
+#ifdef PCGMIX_PHASE_CLOCK
+extern "C" int pcgmix_armed_phase_clock(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pcgmix::g_armed_clock), sizeof(long long) * 2 * (pcgmix::kPackB + 1) * 4);
+}
+#endif
+
+int pcgmix::launch_mix_armed(const float* x, float* y, const ArmedArgs& a, float lam, int B, int C,
+                             int T, hipStream_t s, const void* pay_host, int pay_bytes,
+                             void* pay_dst) {
+  using namespace pcgmix;
+  if (pay_bytes < 0 || pay_bytes > kPackPayBytes ||
+      (pay_bytes > 0 && (!pay_host || !pay_dst || (reinterpret_cast<uintptr_t>(pay_dst) & 15))))
+    return hipErrorInvalidValue;
+  if (!x || !y || x == y || B <= 0 || B > kPackB || C <= 0 || T <= 0 || T > 32767 || (T & 3) ||
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) || !a.ohe || a.K <= 0 ||
+      !a.lab64 || a.K > 256 || !a.rec_h || !a.rec_d || !a.abort_h || a.seq == 0 || (a.seq & kArmedAbort) ||
+      ((reinterpret_cast<uintptr_t>(a.rec_h) | reinterpret_cast<uintptr_t>(a.rec_d) |
+        reinterpret_cast<uintptr_t>(a.lab64)) & 7))
+    return hipErrorInvalidValue;
+  const long long plane = (long long)C * T;
+  if (plane > 0x7fffffffLL) return hipErrorInvalidValue;
+  PayPack pay;
+  pay.n16 = (pay_bytes + 15) / 16;
+  if (pay_bytes) {
+    memset(pay.w, 0, sizeof(pay.w));
+    memcpy(pay.w, pay_host, (size_t)pay_bytes);
+  }
+  const int U = choose_unroll(B, plane, false);
+  const int epb = kThreads * 4 * (U == 4 ? 2 : U);
+  const unsigned chunks = (unsigned)((plane + epb - 1) / epb);
+  const float oml = 1.0f - lam;
+  // every block resident at once: at most 2,048 blocks of four waves, each taking its sample's chunks
+  // blockIdx.x, blockIdx.x + gridDim.x, ...
+  unsigned per_sample = chunks;
+  while (per_sample > 1 && per_sample * (unsigned)B > 2048u) per_sample = (per_sample + 1) / 2;
+  dim3 grid(per_sample, (unsigned)B), block(kThreads);
+  if (U >= 2)
+    hipLaunchKernelGGL((mix_armed_kernel<2>), grid, block, 0, s, x, y, a, lam, oml, B, C, T, epb,
+                       (int)chunks, pay, static_cast<uint4*>(pay_dst));
+  else
+    hipLaunchKernelGGL((mix_armed_kernel<1>), grid, block, 0, s, x, y, a, lam, oml, B, C, T, epb,
+                       (int)chunks, pay, static_cast<uint4*>(pay_dst));
   return (int)hipGetLastError();
 }
 

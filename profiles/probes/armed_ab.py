@@ -1,0 +1,34 @@
+"""Strict-signature step (256,4,5000) `durratiomixup`, 1000-step regions, armed kernel against the
+two-launch path (run twice: PCGMIX_NO_ARMED unset / =1).   python profiles/probes/armed_ab.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import pcgmix_amd  # noqa: F401
+from pcgmix_amd import augmentations, hostprep, synthetic
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+from conftest import Args, StepCounter
+dev = torch.device("cuda", 0)
+print(hostprep.bind_host_threads(0), "| PCGMIX_NO_ARMED =", os.environ.get("PCGMIX_NO_ARMED"), flush=True)
+for (B, C, T) in [(256, 4, 5000), (256, 1, 5000)]:
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=2000, seed=0)
+    data = torch.from_numpy(x).to(dev)
+    tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(dev)
+    fr = torch.from_numpy(frames)
+    args, sc = Args("durratiomixup"), StepCounter(0)
+    def region(n):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for k in range(n):
+            sc.count = k
+            augmentations.augment(args, data, tgt, fr, wav, sc, None, dev, "")
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
+    region(200)
+    print((B, C, T), " ".join("%.2f" % region(1000) for _ in range(5)), "us/step;  20-step regions:",
+          " ".join("%.2f" % region(20) for _ in range(5)), flush=True)
+    import ctypes
+    from pcgmix_amd import _lib
+    lib = _lib.load(); ctx = augmentations.step_context(0)
+    out = (ctypes.c_double * 8)()
+    lib.pcgmix_ctx_phase_times(ctx, out)
+    t = region(1000)
+    n = lib.pcgmix_ctx_phase_times(ctx, out)
+    print("   phases (ns/call over %d calls, step %.2f us):" % (n, t), " ".join("%.0f" % v for v in out), " sum %.0f" % sum(out), flush=True)
