@@ -6,11 +6,16 @@
 #include <immintrin.h>
 
 #include <time.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -187,21 +192,28 @@ struct PyRandom {
     init_by_array(key, key[1] ? 2 : 1);
   }
 
-  uint32_t next32() {
-    if (idx >= 624) {
-      int kk;
-      for (kk = 0; kk < 624 - 397; ++kk) {
-        uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
-        mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-      }
-      for (; kk < 623; ++kk) {
-        uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
-        mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-      }
-      uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
-      mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-      idx = 0;
+  void regen() {
+    int kk;
+    for (kk = 0; kk < 624 - 397; ++kk) {
+      uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+      mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
     }
+    for (; kk < 623; ++kk) {
+      uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+      mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+    mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    idx = 0;
+  }
+  // the regeneration the first draw from a freshly seeded state starts with: done once per seeding
+  // instead of once per COPY of the seeded state (the partner draw copies it per label group)
+  void twist() {
+    if (idx >= 624) regen();
+  }
+
+  uint32_t next32() {
+    if (idx >= 624) regen();
     uint32_t y = mt[idx++];
     y ^= (y >> 11);
     y ^= (y << 7) & 0x9d2c5680u;
@@ -553,6 +565,20 @@ struct pcgmix_ctx {
   hipStream_t armed_stream = nullptr;    // stream of the last armed launch
   bool armed_any = false;
   long long armed_calls = 0, armed_slow = 0, armed_aborted = 0;
+  // Random(step + 1) seeded (1,247 dependent steps, 1.9 us) and regenerated on a helper thread while
+  // this step runs: the next call copies 2.5 KB instead.  The helper spins for half a millisecond
+  // after a job, then sleeps.
+  struct SeedAhead {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int> job{0};          // 0 idle | 1 posted | 2 done
+    std::atomic<bool> quit{false};
+    uint64_t step = 0;
+    PyRandom* state = nullptr;
+    pid_t pid = 0;
+    long long hits = 0, misses = 0;
+  } ahead;
   unsigned long long armed_timeout = 100000000ull;   // 1 s of the 100 MHz clock, from the kernel's start
   int armed_stall_ms = 0;                            // tests: host stall in front of the record write
 };
@@ -574,6 +600,69 @@ extern "C" int pcgmix_fetch_h2d(const void* src_pinned, void* dst_dev, size_t nb
                      static_cast<uint4*>(dst_dev), n16);
   return (int)hipGetLastError();
 }
+
+namespace {
+
+void seed_ahead_run(pcgmix_ctx* c) {
+  pcgmix_ctx::SeedAhead& a = c->ahead;
+  for (;;) {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (a.job.load(std::memory_order_acquire) != 1 && !a.quit.load(std::memory_order_relaxed)) {
+      if ((++spins & 63) || std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(500)) {
+        _mm_pause();
+        continue;
+      }
+      std::unique_lock<std::mutex> lk(a.mu);
+      a.cv.wait(lk, [&] { return a.job.load(std::memory_order_acquire) == 1 || a.quit.load(); });
+    }
+    if (a.quit.load()) return;
+    new (a.state) PyRandom(a.step);
+    a.state->twist();
+    a.job.store(2, std::memory_order_release);
+  }
+}
+
+// c->seeded = Random(step), regenerated: from the helper if it has this step, else here
+void seed_for_step(pcgmix_ctx* c, uint64_t step) {
+  if (c->gate_step == step) return;
+  pcgmix_ctx::SeedAhead& a = c->ahead;
+  bool have = false;
+  if (a.state && a.job.load(std::memory_order_acquire) != 0) {
+    while (a.job.load(std::memory_order_acquire) == 1) _mm_pause();      // <= one seeding
+    have = a.step == step;
+    if (have) std::memcpy(static_cast<void*>(c->seeded), a.state, sizeof(PyRandom));
+    a.job.store(0, std::memory_order_relaxed);
+  }
+  if (have) {
+    ++a.hits;
+  } else {
+    new (c->seeded) PyRandom(step);
+    c->seeded->twist();
+    ++a.misses;
+  }
+  c->gate_step = step;
+}
+
+// ask the helper for Random(step) (the step a training loop calls next); starts it on first use
+void seed_ahead_post(pcgmix_ctx* c, uint64_t step) {
+  pcgmix_ctx::SeedAhead& a = c->ahead;
+  static const bool enabled = getenv("PCGMIX_NO_SEED_AHEAD") == nullptr;
+  if (!enabled) return;
+  if (!a.state) {
+    a.state = static_cast<PyRandom*>(::operator new(sizeof(PyRandom)));
+    a.pid = getpid();
+    a.th = std::thread([c] { seed_ahead_run(c); });
+  }
+  if (a.pid != getpid()) return;                     // a forked child has no helper thread
+  if (a.job.load(std::memory_order_acquire) == 1) return;      // still busy with an older request
+  a.step = step;
+  a.job.store(1, std::memory_order_release);
+  { std::lock_guard<std::mutex> lk(a.mu); }          // the helper is before its check or asleep
+  a.cv.notify_one();
+}
+
+}  // namespace
 
 extern "C" int pcgmix_ctx_create(int device, pcgmix_ctx** out) {
   if (!out) return hipErrorInvalidValue;
@@ -607,6 +696,19 @@ extern "C" void pcgmix_ctx_destroy(pcgmix_ctx* c) {
     if (s.dev) (void)hipFree(s.dev);
     if (s.ev) (void)hipEventDestroy(s.ev);
   }
+  if (c->ahead.state) {
+    if (c->ahead.pid == getpid()) {
+      {
+        std::lock_guard<std::mutex> lk(c->ahead.mu);
+        c->ahead.quit.store(true);
+      }
+      c->ahead.cv.notify_all();
+      if (c->ahead.th.joinable()) c->ahead.th.join();
+    } else if (c->ahead.th.joinable()) {
+      c->ahead.th.detach();
+    }
+    ::operator delete(c->ahead.state);
+  }
   if (c->lab) (void)hipHostFree(c->lab);
   if (c->flag) (void)hipHostFree(c->flag);
   if (c->ws) (void)hipFree(c->ws);
@@ -622,8 +724,7 @@ extern "C" void pcgmix_ctx_destroy(pcgmix_ctx* c) {
 // step call that follows a passed gate does not initialise MT19937 a second time.
 extern "C" double pcgmix_ctx_gate(pcgmix_ctx* c, uint64_t step) {
   if (!c) return 2.0;
-  new (c->seeded) PyRandom(step);
-  c->gate_step = step;
+  seed_for_step(c, step);
   PyRandom r = *c->seeded;
   return 0.0 + (1.0 - 0.0) * r.random();
 }
@@ -721,6 +822,43 @@ int pack_frames(const int64_t* frames, int B, int T, int32_t* st, int* max_len) 
     for (int k = 0; k < 5; ++k) st[b * 5 + k] = (int32_t)r[k];
   }
   if (max_len) *max_len = (int)(longest > T ? T : longest);
+  return bad;
+}
+
+// The same as int16 for the launches that carry the boundaries in their arguments (B <= kPackB,
+// T <= 32767).  Branch-free passes (the compiler vectorises them; the row-by-row version with its
+// first-failure bookkeeping was 1.2 us of a 17 us step); the exact code of the FIRST offending row,
+// as pack_frames reports it, is worked out only when something is wrong.
+__attribute__((always_inline)) inline bool frames16_scan(const int64_t* frames, int n, int T,
+                                                        int16_t* fr16) {
+  int64_t lo = 0, hi = 0;
+  for (int i = 0; i < n; ++i) {
+    const int64_t v = frames[i];
+    lo = v < lo ? v : lo;
+    hi = v > hi ? v : hi;
+    fr16[i] = (int16_t)v;
+  }
+  int dec = 0;
+  for (int i = 0; i + 1 < n; ++i) dec |= (int)(frames[i + 1] < frames[i]) & (int)((i + 1) % 5 != 0);
+  return lo < 0 || hi > T || dec;
+}
+__attribute__((target("avx2"))) bool frames16_scan_avx2(const int64_t* f, int n, int T, int16_t* o) {
+  return frames16_scan(f, n, T, o);
+}
+bool frames16_scan_base(const int64_t* f, int n, int T, int16_t* o) { return frames16_scan(f, n, T, o); }
+
+int pack_frames16(const int64_t* frames, int B, int T, int16_t* fr16) {
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (!(avx2 ? frames16_scan_avx2(frames, B * 5, T, fr16) : frames16_scan_base(frames, B * 5, T, fr16)))
+    return 0;
+  int bad = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t* r = frames + (size_t)b * 5;
+    if (r[0] < 0) bad = bad ? bad : -1;
+    for (int k = 0; k < 4; ++k)
+      if (r[k + 1] < r[k]) bad = bad ? bad : -1;
+    if (r[4] > T) bad = bad ? bad : -2;
+  }
   return bad;
 }
 
@@ -1040,20 +1178,9 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     lap(0);
     // from here on the kernel is waiting: every way out writes its records
     int16_t fr16[pcgmix::kPackB * 5], mix16[pcgmix::kPackB];
-    int bad16 = 0;
-    for (int b = 0; b < B; ++b) {
-      const int64_t* r = frames + (size_t)b * 5;
-      if (r[0] < 0) bad16 = bad16 ? bad16 : -1;
-      for (int k = 0; k < 4; ++k)
-        if (r[k + 1] < r[k]) bad16 = bad16 ? bad16 : -1;
-      if (r[4] > T) bad16 = bad16 ? bad16 : -2;
-      for (int k = 0; k < 5; ++k) fr16[b * 5 + k] = (int16_t)r[k];
-    }
+    const int bad16 = pack_frames16(frames, B, T, fr16);
     lap(1);
-    if (c->gate_step != step) {
-      new (c->seeded) PyRandom(step);
-      c->gate_step = step;
-    }
+    seed_for_step(c, step);
     lap(2);
     int64_t lab64a[pcgmix::kPackB];
     if (bad16 || (e = labels_wait_armed(c, B, lab64a)) != hipSuccess) {
@@ -1086,6 +1213,7 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     }
     lap(6);
     lap(7);
+    seed_ahead_post(c, step + 1);
     ++c->calls;
     return hipSuccess;
   }
@@ -1101,20 +1229,9 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   //     host -> splice that bounds a strict-signature step.
   if (small) {
     int16_t fr16[pcgmix::kPackB * 5], mix16[pcgmix::kPackB];
-    int bad16 = 0;
-    for (int b = 0; b < B; ++b) {
-      const int64_t* r = frames + (size_t)b * 5;
-      if (r[0] < 0) bad16 = bad16 ? bad16 : -1;
-      for (int k = 0; k < 4; ++k)
-        if (r[k + 1] < r[k]) bad16 = bad16 ? bad16 : -1;
-      if (r[4] > T) bad16 = bad16 ? bad16 : -2;
-      for (int k = 0; k < 5; ++k) fr16[b * 5 + k] = (int16_t)r[k];
-    }
+    const int bad16 = pack_frames16(frames, B, T, fr16);
     lap(1);
-    if (c->gate_step != step) {
-      new (c->seeded) PyRandom(step);
-      c->gate_step = step;
-    }
+    seed_for_step(c, step);
     lap(2);
     std::vector<int64_t> lab64k;
     const int64_t* labels_k = labels_host;
@@ -1136,6 +1253,7 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     c->payload_dst = nullptr;
     lap(6);
     lap(7);
+    seed_ahead_post(c, step + 1);
     ++c->calls;
     return hipSuccess;
   }
@@ -1159,10 +1277,7 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     knots_dev = reinterpret_cast<const double*>(sl.dev + n_int_pad * 4);
   }
   if (!c->payload.empty()) std::memcpy(sl.pinned + pay_off, c->payload.data(), c->payload.size());
-  if (c->gate_step != step) {
-    new (c->seeded) PyRandom(step);
-    c->gate_step = step;
-  }
+  seed_for_step(c, step);
 
   lap(2);
   // 3. wait for the labels (the one host wait the reference's signature forces,
@@ -1200,6 +1315,7 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   lap(6);
   if ((e = slot_commit(c, my_slot, s)) != hipSuccess) return (int)e;
   lap(7);
+  seed_ahead_post(c, step + 1);
   ++c->calls;
   return hipSuccess;
 }
@@ -1401,10 +1517,7 @@ extern "C" int pcgmix_ctx_salopt_finish(pcgmix_ctx* c, const float* x, float* y,
     if ((e = hipMalloc(&c->ws, ws_bytes)) != hipSuccess) return (int)e;
     c->ws_cap = ws_bytes;
   }
-  if (c->gate_step != step) {
-    new (c->seeded) PyRandom(step);
-    c->gate_step = step;
-  }
+  seed_for_step(c, step);
   std::vector<int64_t> lab64;
   const int64_t* labels = labels_host;
   if (!labels) {
