@@ -674,6 +674,16 @@ def measured_traffic(method, B, C, T):
     return None, None
 
 
+def armed_step_stats(device):
+    """[armed steps, checked after a stream synchronisation, relaunched] of this device's step context."""
+    import ctypes
+    from pcgmix_amd import _lib
+    out = (ctypes.c_longlong * 3)()
+    if _lib.load().pcgmix_ctx_armed_stats(augmentations.step_context(device.index), out):
+        return None
+    return list(out)
+
+
 def roofline_entry(method, B, C, T, kern_ms, info):
     """Roofline object of one splice launch.  ``achieved``/``frac`` use the bytes THIS batch needs
     (own read + write + partner read inside blended ranges, ``exact_mix_bytes``); the contract's
@@ -822,6 +832,17 @@ def main():
     roof["per_launch_event_pair_ms"] = per_launch_pair_ms
     roof["timing"] = ("HIP events on the launch stream around 200 back-to-back launches "
                       "(in-order stream, queue kept full), divided by 200")
+    armed = armed_step_stats(device)
+    if armed and armed[0] > 0:
+        roof["step_kernel"] = {
+            "name": "pcgmix::mix_armed_kernel<%d>" % max(1, karg_unroll(B, C, T, False) or 1),
+            "armed_steps": armed[0], "checked_after_sync": armed[1], "relaunched": armed[2],
+            "note": "the timed augment() steps launch this instantiation of the same splice body (mix_body) "
+                    "BEFORE its index block exists: block (0,0) does the label arg-max, the other blocks wait for "
+                    "the records the host writes once it has drawn the partners.  Its duration under rocprofv3 "
+                    "therefore contains the host's reaction (label arg-max 1.0 + host 4.4 + relay 1.0 us of ~12, "
+                    "profiles/r4_armed_step.txt); `kernel` above is the two-launch instantiation of the same "
+                    "body issued back to back, which is what a roofline can be read from"}
     result = {
         "metric": "augmented PCG samples/s", "value": value, "unit": "samples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
