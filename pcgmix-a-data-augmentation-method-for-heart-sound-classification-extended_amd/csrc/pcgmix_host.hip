@@ -1218,6 +1218,80 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     return hipSuccess;
   }
 
+  // 0b. The same for splice + warp (durmixmagwarp through the strict signature): the knots go into a
+  //     pinned slot the waiting blocks read directly (8 * n_knots * C bytes per sample), so the label
+  //     launch AND the fetch launch of the path below leave the chain.
+  if (armed_ok && readback && knots && num_classes <= 256 &&
+      c->payload.size() <= (size_t)pcgmix::kPackPayBytes &&
+      !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) &&
+      pcgmix::mix_tq_armed_ok(B, C, T, n_knots)) {
+    const size_t nkb = (size_t)B * n_knots * C * sizeof(double);
+    const int my_slot = c->next;
+    Slot& sl = c->slot[my_slot];
+    const double* op_dev = nullptr;
+    if ((e = labels_prepare(c, B, s)) != hipSuccess) return (int)e;
+    if ((e = armed_prepare(c, s)) != hipSuccess) return (int)e;
+    if ((e = slot_reserve(c, my_slot, nkb)) != hipSuccess) return (int)e;
+    if ((e = spline_op_device(c, T, n_knots, &op_dev)) != hipSuccess) return (int)e;
+    std::memcpy(sl.pinned, knots, nkb);
+    pcgmix::ArmedArgs a;
+    a.ohe = target_ohe_dev;
+    a.K = num_classes;
+    a.lab64 = reinterpret_cast<unsigned long long*>(c->lab);
+    a.token = c->token;
+    a.rec_h = c->rec_h;
+    a.rec_d = c->rec_d;
+    a.abort_h = c->flag + 8;
+    a.seq = c->armed_seq;
+    a.timeout_ticks = c->armed_timeout;
+    const auto t_launch = std::chrono::steady_clock::now();
+    const int err = pcgmix::launch_mix_tq_armed(x, y, a, lam, reinterpret_cast<const double*>(sl.pinned),
+                                                op_dev, n_knots, B, C, T, s, c->payload.data(),
+                                                (int)c->payload.size(), c->payload_dst);
+    if (err) return err;
+    c->armed_stream = s;
+    c->armed_any = true;
+    lap(0);
+    int16_t fr16[pcgmix::kPackB * 5], mix16[pcgmix::kPackB];
+    const int bad16 = pack_frames16(frames, B, T, fr16);
+    lap(1);
+    seed_for_step(c, step);
+    lap(2);
+    int64_t lab64a[pcgmix::kPackB];
+    if (bad16 || (e = labels_wait_armed(c, B, lab64a)) != hipSuccess) {
+      armed_write(c, a.seq | pcgmix::kArmedAbort, nullptr, nullptr, B);
+      (void)slot_commit(c, my_slot, s);        // the kernel may still read the slot's knots
+      return bad16 ? bad16 : (int)e;
+    }
+    lap(3);
+    draw_partners(c, lab64a, B, mix_out, nullptr, mix16);
+    lap(4);
+    if (c->armed_stall_ms > 0) {
+      timespec ts{c->armed_stall_ms / 1000, (long)(c->armed_stall_ms % 1000) * 1000000L};
+      nanosleep(&ts, nullptr);
+    }
+    armed_write(c, a.seq, fr16, mix16, B);
+    lap(5);
+    c->payload.clear();
+    c->payload_dst = nullptr;
+    ++c->armed_calls;
+    if ((e = slot_commit(c, my_slot, s)) != hipSuccess) return (int)e;
+    lap(6);
+    if (std::chrono::steady_clock::now() - t_launch > std::chrono::milliseconds(400)) {
+      ++c->armed_slow;
+      if ((e = hipStreamSynchronize(s)) != hipSuccess) return (int)e;
+      if (__atomic_load_n(c->flag + 8, __ATOMIC_ACQUIRE) == a.seq) {
+        ++c->armed_aborted;          // the blocks gave up: the step again, with the labels we hold
+        return pcgmix_augment_plain_f32(c, x, y, nullptr, 0, lab64a, frames, step, lam, knots, n_knots,
+                                        mix_out, B, C, T, stream);
+      }
+    }
+    lap(7);
+    seed_ahead_post(c, step + 1);
+    ++c->calls;
+    return hipSuccess;
+  }
+
   // 1. start the label read-back first: everything below up to step 4 does not need the labels
   //    and runs while the GPU finishes what precedes this call on `stream`
   if (readback && (e = labels_begin(c, target_ohe_dev, num_classes, B, s)) != hipSuccess)

@@ -334,22 +334,21 @@ __global__ __launch_bounds__(kThreads) void mix_warp_kernel(
 // operation rounded on its own: bit-identical output (tests/test_mix_gpu.py).
 // Block = kThreads * 4 * UT consecutive positions of one sample, all channels; LDS = the C * (n-1)
 // coefficient records of the sample, built while the first loads are in flight.
-template <int CG, int UT>
-__global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
-    const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ frames,
-    const int32_t* __restrict__ mix_idx, const int32_t* __restrict__ off, float lam, float oml,
-    const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots, int B, int C,
-    int T, const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst, int pay_n16,
-    const float2* __restrict__ disp_part, const PartnerPack pk) {
-  extern __shared__ __align__(16) double lds[];  // C * (n_knots - 1) records, then thresholds
-  if (pay_n16 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0)
-    for (int i = threadIdx.x; i < pay_n16; i += kThreads) pay_dst[i] = pay_src[i];
-  const int b = blockIdx.z * kBatchPerGridZ + blockIdx.y;
-  if (b >= B) return;  // block-uniform
-  int m = pk.n ? partner_get(pk, b) : mix_idx[b];
-  m = (m < 0 || m >= B) ? b : m;
-  const StateMap sm = make_state_map(frames, off, b, m, T, disp_part);
-  const size_t own_base = (size_t)b * C * T, par_base = (size_t)m * C * T;
+// knots_b: the n_knots * C knots of THIS sample (device memory, or device-readable host memory for the
+// armed launch).  LATE (the armed launch): the sample's partner and blended ranges are not known when the
+// block starts — everything that does not depend on them (the own rows' first loads, operator and
+// knots into LDS, the coefficient records, every position's spline piece and powers) runs first, then
+// `await(sm, m)` (block-uniform; false = give up) delivers them.
+struct TqKnown {
+  __device__ bool operator()(StateMap&, int&) const { return true; }
+};
+template <int CG, int UT, bool LATE = false, class Await = TqKnown>
+__device__ __forceinline__ void tq_body(
+    const float* __restrict__ x, float* __restrict__ y, float lam, float oml,
+    const double* __restrict__ knots_b, const double* __restrict__ spline_op, int n_knots, int C, int T,
+    int b, int m, StateMap sm, double* lds, Await await = Await()) {
+  const size_t own_base = (size_t)b * C * T;
+  size_t par_base = (size_t)m * C * T;
   const int rec_per_ch = (n_knots - 1) * kRec;
   int* thr = reinterpret_cast<int*>(lds + (size_t)C * rec_per_ch);
   const int tq0 = blockIdx.x * (kThreads * 4 * UT);
@@ -359,26 +358,32 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
 #pragma unroll
   for (int q = 0; q < UT; ++q) {
     const int t0 = tq0 + (q * kThreads + (int)threadIdx.x) * 4;
-    const bool valid = t0 < T;
-    const int tt = valid ? t0 : 0;
-    bool hit[4];
-    int d[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) d[e] = blend_shift(sm, tt + e, hit[e]);
-    const int dsel = hit[0] ? d[0] : hit[1] ? d[1] : hit[2] ? d[2] : hit[3] ? d[3] : 0;
-    int src0 = tt + dsel;
-    src0 = src0 < 0 ? 0 : (src0 > T - 4 ? T - 4 : src0);
-    const bool clamped = src0 != tt + dsel;
-    int mask = valid ? 0x100 : 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (hit[e]) mask |= 1 << e;
-      if (hit[e] && (clamped || d[e] != dsel)) mask |= 16 << e;
-    }
-    t0s[q] = tt;
-    masks[q] = mask;
-    src0s[q] = src0;
+    t0s[q] = t0 < T ? t0 : 0;
+    masks[q] = t0 < T ? 0x100 : 0;
+    src0s[q] = 0;
   }
+  auto classify = [&]() {
+#pragma unroll
+    for (int q = 0; q < UT; ++q) {
+      const int tt = t0s[q];
+      bool hit[4];
+      int d[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = blend_shift(sm, tt + e, hit[e]);
+      const int dsel = hit[0] ? d[0] : hit[1] ? d[1] : hit[2] ? d[2] : hit[3] ? d[3] : 0;
+      int src0 = tt + dsel;
+      src0 = src0 < 0 ? 0 : (src0 > T - 4 ? T - 4 : src0);
+      const bool clamped = src0 != tt + dsel;
+      int mask = masks[q] & 0x100;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (hit[e]) mask |= 1 << e;
+        if (hit[e] && (clamped || d[e] != dsel)) mask |= 16 << e;
+      }
+      masks[q] = mask;
+      src0s[q] = src0;
+    }
+  };
   float4_a own[UT][CG];
   float4_u par[UT][CG];
   auto issue_loads = [&](int c0) {
@@ -394,7 +399,10 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
         par[q][cc] = *reinterpret_cast<const float4_u*>(x + poff);
       }
   };
-  issue_loads(0);
+  if (!LATE) {
+    classify();
+    issue_loads(0);
+  }
   // coefficient records of all channels of this sample: coef = op * knots[b, :, c].  The operator
   // and the sample's knots are staged in LDS first — ONE round trip to memory; the dot products
   // with their operands in global memory were n_knots dependent round trips on every block's
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
   double* opl = reinterpret_cast<double*>(thr + ((n_knots + 1) & ~1));
   double* knl = opl + n_op;
   for (int i = threadIdx.x; i < n_op + n_knots * C; i += kThreads)
-    opl[i] = i < n_op ? spline_op[i] : knots[(size_t)b * n_knots * C + (i - n_op)];
+    opl[i] = i < n_op ? spline_op[i] : knots_b[i - n_op];
   __syncthreads();
   for (int i = threadIdx.x; i < n_knots; i += kThreads) thr[i] = (int)ceil(opl[i]);
   for (int i = threadIdx.x; i < C * rec_per_ch; i += kThreads) {
@@ -436,6 +444,28 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
       s2[q][e] = z;
       s3[q][e] = __dmul_rn(z, s);
     }
+  if (LATE) {
+    // the own rows' first loads go out here, behind the records and the positions: at the kernel's entry
+    // they (20 MB at once from every block) stood in front of block (0,0)'s label loads — labels 3.0 us
+    // after the entry instead of 1.0 — and they have the whole wait to arrive anyway
+#pragma unroll
+    for (int q = 0; q < UT; ++q)
+#pragma unroll
+      for (int cc = 0; cc < CG; ++cc)
+        own[q][cc] = *reinterpret_cast<const float4_a*>(x + own_base + (size_t)cc * T + t0s[q]);
+    if (!await(sm, m)) return;                   // block-uniform
+    par_base = (size_t)m * C * T;
+    classify();
+#pragma unroll
+    for (int q = 0; q < UT; ++q)
+#pragma unroll
+      for (int cc = 0; cc < CG; ++cc) {
+        const size_t row = (size_t)cc * T;
+        size_t poff = (masks[q] & 0xf) ? par_base + row + src0s[q] : own_base + row + t0s[q];
+        asm volatile("" : "+v"(poff));
+        par[q][cc] = *reinterpret_cast<const float4_u*>(x + poff);
+      }
+  }
   for (int c0 = 0; c0 < C; c0 += CG) {
     if (c0) issue_loads(c0);
 #pragma unroll
@@ -486,6 +516,24 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
       }
     }
   }
+}
+
+template <int CG, int UT>
+__global__ __launch_bounds__(kThreads) void mix_warp_tq_kernel(
+    const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ frames,
+    const int32_t* __restrict__ mix_idx, const int32_t* __restrict__ off, float lam, float oml,
+    const double* __restrict__ knots, const double* __restrict__ spline_op, int n_knots, int B, int C,
+    int T, const uint4* __restrict__ pay_src, uint4* __restrict__ pay_dst, int pay_n16,
+    const float2* __restrict__ disp_part, const PartnerPack pk) {
+  extern __shared__ __align__(16) double lds[];  // C * (n_knots - 1) records, then thresholds
+  if (pay_n16 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0)
+    for (int i = threadIdx.x; i < pay_n16; i += kThreads) pay_dst[i] = pay_src[i];
+  const int b = blockIdx.z * kBatchPerGridZ + blockIdx.y;
+  if (b >= B) return;  // block-uniform
+  int m = pk.n ? partner_get(pk, b) : mix_idx[b];
+  m = (m < 0 || m >= B) ? b : m;
+  const StateMap sm = make_state_map(frames, off, b, m, T, disp_part);
+  tq_body<CG, UT>(x, y, lam, oml, knots + (size_t)b * n_knots * C, spline_op, n_knots, C, T, b, m, sm, lds);
 }
 
 // The same kernel with the whole index block — boundaries and partners of up to kPackB samples
@@ -656,6 +704,112 @@ __global__ __launch_bounds__(kThreads) void mix_armed_kernel(
   // once (2,048 of four waves) — the last fifth would start, and begin to wait, when the first ones leave
   for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x)
     mix_body<4, false, U>(x, y, lam, oml, nullptr, nullptr, 0, nullptr, C, T, epb, b, m, sm, lds, chunk);
+  if (blockIdx.x == 1 && threadIdx.x == 0) { PCGMIX_ACLOCK(b, 3); }
+}
+
+// The splice + warp kernel armed the same way (PCGmix+ through the strict signature): the knots are known
+// at launch time — the library drew them ahead — and sit in device-readable pinned memory, 8 * n_knots * C
+// bytes per sample: every block stages the operator and its sample's knots into LDS while it waits for
+// the sample's record, so neither a label launch nor a fetch launch nor their starts are left in the
+// chain.  One wave per block polls; the verdict reaches the others through LDS, block-uniform (the body
+// has barriers).
+template <int CG, int UT>
+__global__ __launch_bounds__(kThreads) void mix_warp_tq_armed_kernel(
+    const float* __restrict__ x, float* __restrict__ y, const ArmedArgs a, float lam, float oml,
+    const double* __restrict__ knots_host, const double* __restrict__ spline_op, int n_knots, int B,
+    int C, int T, const PayPack pay, uint4* __restrict__ pay_dst) {
+  extern __shared__ __align__(16) double lds[];
+  __shared__ unsigned long long rec_s[8];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  if ((blockIdx.x | blockIdx.y) == 0) {
+    if (threadIdx.x == 0) { PCGMIX_ACLOCK(kPackB, 0); }
+    if (pay.n16 && (int)threadIdx.x < pay.n16) pay_dst[threadIdx.x] = pay.w[threadIdx.x];
+    if (threadIdx.x < 64) {                      // labels, as mix_armed_kernel
+      unsigned long long w = (unsigned long long)a.token << 32;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * lane + j;
+        const int best = onehot_argmax(a.ohe, a.K, r < B ? r : B - 1);
+        w |= (unsigned long long)(r < B ? best & 0xff : 0) << (8 * j);
+      }
+      __hip_atomic_store(a.lab64 + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (threadIdx.x == 0) { PCGMIX_ACLOCK(kPackB, 1); }
+    }
+  }
+  if (b >= B) return;
+  const unsigned long long t0 = wall_clock64();
+  if (blockIdx.x == 0 && threadIdx.x == 0) { PCGMIX_ACLOCK(b, 0); }
+  // (Tried: the sample's relay copies the knots to device memory once and stamps a "ready" word the other
+  // blocks wait for — 49 KB across the link instead of 245 KB at (256,4,5000); two fences and a second wait
+  // later the step was 25.0 us instead of 23.0: the link was not in the way.)
+  auto await = [&](StateMap& sm, int& m) -> bool {
+    const uint32_t go = a.seq, stop = a.seq | kArmedAbort;
+    const int word = lane < 6 ? lane : 5;
+    if (threadIdx.x < 64) {
+      unsigned long long w;
+      if (blockIdx.x == 0) {                     // this sample's relay: host record -> device record
+        const unsigned long long* src = a.rec_h + (size_t)b * kArmedRecWords + word;
+        bool aborted = false;
+        for (;;) {
+          w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          const uint32_t st = (uint32_t)(w >> 32);
+          if (__all(st == go)) break;
+          if (__any(st == stop) || wall_clock64() - t0 > a.timeout_ticks) { aborted = true; break; }
+          __builtin_amdgcn_s_sleep(4);
+        }
+        if (aborted) {
+          w = (unsigned long long)stop << 32;
+          if (lane == 0) __hip_atomic_store(a.abort_h, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (lane < 6)
+          __hip_atomic_store(a.rec_d + (size_t)b * kArmedRecWords + lane, w, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) { PCGMIX_ACLOCK(b, 1); }
+      }
+      const unsigned long long* src = a.rec_d + (size_t)b * kArmedRecWords + word;
+      bool ok = false;
+      for (;;) {
+        w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t st = (uint32_t)(w >> 32);
+        if (__all(st == go)) { ok = true; break; }
+        if (__any(st == stop) || wall_clock64() - t0 > 2 * a.timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(12);
+      }
+      if (lane < 6) rec_s[lane] = w;
+      if (lane == 6) rec_s[7] = ok ? 1ull : 0ull;
+    }
+    __syncthreads();
+    if (blockIdx.x == 1 && threadIdx.x == 0) { PCGMIX_ACLOCK(b, 2); }
+    if (!rec_s[7]) return false;
+    int f1[5], f2[5];
+    auto lo16 = [](int v) { return (int)((unsigned)v << 16) >> 16; };
+    const int w0 = (int)(uint32_t)rec_s[0], w1 = (int)(uint32_t)rec_s[1], w2 = (int)(uint32_t)rec_s[2],
+              w3 = (int)(uint32_t)rec_s[3], w4 = (int)(uint32_t)rec_s[4], w5 = (int)(uint32_t)rec_s[5];
+    f1[0] = lo16(w0); f1[1] = w0 >> 16; f1[2] = lo16(w1); f1[3] = w1 >> 16; f1[4] = lo16(w2);
+    m = w2 >> 16;
+    f2[0] = lo16(w3); f2[1] = w3 >> 16; f2[2] = lo16(w4); f2[3] = w4 >> 16; f2[4] = lo16(w5);
+    m = (m < 0 || m >= B) ? b : m;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {        // make_state_map without offsets
+      const int a0 = f1[k], s = f2[k];
+      const int len1 = f1[k + 1] - a0, len2 = f2[k + 1] - s;
+      int n = len1 < len2 ? len1 : len2;
+      if (a0 < 0 || s < 0) n = 0;
+      if (n > T - a0) n = T - a0;
+      if (n > T - s) n = T - s;
+      if (n < 0) n = 0;
+      sm.a[k] = a0;
+      sm.n[k] = n;
+      sm.delta[k] = s - a0;
+    }
+    return true;
+  };
+  StateMap sm0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sm0.a[k] = 0; sm0.n[k] = 0; sm0.delta[k] = 0; }
+  tq_body<CG, UT, true>(x, y, lam, oml, knots_host + (size_t)b * n_knots * C, spline_op, n_knots, C, T, b, b,
+                        sm0, lds, await);
   if (blockIdx.x == 1 && threadIdx.x == 0) { PCGMIX_ACLOCK(b, 3); }
 }
 
@@ -836,6 +990,48 @@ int pcgmix::launch_mix_armed(const float* x, float* y, const ArmedArgs& a, float
   else
     hipLaunchKernelGGL((mix_armed_kernel<1>), grid, block, 0, s, x, y, a, lam, oml, B, C, T, epb,
                        (int)chunks, pay, static_cast<uint4*>(pay_dst));
+  return (int)hipGetLastError();
+}
+
+// 1 if launch_mix_tq_armed takes this problem (the tq instantiation exists for it and its grid is resident)
+int pcgmix::mix_tq_armed_ok(int B, int C, int T, int n_knots) {
+  if (B <= 0 || B > kPackB || C <= 0 || T <= 0 || T > 32767 || (T & 3) || n_knots < 2 || n_knots > 64) return 0;
+  const MixVariant mv = choose_mix_variant(B, C, T, true, n_knots, false);
+  if (!mv.tq) return 0;
+  const long long blocks = (long long)((T + kThreads * 4 * mv.UT - 1) / (kThreads * 4 * mv.UT)) * B;
+  return blocks <= 2048 && mv.lds_tq <= 32 * 1024;
+}
+
+int pcgmix::launch_mix_tq_armed(const float* x, float* y, const ArmedArgs& a, float lam,
+                                const double* knots_host, const double* spline_op, int n_knots, int B,
+                                int C, int T, hipStream_t s, const void* pay_host, int pay_bytes,
+                                void* pay_dst) {
+  using namespace pcgmix;
+  if (pay_bytes < 0 || pay_bytes > kPackPayBytes ||
+      (pay_bytes > 0 && (!pay_host || !pay_dst || (reinterpret_cast<uintptr_t>(pay_dst) & 15))))
+    return hipErrorInvalidValue;
+  if (!x || !y || x == y || !knots_host || !spline_op || !mix_tq_armed_ok(B, C, T, n_knots) ||
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) || !a.ohe || a.K <= 0 ||
+      !a.lab64 || a.K > 256 || !a.rec_h || !a.rec_d || !a.abort_h || a.seq == 0 || (a.seq & kArmedAbort) ||
+      ((reinterpret_cast<uintptr_t>(a.rec_h) | reinterpret_cast<uintptr_t>(a.rec_d) |
+        reinterpret_cast<uintptr_t>(a.lab64) | reinterpret_cast<uintptr_t>(knots_host)) & 7))
+    return hipErrorInvalidValue;
+  PayPack pay;
+  pay.n16 = (pay_bytes + 15) / 16;
+  if (pay_bytes) {
+    memset(pay.w, 0, sizeof(pay.w));
+    memcpy(pay.w, pay_host, (size_t)pay_bytes);
+  }
+  const MixVariant mv = choose_mix_variant(B, C, T, true, n_knots, false);
+  const float oml = 1.0f - lam;
+  dim3 grid((unsigned)((T + kThreads * 4 * mv.UT - 1) / (kThreads * 4 * mv.UT)), (unsigned)B), block(kThreads);
+#define PCGMIX_LAUNCH_TQA(CGV, UTV)                                                                  \
+  hipLaunchKernelGGL((mix_warp_tq_armed_kernel<CGV, UTV>), grid, block, mv.lds_tq, s, x, y, a, lam,  \
+                     oml, knots_host, spline_op, n_knots, B, C, T, pay, static_cast<uint4*>(pay_dst))
+  if (mv.CG == 4) { if (mv.UT == 2) PCGMIX_LAUNCH_TQA(4, 2); else PCGMIX_LAUNCH_TQA(4, 1); }
+  else if (mv.CG == 2) { if (mv.UT == 2) PCGMIX_LAUNCH_TQA(2, 2); else PCGMIX_LAUNCH_TQA(2, 1); }
+  else { if (mv.UT == 2) PCGMIX_LAUNCH_TQA(1, 2); else PCGMIX_LAUNCH_TQA(1, 1); }
+#undef PCGMIX_LAUNCH_TQA
   return (int)hipGetLastError();
 }
 

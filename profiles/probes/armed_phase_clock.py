@@ -28,7 +28,7 @@ for (B, C, T) in [(256, 4, 5000), (256, 1, 5000)]:
     data = torch.from_numpy(x).to(dev)
     tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(dev)
     fr = torch.from_numpy(frames)
-    args, sc = Args("durratiomixup"), StepCounter(0)
+    args, sc = Args(os.environ.get("PCGMIX_PROBE_METHOD", "durratiomixup")), StepCounter(0)
     for rep in range(3):
         n = 400 + rep            # both parities end up "last"
         for k in range(n):

@@ -49,6 +49,54 @@ def test_armed_step_equals_two_launch_path_and_oracle(B, C, T, rate, device):
     assert after[2] == before[2], "an armed kernel gave up"
 
 
+@pytest.mark.parametrize("B,C,T,rate,method", [(256, 4, 5000, 2000, "durmixmagwarp(0.2,4)"),
+                                               (256, 1, 5000, 2000, "durmixmagwarp(0.2,4)"),
+                                               (31, 4, 2500, 1000, "durmixmagwarp(0.1,3)"),
+                                               (64, 3, 5000, 2000, "durmixmagwarp(0.3,8)")])
+def test_armed_splice_warp_equals_two_launch_path_and_oracle(B, C, T, rate, method, device):
+    """PCGmix+ (augmentations.py:674-683, 924-928) through the strict signature: the armed splice + warp
+    kernel reads its knots from the pinned slot while it waits.  Bit-equal to the path with host labels
+    (label kernel-free, fetch + launch); against the oracle the warp's usual bar (<= 1 ulp, rare)."""
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=rate, seed=B + C)
+    data = torch.from_numpy(x).to(device)
+    before = _stats(device)
+    for step in (1, 8, 23):
+        y_a, _, mix_a, _ = _step(augmentations, method, data, labels, frames, wav, step, device)
+        y_h, _, mix_h, _ = _step(augmentations, method, data, labels, frames, wav, step, device,
+                                 host_labels=labels)
+        assert np.array_equal(mix_a, mix_h) and torch.equal(y_a, y_h) and not torch.equal(y_a, data)
+        ref = O.augment(method, x, labels, frames, wav, step)
+        got = y_a.cpu().numpy()
+        assert np.array_equal(mix_a, ref["mix"]) and np.abs(got - ref["y"]).max() <= 1e-4
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - ref["y"].view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1 and (ulp > 0).mean() < 1e-3
+    after = _stats(device)
+    assert after[0] - before[0] == 3 and after[2] == before[2]
+
+
+def test_late_records_for_splice_warp(device):
+    """The relaunch after a give-up, for the splice + warp step (it goes through the staged path with the
+    labels the call already holds)."""
+    lib = _lib.load()
+    ctx = augmentations.step_context(device.index)
+    B, C, T = 80, 4, 5000
+    method = "durmixmagwarp(0.2,4)"
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=2000, seed=13)
+    data = torch.from_numpy(x).to(device)
+    want, _, mix_w, _ = _step(augmentations, method, data, labels, frames, wav, 4, device, host_labels=labels)
+    try:
+        before = _stats(device)
+        _lib.check(lib.pcgmix_ctx_armed_debug(ctx, 200000, 600), "debug")
+        y, _, mix, _ = _step(augmentations, method, data, labels, frames, wav, 4, device)
+        after = _stats(device)
+        assert np.array_equal(mix, mix_w) and torch.equal(y, want)
+        assert after[1] - before[1] == 1 and after[2] - before[2] == 1
+    finally:
+        _lib.check(lib.pcgmix_ctx_armed_debug(ctx, 0, 0), "debug")
+    y, _, mix, _ = _step(augmentations, method, data, labels, frames, wav, 4, device)
+    assert torch.equal(y, want) and _stats(device)[2] == after[2]
+
+
 def test_armed_step_on_spectrograms(device):
     """2D plain splice (augmentations2d.py:206-221): (B, 1, F, W) through the same armed kernel."""
     rs = np.random.RandomState(5)
