@@ -128,6 +128,32 @@ __device__ __forceinline__ int onehot_argmax(const int64_t* __restrict__ ohe, in
   return best;
 }
 
+// Labels of rows r0 .. r0+3 (rows >= B read row B-1 and report 0) packed one byte each.  For two classes
+// the four 16-byte rows are loaded FIRST and compared afterwards: four calls of onehot_argmax compile to
+// load, wait, compare four times over — four memory round trips in front of the word the host waits for.
+__device__ __forceinline__ uint32_t onehot_argmax4(const int64_t* __restrict__ ohe, int K, int r0, int B) {
+  uint32_t packed = 0;
+  if (K == 2 && !(reinterpret_cast<uintptr_t>(ohe) & 15)) {
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    ll2 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = r0 + j < B ? r0 + j : B - 1;
+      v[j] = *reinterpret_cast<const ll2*>(ohe + (size_t)r * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) packed |= (uint32_t)((r0 + j < B && v[j].y > v[j].x) ? 1 : 0) << (8 * j);
+    return packed;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = r0 + j;
+    const int best = onehot_argmax(ohe, K, r < B ? r : B - 1);
+    packed |= (uint32_t)(r < B ? best & 0xff : 0) << (8 * j);
+  }
+  return packed;
+}
+
 // pcgmix_saliency.hip: the displacement search of pcgmix_salopt_disp_f32; disp == nullptr leaves
 // the per-block results in `workspace` for launch_mix_warp's disp_part.
 // pay_*: pay_n16 16-byte words that one otherwise idle block copies from pay_src (device-readable

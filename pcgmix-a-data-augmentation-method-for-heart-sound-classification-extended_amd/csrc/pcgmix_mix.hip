@@ -626,13 +626,7 @@ __global__ __launch_bounds__(kThreads) void mix_armed_kernel(
     // word — valid by itself like the records, so neither a fence nor a flag (and no wait for the
     // stores to be acknowledged across the link) stands between the arg-max and the host
     if (threadIdx.x < 64) {
-      unsigned long long w = (unsigned long long)a.token << 32;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = 4 * lane + j;
-        const int best = onehot_argmax(a.ohe, a.K, r < B ? r : B - 1);
-        w |= (unsigned long long)(r < B ? best & 0xff : 0) << (8 * j);
-      }
+      const unsigned long long w = ((unsigned long long)a.token << 32) | onehot_argmax4(a.ohe, a.K, 4 * lane, B);
       __hip_atomic_store(a.lab64 + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (threadIdx.x == 0) { PCGMIX_ACLOCK(kPackB, 1); }
     }
@@ -726,13 +720,7 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_armed_kernel(
     if (threadIdx.x == 0) { PCGMIX_ACLOCK(kPackB, 0); }
     if (pay.n16 && (int)threadIdx.x < pay.n16) pay_dst[threadIdx.x] = pay.w[threadIdx.x];
     if (threadIdx.x < 64) {                      // labels, as mix_armed_kernel
-      unsigned long long w = (unsigned long long)a.token << 32;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = 4 * lane + j;
-        const int best = onehot_argmax(a.ohe, a.K, r < B ? r : B - 1);
-        w |= (unsigned long long)(r < B ? best & 0xff : 0) << (8 * j);
-      }
+      const unsigned long long w = ((unsigned long long)a.token << 32) | onehot_argmax4(a.ohe, a.K, 4 * lane, B);
       __hip_atomic_store(a.lab64 + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       if (threadIdx.x == 0) { PCGMIX_ACLOCK(kPackB, 1); }
     }
