@@ -1246,7 +1246,7 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     a.timeout_ticks = c->armed_timeout;
     const auto t_launch = std::chrono::steady_clock::now();
     const int err = pcgmix::launch_mix_tq_armed(x, y, a, lam, reinterpret_cast<const double*>(sl.pinned),
-                                                op_dev, n_knots, B, C, T, s, c->payload.data(),
+                                                reinterpret_cast<double*>(sl.dev), op_dev, n_knots, B, C, T, s, c->payload.data(),
                                                 (int)c->payload.size(), c->payload_dst);
     if (err) return err;
     c->armed_stream = s;

@@ -104,10 +104,11 @@ int launch_mix_armed(const float* x, float* y, const ArmedArgs& a, float lam, in
                      hipStream_t s, const void* pay = nullptr, int pay_bytes = 0,
                      void* pay_dst = nullptr);
 // The same for the splice + warp kernel (durmixmagwarp): knots_host = this step's knots (B, n_knots, C)
-// float64 in device-readable pinned memory, spline_op the constant operator on the device.
+// float64 in device-readable pinned memory, knots_dev = device scratch of the same size (each sample's
+// relay copies its knots there once), spline_op the constant operator on the device.
 int mix_tq_armed_ok(int B, int C, int T, int n_knots);
 int launch_mix_tq_armed(const float* x, float* y, const ArmedArgs& a, float lam, const double* knots_host,
-                        const double* spline_op, int n_knots, int B, int C, int T, hipStream_t s,
+                        double* knots_dev, const double* spline_op, int n_knots, int B, int C, int T, hipStream_t s,
                         const void* pay = nullptr, int pay_bytes = 0, void* pay_dst = nullptr);
 // first maximum of row b of a (B, K) int64 one-hot matrix (torch.max / np.argmax, augmentations.py:501)
 __device__ __forceinline__ int onehot_argmax(const int64_t* __restrict__ ohe, int K, int b) {

@@ -410,8 +410,15 @@ __device__ __forceinline__ void tq_body(
   const int n_op = n_knots + 4 * (n_knots - 1) * n_knots;
   double* opl = reinterpret_cast<double*>(thr + ((n_knots + 1) & ~1));
   double* knl = opl + n_op;
-  for (int i = threadIdx.x; i < n_op + n_knots * C; i += kThreads)
-    opl[i] = i < n_op ? spline_op[i] : knots_b[i - n_op];
+  for (int i = threadIdx.x; i < n_op + n_knots * C; i += kThreads) {
+    if (LATE && i >= n_op) {       // written by another block of this launch: agent-scope load (no stale L2 line)
+      const unsigned long long bits = __hip_atomic_load(
+          reinterpret_cast<const unsigned long long*>(knots_b) + (i - n_op), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      opl[i] = __longlong_as_double((long long)bits);
+    } else {
+      opl[i] = i < n_op ? spline_op[i] : knots_b[i - n_op];
+    }
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < n_knots; i += kThreads) thr[i] = (int)ceil(opl[i]);
   for (int i = threadIdx.x; i < C * rec_per_ch; i += kThreads) {
@@ -710,8 +717,9 @@ __global__ __launch_bounds__(kThreads) void mix_armed_kernel(
 template <int CG, int UT>
 __global__ __launch_bounds__(kThreads) void mix_warp_tq_armed_kernel(
     const float* __restrict__ x, float* __restrict__ y, const ArmedArgs a, float lam, float oml,
-    const double* __restrict__ knots_host, const double* __restrict__ spline_op, int n_knots, int B,
-    int C, int T, const PayPack pay, uint4* __restrict__ pay_dst) {
+    const double* __restrict__ knots_host, double* __restrict__ knots_dev,
+    const double* __restrict__ spline_op, int n_knots, int B, int C, int T, const PayPack pay,
+    uint4* __restrict__ pay_dst) {
   extern __shared__ __align__(16) double lds[];
   __shared__ unsigned long long rec_s[8];
   const int b = blockIdx.y;
@@ -728,9 +736,39 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_armed_kernel(
   if (b >= B) return;
   const unsigned long long t0 = wall_clock64();
   if (blockIdx.x == 0 && threadIdx.x == 0) { PCGMIX_ACLOCK(b, 0); }
-  // (Tried: the sample's relay copies the knots to device memory once and stamps a "ready" word the other
-  // blocks wait for — 49 KB across the link instead of 245 KB at (256,4,5000); two fences and a second wait
-  // later the step was 25.0 us instead of 23.0: the link was not in the way.)
+  // The sample's knots cross the link ONCE: its relay copies them from the pinned slot to the slot's device
+  // twin and stamps word 7 of the device record; the sample's blocks wait for that stamp — it comes
+  // microseconds before the record can — and stage from device memory.  With every block reading its
+  // 8 * n_knots * C bytes from the pinned slot itself, 2,560 small reads (245 KB at (256,4,5000)) were in
+  // flight across the link when the label words and the relays' first polls had to cross it: labels
+  // 2.2 us after the entry instead of 0.6, records seen 7.7 us after the labels instead of 4.4.
+  const int nkc = n_knots * C;
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    // agent-scope stores (written through, no L2 write-back) and a wait for their acknowledgement instead of
+    // a release fence: 256 relays issuing buffer_wbl2 at once held up everything behind them — the label
+    // words reached the host 8 us late
+    for (int i = lane; i < nkc; i += 64)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(knots_dev) + (size_t)b * nkc + i,
+                         reinterpret_cast<const unsigned long long*>(knots_host)[(size_t)b * nkc + i],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+      __hip_atomic_store(a.rec_d + (size_t)b * kArmedRecWords + 7, (unsigned long long)a.seq << 32,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x < 64) {
+    const unsigned long long* src = a.rec_d + (size_t)b * kArmedRecWords + 7;
+    bool ready = false;
+    for (;;) {
+      const uint32_t st = (uint32_t)(__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32);
+      if (st == a.seq) { ready = true; break; }
+      if (wall_clock64() - t0 > 2 * a.timeout_ticks) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (lane == 0) rec_s[6] = ready ? 1ull : 0ull;
+  }
+  __syncthreads();
+  if (!rec_s[6]) return;                         // block-uniform: the relay never came (its block gave up?)
   auto await = [&](StateMap& sm, int& m) -> bool {
     const uint32_t go = a.seq, stop = a.seq | kArmedAbort;
     const int word = lane < 6 ? lane : 5;
@@ -796,8 +834,8 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_armed_kernel(
   StateMap sm0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) { sm0.a[k] = 0; sm0.n[k] = 0; sm0.delta[k] = 0; }
-  tq_body<CG, UT, true>(x, y, lam, oml, knots_host + (size_t)b * n_knots * C, spline_op, n_knots, C, T, b, b,
-                        sm0, lds, await);
+  tq_body<CG, UT, true>(x, y, lam, oml, knots_dev + (size_t)b * nkc, spline_op, n_knots, C, T, b, b, sm0, lds,
+                        await);
   if (blockIdx.x == 1 && threadIdx.x == 0) { PCGMIX_ACLOCK(b, 3); }
 }
 
@@ -991,14 +1029,14 @@ int pcgmix::mix_tq_armed_ok(int B, int C, int T, int n_knots) {
 }
 
 int pcgmix::launch_mix_tq_armed(const float* x, float* y, const ArmedArgs& a, float lam,
-                                const double* knots_host, const double* spline_op, int n_knots, int B,
+                                const double* knots_host, double* knots_dev, const double* spline_op, int n_knots, int B,
                                 int C, int T, hipStream_t s, const void* pay_host, int pay_bytes,
                                 void* pay_dst) {
   using namespace pcgmix;
   if (pay_bytes < 0 || pay_bytes > kPackPayBytes ||
       (pay_bytes > 0 && (!pay_host || !pay_dst || (reinterpret_cast<uintptr_t>(pay_dst) & 15))))
     return hipErrorInvalidValue;
-  if (!x || !y || x == y || !knots_host || !spline_op || !mix_tq_armed_ok(B, C, T, n_knots) ||
+  if (!x || !y || x == y || !knots_host || !knots_dev || !spline_op || !mix_tq_armed_ok(B, C, T, n_knots) ||
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) || !a.ohe || a.K <= 0 ||
       !a.lab64 || a.K > 256 || !a.rec_h || !a.rec_d || !a.abort_h || a.seq == 0 || (a.seq & kArmedAbort) ||
       ((reinterpret_cast<uintptr_t>(a.rec_h) | reinterpret_cast<uintptr_t>(a.rec_d) |
@@ -1015,7 +1053,8 @@ int pcgmix::launch_mix_tq_armed(const float* x, float* y, const ArmedArgs& a, fl
   dim3 grid((unsigned)((T + kThreads * 4 * mv.UT - 1) / (kThreads * 4 * mv.UT)), (unsigned)B), block(kThreads);
 #define PCGMIX_LAUNCH_TQA(CGV, UTV)                                                                  \
   hipLaunchKernelGGL((mix_warp_tq_armed_kernel<CGV, UTV>), grid, block, mv.lds_tq, s, x, y, a, lam,  \
-                     oml, knots_host, spline_op, n_knots, B, C, T, pay, static_cast<uint4*>(pay_dst))
+                     oml, knots_host, knots_dev, spline_op, n_knots, B, C, T, pay,                   \
+                     static_cast<uint4*>(pay_dst))
   if (mv.CG == 4) { if (mv.UT == 2) PCGMIX_LAUNCH_TQA(4, 2); else PCGMIX_LAUNCH_TQA(4, 1); }
   else if (mv.CG == 2) { if (mv.UT == 2) PCGMIX_LAUNCH_TQA(2, 2); else PCGMIX_LAUNCH_TQA(2, 1); }
   else { if (mv.UT == 2) PCGMIX_LAUNCH_TQA(1, 2); else PCGMIX_LAUNCH_TQA(1, 1); }
