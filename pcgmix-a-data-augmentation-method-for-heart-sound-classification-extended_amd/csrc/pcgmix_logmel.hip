@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kMelThreads) void logmel_kernel(
     for (int i = tid; i < n_mels * W; i += kMelThreads) {  // coalesced rows of the image
       float v = 0.f;  // zero padding is applied AFTER normalisation (cell 6:99, 141-142)
       if (inside) v = (fmaxf(img[i] - ref_db, floor_db) - mean) / inv_guard;
-      out[i] = v;
+      __builtin_nontemporal_store(v, out + i);
     }
   } else {
     for (int i = tid; i < n_mels * W; i += kMelThreads) {

@@ -1505,7 +1505,7 @@ __global__ __launch_bounds__(kPotThreads) void potes_input_grad_pair_kernel(
         float* dst = gx + (size_t)n * T + u;
         const float o0 = acc0.x + acc0.y, o1 = acc1.x + acc1.y;
         if (u + 1 < T && !(reinterpret_cast<uintptr_t>(dst) & 7)) {
-          *reinterpret_cast<f2*>(dst) = f2{o0, o1};
+          __builtin_nontemporal_store(f2{o0, o1}, reinterpret_cast<f2*>(dst));
         } else {
           if (u < T) dst[0] = o0;
           if (u + 1 < T) dst[1] = o1;

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kSalThreads) void saliency_post_kernel(
   for (int t = threadIdx.x; t < T; t += kSalThreads) {
     float v = __fdiv_rn(s[t], rmax);  // saliency.py:84; 0/0 -> NaN -> 0 (saliency.py:87)
     if (v != v) v = 0.f;
-    sal[(size_t)b * T + t] = v;
+    __builtin_nontemporal_store(v, sal + (size_t)b * T + t);
   }
   PCGMIX_SCLOCK(5);
 }
