@@ -1155,10 +1155,27 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
   //    two-launch chain below this takes the splice's launch (3 us of host time, 3-4 us until the
   //    command processor has started it) and the label kernel's own start out of the chain
   //    label -> host -> splice that bounds the step.
+  //    The same for splice + warp (durmixmagwarp): the knots go into a pinned slot and cross the link
+  //    inside the kernel, once per sample, so the label launch AND the fetch launch of the staged path
+  //    leave the chain.
   static const bool armed_ok = getenv("PCGMIX_NO_ARMED") == nullptr;
-  if (armed_ok && small && readback && num_classes <= 256) {
+  const bool arm_base = armed_ok && readback && num_classes <= 256 &&
+                        c->payload.size() <= (size_t)pcgmix::kPackPayBytes &&
+                        !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15);
+  const bool arm_plain = arm_base && small;
+  const bool arm_warp = arm_base && knots && pcgmix::mix_tq_armed_ok(B, C, T, n_knots);
+  if (arm_plain || arm_warp) {
+    const int my_slot = c->next;               // (splice + warp only: the slot that carries the knots)
+    Slot& sl = c->slot[my_slot];
+    const double* op_dev = nullptr;
     if ((e = labels_prepare(c, B, s)) != hipSuccess) return (int)e;
     if ((e = armed_prepare(c, s)) != hipSuccess) return (int)e;
+    if (arm_warp) {
+      const size_t nkb = (size_t)B * n_knots * C * sizeof(double);
+      if ((e = slot_reserve(c, my_slot, nkb)) != hipSuccess) return (int)e;
+      if ((e = spline_op_device(c, T, n_knots, &op_dev)) != hipSuccess) return (int)e;
+      std::memcpy(sl.pinned, knots, nkb);
+    }
     pcgmix::ArmedArgs a;
     a.ohe = target_ohe_dev;
     a.K = num_classes;
@@ -1170,8 +1187,12 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     a.seq = c->armed_seq;
     a.timeout_ticks = c->armed_timeout;
     const auto t_launch = std::chrono::steady_clock::now();
-    const int err = pcgmix::launch_mix_armed(x, y, a, lam, B, C, T, s, c->payload.data(),
-                                             (int)c->payload.size(), c->payload_dst);
+    const int err =
+        arm_warp ? pcgmix::launch_mix_tq_armed(x, y, a, lam, reinterpret_cast<const double*>(sl.pinned),
+                                               reinterpret_cast<double*>(sl.dev), op_dev, n_knots, B, C, T, s,
+                                               c->payload.data(), (int)c->payload.size(), c->payload_dst)
+                 : pcgmix::launch_mix_armed(x, y, a, lam, B, C, T, s, c->payload.data(),
+                                            (int)c->payload.size(), c->payload_dst);
     if (err) return err;
     c->armed_stream = s;
     c->armed_any = true;
@@ -1185,6 +1206,7 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     int64_t lab64a[pcgmix::kPackB];
     if (bad16 || (e = labels_wait_armed(c, B, lab64a)) != hipSuccess) {
       armed_write(c, a.seq | pcgmix::kArmedAbort, nullptr, nullptr, B);
+      if (arm_warp) (void)slot_commit(c, my_slot, s);      // the kernel may still read the slot's knots
       return bad16 ? bad16 : (int)e;
     }
     lap(3);
@@ -1199,89 +1221,17 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     c->payload.clear();
     c->payload_dst = nullptr;
     ++c->armed_calls;
+    if (arm_warp && (e = slot_commit(c, my_slot, s)) != hipSuccess) return (int)e;
+    lap(6);
     // The relays give up 1 s after the kernel STARTED, which is later than t_launch: records written
     // within 0.4 s of the launch were in time whatever happened in between.  Otherwise (a debugger, a
-    // stopped process, a host that lost its CPU for that long): wait for the kernel and look.
+    // stopped process, a host that lost its CPU for that long): wait for the kernel and look; if the
+    // blocks gave up, the step again through the unarmed path, with the labels this call holds.
     if (std::chrono::steady_clock::now() - t_launch > std::chrono::milliseconds(400)) {
       ++c->armed_slow;
       if ((e = hipStreamSynchronize(s)) != hipSuccess) return (int)e;
       if (__atomic_load_n(c->flag + 8, __ATOMIC_ACQUIRE) == a.seq) {
         ++c->armed_aborted;
-        const int err2 = pcgmix::launch_mix_karg(x, y, fr16, mix16, lam, B, C, T, s);
-        if (err2) return err2;
-      }
-    }
-    lap(6);
-    lap(7);
-    seed_ahead_post(c, step + 1);
-    ++c->calls;
-    return hipSuccess;
-  }
-
-  // 0b. The same for splice + warp (durmixmagwarp through the strict signature): the knots go into a
-  //     pinned slot the waiting blocks read directly (8 * n_knots * C bytes per sample), so the label
-  //     launch AND the fetch launch of the path below leave the chain.
-  if (armed_ok && readback && knots && num_classes <= 256 &&
-      c->payload.size() <= (size_t)pcgmix::kPackPayBytes &&
-      !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) &&
-      pcgmix::mix_tq_armed_ok(B, C, T, n_knots)) {
-    const size_t nkb = (size_t)B * n_knots * C * sizeof(double);
-    const int my_slot = c->next;
-    Slot& sl = c->slot[my_slot];
-    const double* op_dev = nullptr;
-    if ((e = labels_prepare(c, B, s)) != hipSuccess) return (int)e;
-    if ((e = armed_prepare(c, s)) != hipSuccess) return (int)e;
-    if ((e = slot_reserve(c, my_slot, nkb)) != hipSuccess) return (int)e;
-    if ((e = spline_op_device(c, T, n_knots, &op_dev)) != hipSuccess) return (int)e;
-    std::memcpy(sl.pinned, knots, nkb);
-    pcgmix::ArmedArgs a;
-    a.ohe = target_ohe_dev;
-    a.K = num_classes;
-    a.lab64 = reinterpret_cast<unsigned long long*>(c->lab);
-    a.token = c->token;
-    a.rec_h = c->rec_h;
-    a.rec_d = c->rec_d;
-    a.abort_h = c->flag + 8;
-    a.seq = c->armed_seq;
-    a.timeout_ticks = c->armed_timeout;
-    const auto t_launch = std::chrono::steady_clock::now();
-    const int err = pcgmix::launch_mix_tq_armed(x, y, a, lam, reinterpret_cast<const double*>(sl.pinned),
-                                                reinterpret_cast<double*>(sl.dev), op_dev, n_knots, B, C, T, s, c->payload.data(),
-                                                (int)c->payload.size(), c->payload_dst);
-    if (err) return err;
-    c->armed_stream = s;
-    c->armed_any = true;
-    lap(0);
-    int16_t fr16[pcgmix::kPackB * 5], mix16[pcgmix::kPackB];
-    const int bad16 = pack_frames16(frames, B, T, fr16);
-    lap(1);
-    seed_for_step(c, step);
-    lap(2);
-    int64_t lab64a[pcgmix::kPackB];
-    if (bad16 || (e = labels_wait_armed(c, B, lab64a)) != hipSuccess) {
-      armed_write(c, a.seq | pcgmix::kArmedAbort, nullptr, nullptr, B);
-      (void)slot_commit(c, my_slot, s);        // the kernel may still read the slot's knots
-      return bad16 ? bad16 : (int)e;
-    }
-    lap(3);
-    draw_partners(c, lab64a, B, mix_out, nullptr, mix16);
-    lap(4);
-    if (c->armed_stall_ms > 0) {
-      timespec ts{c->armed_stall_ms / 1000, (long)(c->armed_stall_ms % 1000) * 1000000L};
-      nanosleep(&ts, nullptr);
-    }
-    armed_write(c, a.seq, fr16, mix16, B);
-    lap(5);
-    c->payload.clear();
-    c->payload_dst = nullptr;
-    ++c->armed_calls;
-    if ((e = slot_commit(c, my_slot, s)) != hipSuccess) return (int)e;
-    lap(6);
-    if (std::chrono::steady_clock::now() - t_launch > std::chrono::milliseconds(400)) {
-      ++c->armed_slow;
-      if ((e = hipStreamSynchronize(s)) != hipSuccess) return (int)e;
-      if (__atomic_load_n(c->flag + 8, __ATOMIC_ACQUIRE) == a.seq) {
-        ++c->armed_aborted;          // the blocks gave up: the step again, with the labels we hold
         return pcgmix_augment_plain_f32(c, x, y, nullptr, 0, lab64a, frames, step, lam, knots, n_knots,
                                         mix_out, B, C, T, stream);
       }
