@@ -63,4 +63,5 @@ loss = loop("pipelined cfg3 train step", 10_000, step3)
 print("final loss", float(loss))
 assert torch.isfinite(loss)
 saliency.set_saliency_model(None)
+print("armed steps | checked after a stream synchronisation | launched again:", bench.armed_step_stats(dev))
 print("soak ok")
