@@ -203,3 +203,26 @@ def check(err: int, what: str) -> None:
         msg = load().pcgmix_error_string(err)
         raise RuntimeError(f"{what} failed: hipError_t {err} "
                            f"({msg.decode() if msg else 'unknown'})")
+
+
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def capture_without_gc():
+    """Around a stream capture: collect now, then keep Python's cyclic collector off until the capture
+    has ended.  A collection that fires inside the capture runs finalizers of unrelated garbage on the
+    capturing thread — torch objects whose release makes HIP calls a capture does not allow — and the
+    process aborts inside torch (seen as a bare SIGABRT under ``Garbage-collecting`` in the second
+    ``GraphedTrainStep`` of a long test session; whether it happens depends on the allocation count at
+    that moment).  ``torch.cuda.graph`` collects before the capture for the same reason but leaves the
+    collector running."""
+    import gc
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()

@@ -325,7 +325,7 @@ class _SaliencyGraph:
         torch.cuda.current_stream(device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: HIP calls of other threads (e.g. RCCL's watchdog) must not abort the capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with _lib.capture_without_gc(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.sal = self._run()
 
     def _run(self):

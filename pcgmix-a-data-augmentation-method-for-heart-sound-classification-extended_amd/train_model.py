@@ -644,7 +644,7 @@ class GraphedTrainStep:
         want_tape = (self.use_tape and fold is not None and self.labels_mode
                      and isinstance(model, models.CNN_potes) and os.environ.get("PCGMIX_NO_TAPE") is None)
         tape = [] if want_tape else None
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with _lib.capture_without_gc(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             models.PotesStackFunction.defer_reduce = fold
             _lib.TAPE = tape
             try:
@@ -670,7 +670,7 @@ class GraphedTrainStep:
             for p, v in zip(sync.params, sync.views):
                 p.grad = v
             self.graph_update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_update, capture_error_mode="thread_local"):
+            with _lib.capture_without_gc(), torch.cuda.graph(self.graph_update, capture_error_mode="thread_local"):
                 self.opt.capture_update(self.aux[4:12])
 
     def _tape_covers_capture(self, tape, fold) -> bool:

@@ -544,3 +544,19 @@ def test_cpu_slices_of_one_node_do_not_overlap():
     # a small cgroup: whatever is there, at least two CPUs, never an empty mask
     assert hostprep._slice_for([3, 4, 5, 6], 5, 8) == [3, 4]
     assert hostprep._slice_for(list(range(16)), 1, 8) == list(range(8))
+
+
+def test_capture_without_gc_restores_the_collector():
+    import gc
+    from pcgmix_amd import _lib
+    assert gc.isenabled()
+    with _lib.capture_without_gc():
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with _lib.capture_without_gc():
+            assert not gc.isenabled()
+        assert not gc.isenabled()          # a caller that had it off keeps it off
+    finally:
+        gc.enable()
