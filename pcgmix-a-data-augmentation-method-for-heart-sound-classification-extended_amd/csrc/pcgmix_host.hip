@@ -5,8 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <immintrin.h>
 
+#include <pthread.h>
 #include <time.h>
-#include <unistd.h>
 
 #include <chrono>
 #include <cmath>
@@ -576,7 +576,7 @@ struct pcgmix_ctx {
     std::atomic<bool> quit{false};
     uint64_t step = 0;
     PyRandom* state = nullptr;
-    pid_t pid = 0;
+    int fork_generation = 0;       // of the process that started the helper
     long long hits = 0, misses = 0;
   } ahead;
   unsigned long long armed_timeout = 100000000ull;   // 1 s of the 100 MHz clock, from the kernel's start
@@ -603,6 +603,11 @@ extern "C" int pcgmix_fetch_h2d(const void* src_pinned, void* dst_dev, size_t nb
 
 namespace {
 
+// A forked child has the parent's context bytes but not its helper thread: everything that would wait for
+// the helper first checks that no fork happened since it was started.
+std::atomic<int> g_ctx_fork_generation{0};
+void ctx_mark_forked() { g_ctx_fork_generation.fetch_add(1, std::memory_order_relaxed); }
+
 void seed_ahead_run(pcgmix_ctx* c) {
   pcgmix_ctx::SeedAhead& a = c->ahead;
   for (;;) {
@@ -628,7 +633,8 @@ void seed_for_step(pcgmix_ctx* c, uint64_t step) {
   if (c->gate_step == step) return;
   pcgmix_ctx::SeedAhead& a = c->ahead;
   bool have = false;
-  if (a.state && a.job.load(std::memory_order_acquire) != 0) {
+  if (a.state && a.fork_generation == g_ctx_fork_generation.load(std::memory_order_relaxed) &&
+      a.job.load(std::memory_order_acquire) != 0) {
     while (a.job.load(std::memory_order_acquire) == 1) _mm_pause();      // <= one seeding
     have = a.step == step;
     if (have) std::memcpy(static_cast<void*>(c->seeded), a.state, sizeof(PyRandom));
@@ -650,11 +656,13 @@ void seed_ahead_post(pcgmix_ctx* c, uint64_t step) {
   static const bool enabled = getenv("PCGMIX_NO_SEED_AHEAD") == nullptr;
   if (!enabled) return;
   if (!a.state) {
+    static const int once = pthread_atfork(nullptr, nullptr, ctx_mark_forked);
+    (void)once;
     a.state = static_cast<PyRandom*>(::operator new(sizeof(PyRandom)));
-    a.pid = getpid();
+    a.fork_generation = g_ctx_fork_generation.load(std::memory_order_relaxed);
     a.th = std::thread([c] { seed_ahead_run(c); });
   }
-  if (a.pid != getpid()) return;                     // a forked child has no helper thread
+  if (a.fork_generation != g_ctx_fork_generation.load(std::memory_order_relaxed)) return;   // forked child
   if (a.job.load(std::memory_order_acquire) == 1) return;      // still busy with an older request
   a.step = step;
   a.job.store(1, std::memory_order_release);
@@ -697,7 +705,7 @@ extern "C" void pcgmix_ctx_destroy(pcgmix_ctx* c) {
     if (s.ev) (void)hipEventDestroy(s.ev);
   }
   if (c->ahead.state) {
-    if (c->ahead.pid == getpid()) {
+    if (c->ahead.fork_generation == g_ctx_fork_generation.load(std::memory_order_relaxed)) {
       {
         std::lock_guard<std::mutex> lk(c->ahead.mu);
         c->ahead.quit.store(true);
@@ -1016,8 +1024,9 @@ hipError_t armed_prepare(pcgmix_ctx* c, hipStream_t s) {
   }
   // the records are one set per context: an armed kernel still queued on ANOTHER stream must have read
   // its records before they are rewritten (on the same stream the label wait already implies it)
+  // (the whole device, not the other stream: its handle may have been destroyed by its owner since)
   if (c->armed_any && c->armed_stream != s) {
-    const hipError_t e = hipStreamSynchronize(c->armed_stream);
+    const hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) return e;
   }
   c->armed_seq = c->armed_seq >= 0x7ffffffeu ? 1u : c->armed_seq + 1u;
