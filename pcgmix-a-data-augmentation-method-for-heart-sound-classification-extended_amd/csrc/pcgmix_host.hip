@@ -1124,6 +1124,261 @@ extern "C" int pcgmix_ctx_flush_payload(pcgmix_ctx* c, pcgmix_stream_t stream) {
   return (int)e;
 }
 
+namespace {
+
+// One fired step of a plain method, as pcgmix_augment_plain_f32 received it, and the three ways it is
+// carried out.  phase_ns accumulates the host time between laps (pcgmix_ctx_phase_times).
+struct PlainStep {
+  pcgmix_ctx* c;
+  const float* x;
+  float* y;
+  const int64_t* target_ohe_dev;
+  int num_classes;
+  const int64_t* labels_host;
+  const int64_t* frames;
+  uint64_t step;
+  float lam;
+  const double* knots;
+  int n_knots;
+  int64_t* mix_out;
+  int B, C, T;
+  hipStream_t s;
+  pcgmix_stream_t stream;
+  std::chrono::steady_clock::time_point tp;
+  void lap(int i) {
+    const auto now = std::chrono::steady_clock::now();
+    c->phase_ns[i] += std::chrono::duration<double, std::nano>(now - tp).count();
+    tp = now;
+  }
+};
+
+// Strict signature, small plain batch (BASELINE configs[1]): ONE launch at the start of the call —
+//    the splice ARMED before its index block exists (pcgmix_kernels.h, ArmedArgs).  Its first block
+//    does the label arg-max; the host picks the labels up, draws the partners and writes one stamped
+//    record per sample into host-mapped memory, where the waiting blocks find them.  Against the
+//    two-launch chain below this takes the splice's launch (3 us of host time, 3-4 us until the
+//    command processor has started it) and the label kernel's own start out of the chain
+//    label -> host -> splice that bounds the step.
+//    The same for splice + warp (durmixmagwarp): the knots go into a pinned slot and cross the link
+//    inside the kernel, once per sample, so the label launch AND the fetch launch of the staged path
+//    leave the chain.
+int step_armed(PlainStep& p, bool arm_warp) {
+  pcgmix_ctx* c = p.c;
+  const float* x = p.x;
+  float* y = p.y;
+  const int64_t* frames = p.frames;
+  const uint64_t step = p.step;
+  const float lam = p.lam;
+  const double* knots = p.knots;
+  const int n_knots = p.n_knots, B = p.B, C = p.C, T = p.T;
+  int64_t* mix_out = p.mix_out;
+  hipStream_t s = p.s;
+  hipError_t e = hipSuccess;
+  const int64_t* target_ohe_dev = p.target_ohe_dev;
+  const int num_classes = p.num_classes;
+  pcgmix_stream_t stream = p.stream;
+  const int my_slot = c->next;               // (splice + warp only: the slot that carries the knots)
+  Slot& sl = c->slot[my_slot];
+  const double* op_dev = nullptr;
+  if ((e = labels_prepare(c, B, s)) != hipSuccess) return (int)e;
+  if ((e = armed_prepare(c, s)) != hipSuccess) return (int)e;
+  if (arm_warp) {
+    const size_t nkb = (size_t)B * n_knots * C * sizeof(double);
+    if ((e = slot_reserve(c, my_slot, nkb)) != hipSuccess) return (int)e;
+    if ((e = spline_op_device(c, T, n_knots, &op_dev)) != hipSuccess) return (int)e;
+    std::memcpy(sl.pinned, knots, nkb);
+  }
+  pcgmix::ArmedArgs a;
+  a.ohe = target_ohe_dev;
+  a.K = num_classes;
+  a.lab64 = reinterpret_cast<unsigned long long*>(c->lab);
+  a.token = c->token;
+  a.rec_h = c->rec_h;
+  a.rec_d = c->rec_d;
+  a.abort_h = c->flag + 8;
+  a.seq = c->armed_seq;
+  a.timeout_ticks = c->armed_timeout;
+  const auto t_launch = std::chrono::steady_clock::now();
+  const int err =
+      arm_warp ? pcgmix::launch_mix_tq_armed(x, y, a, lam, reinterpret_cast<const double*>(sl.pinned),
+                                             reinterpret_cast<double*>(sl.dev), op_dev, n_knots, B, C, T, s,
+                                             c->payload.data(), (int)c->payload.size(), c->payload_dst)
+               : pcgmix::launch_mix_armed(x, y, a, lam, B, C, T, s, c->payload.data(),
+                                          (int)c->payload.size(), c->payload_dst);
+  if (err) return err;
+  c->armed_stream = s;
+  c->armed_any = true;
+  p.lap(0);
+  // from here on the kernel is waiting: every way out writes its records
+  int16_t fr16[pcgmix::kPackB * 5], mix16[pcgmix::kPackB];
+  const int bad16 = pack_frames16(frames, B, T, fr16);
+  p.lap(1);
+  seed_for_step(c, step);
+  p.lap(2);
+  int64_t lab64a[pcgmix::kPackB];
+  if (bad16 || (e = labels_wait_armed(c, B, lab64a)) != hipSuccess) {
+    armed_write(c, a.seq | pcgmix::kArmedAbort, nullptr, nullptr, B);
+    if (arm_warp) (void)slot_commit(c, my_slot, s);      // the kernel may still read the slot's knots
+    return bad16 ? bad16 : (int)e;
+  }
+  p.lap(3);
+  draw_partners(c, lab64a, B, mix_out, nullptr, mix16);
+  p.lap(4);
+  if (c->armed_stall_ms > 0) {
+    timespec ts{c->armed_stall_ms / 1000, (long)(c->armed_stall_ms % 1000) * 1000000L};
+    nanosleep(&ts, nullptr);
+  }
+  armed_write(c, a.seq, fr16, mix16, B);
+  p.lap(5);
+  c->payload.clear();
+  c->payload_dst = nullptr;
+  ++c->armed_calls;
+  if (arm_warp && (e = slot_commit(c, my_slot, s)) != hipSuccess) return (int)e;
+  p.lap(6);
+  // The relays give up 1 s after the kernel STARTED, which is later than t_launch: records written
+  // within 0.4 s of the launch were in time whatever happened in between.  Otherwise (a debugger, a
+  // stopped process, a host that lost its CPU for that long): wait for the kernel and look; if the
+  // blocks gave up, the step again through the unarmed path, with the labels this call holds.
+  if (std::chrono::steady_clock::now() - t_launch > std::chrono::milliseconds(400)) {
+    ++c->armed_slow;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return (int)e;
+    if (__atomic_load_n(c->flag + 8, __ATOMIC_ACQUIRE) == a.seq) {
+      ++c->armed_aborted;
+      return pcgmix_augment_plain_f32(c, x, y, nullptr, 0, lab64a, frames, step, lam, knots, n_knots,
+                                      mix_out, B, C, T, stream);
+    }
+  }
+  p.lap(7);
+  seed_ahead_post(c, step + 1);
+  ++c->calls;
+  return hipSuccess;
+}
+
+// Small plain batches (BASELINE configs[1]: B = 256): the index block travels in the splice
+//     kernel's ARGUMENTS — no staging slot, no host-to-device copy in the chain label kernel ->
+//     host -> splice that bounds a strict-signature step.
+int step_karg(PlainStep& p) {
+  pcgmix_ctx* c = p.c;
+  const float* x = p.x;
+  float* y = p.y;
+  const int64_t* frames = p.frames;
+  const uint64_t step = p.step;
+  const float lam = p.lam;
+  const int B = p.B, C = p.C, T = p.T;
+  int64_t* mix_out = p.mix_out;
+  hipStream_t s = p.s;
+  hipError_t e = hipSuccess;
+  const int64_t* labels_host = p.labels_host;
+  const bool readback = labels_host == nullptr;
+  int16_t fr16[pcgmix::kPackB * 5], mix16[pcgmix::kPackB];
+  const int bad16 = pack_frames16(frames, B, T, fr16);
+  p.lap(1);
+  seed_for_step(c, step);
+  p.lap(2);
+  std::vector<int64_t> lab64k;
+  const int64_t* labels_k = labels_host;
+  if (readback) {
+    if ((e = labels_wait(c, s)) != hipSuccess) return (int)e;
+    lab64k.resize((size_t)B);
+    for (int b = 0; b < B; ++b) lab64k[(size_t)b] = c->lab[b];
+    labels_k = lab64k.data();
+  }
+  p.lap(3);
+  if (bad16) return bad16;
+  draw_partners(c, labels_k, B, mix_out, nullptr, mix16);
+  p.lap(4);
+  p.lap(5);
+  const int err = pcgmix::launch_mix_karg(x, y, fr16, mix16, lam, B, C, T, s, c->payload.data(),
+                                          (int)c->payload.size(), c->payload_dst);
+  if (err) return err;
+  c->payload.clear();
+  c->payload_dst = nullptr;
+  p.lap(6);
+  p.lap(7);
+  seed_ahead_post(c, step + 1);
+  ++c->calls;
+  return hipSuccess;
+}
+
+// Everything else: a staging slot carries boundaries, partners, knots and payload in one copy.
+int step_staged(PlainStep& p) {
+  pcgmix_ctx* c = p.c;
+  const float* x = p.x;
+  float* y = p.y;
+  const int64_t* frames = p.frames;
+  const uint64_t step = p.step;
+  const float lam = p.lam;
+  const double* knots = p.knots;
+  const int n_knots = p.n_knots, B = p.B, C = p.C, T = p.T;
+  int64_t* mix_out = p.mix_out;
+  hipStream_t s = p.s;
+  hipError_t e = hipSuccess;
+  const int64_t* labels_host = p.labels_host;
+  const bool readback = labels_host == nullptr;
+  // 2. staging slot, boundaries validated and packed, knots copied, generator seeded
+  const size_t n_int = (size_t)B * 6, n_int_pad = (n_int + 1) & ~(size_t)1;
+  const size_t nk = knots ? (size_t)B * n_knots * C : 0;
+  const size_t pay_off = (n_int_pad * 4 + nk * sizeof(double) + 15) & ~(size_t)15;
+  const size_t nbytes = pay_off + c->payload.size();
+  const int my_slot = c->next;           // advanced only when the step has been enqueued
+  Slot& sl = c->slot[my_slot];
+  if ((e = slot_reserve(c, my_slot, nbytes)) != hipSuccess) return (int)e;
+  p.lap(1);
+  int32_t* st = reinterpret_cast<int32_t*>(sl.pinned);
+  const int bad = pack_frames(frames, B, T, st, nullptr);
+  const double* op_dev = nullptr;
+  const double* knots_dev = nullptr;
+  if (knots) {
+    if ((e = spline_op_device(c, T, n_knots, &op_dev)) != hipSuccess) return (int)e;
+    std::memcpy(sl.pinned + n_int_pad * 4, knots, nk * sizeof(double));
+    knots_dev = reinterpret_cast<const double*>(sl.dev + n_int_pad * 4);
+  }
+  if (!c->payload.empty()) std::memcpy(sl.pinned + pay_off, c->payload.data(), c->payload.size());
+  seed_for_step(c, step);
+
+  p.lap(2);
+  // 3. wait for the labels (the one host wait the reference's signature forces,
+  //    augmentations.py:501): spin on the flag word the kernel releases; if it does not show up
+  //    within 2 ms fall back to a stream synchronisation
+  std::vector<int64_t> lab64;
+  const int64_t* labels = labels_host;
+  if (readback) {
+    if ((e = labels_wait(c, s)) != hipSuccess) return (int)e;
+    lab64.resize((size_t)B);
+    for (int b = 0; b < B; ++b) lab64[(size_t)b] = c->lab[b];
+    labels = lab64.data();
+  }
+  p.lap(3);
+  if (bad) return bad;                       // malformed boundaries: nothing else is enqueued
+
+  // 4. partners: groups of equal label, each permuted by a fresh Random(step).sample
+  draw_partners(c, labels, B, mix_out, st + (size_t)B * 5);
+  p.lap(4);
+  // 5. one H2D copy, the launch, the slot's event behind it.  (Round 4 tried the fetch on a side
+  //    stream of the context, beside the previous step's kernels: PCGmix+ train step 129.0 -> 128.0 us,
+  //    but the extra HIP stream can share a hardware queue with the stream a PIPELINED step augments on
+  //    and serialise it — cfg3 train 229 -> 282 us inside the full bench; removed,
+  //    profiles/r4_magwarp_fetch_ahead.txt.)
+  if ((e = upload_slot(sl, nbytes, s)) != hipSuccess) return (int)e;
+  p.lap(5);
+  const int32_t* d = reinterpret_cast<const int32_t*>(sl.dev);
+  const int err = pcgmix::launch_mix_warp(x, y, d, d + (size_t)B * 5, nullptr, lam, knots_dev, op_dev,
+                                          knots ? n_knots : 0, nullptr, B, C, T, s,
+                                          sl.dev + pay_off, c->payload_dst,
+                                          (int)(c->payload.size() / 16));
+  if (err) return err;
+  c->payload.clear();
+  c->payload_dst = nullptr;
+  p.lap(6);
+  if ((e = slot_commit(c, my_slot, s)) != hipSuccess) return (int)e;
+  p.lap(7);
+  seed_ahead_post(c, step + 1);
+  ++c->calls;
+  return hipSuccess;
+}
+
+}  // namespace
+
 extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
                                         const int64_t* target_ohe_dev, int num_classes,
                                         const int64_t* labels_host, const int64_t* frames,
@@ -1136,12 +1391,8 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     return hipErrorInvalidValue;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (stream_is_capturing(s)) return hipErrorStreamCaptureUnsupported;
-  auto tp = std::chrono::steady_clock::now();
-  auto lap = [&](int i) {
-    const auto now = std::chrono::steady_clock::now();
-    c->phase_ns[i] += std::chrono::duration<double, std::nano>(now - tp).count();
-    tp = now;
-  };
+  PlainStep p{c, x, y, target_ohe_dev, num_classes, labels_host, frames, step, lam, knots, n_knots, mix_out,
+              B, C, T, s, stream, std::chrono::steady_clock::now()};
   int cur = 0;
   hipError_t e = hipGetDevice(&cur);
   if (e != hipSuccess) return (int)e;
@@ -1157,200 +1408,20 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
                      B <= pcgmix::kPackB && T <= 32767 && !(T & 3) &&
                      !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15);
 
-  // 0. Strict signature, small plain batch (BASELINE configs[1]): ONE launch at the start of the call —
-  //    the splice ARMED before its index block exists (pcgmix_kernels.h, ArmedArgs).  Its first block
-  //    does the label arg-max; the host picks the labels up, draws the partners and writes one stamped
-  //    record per sample into host-mapped memory, where the waiting blocks find them.  Against the
-  //    two-launch chain below this takes the splice's launch (3 us of host time, 3-4 us until the
-  //    command processor has started it) and the label kernel's own start out of the chain
-  //    label -> host -> splice that bounds the step.
-  //    The same for splice + warp (durmixmagwarp): the knots go into a pinned slot and cross the link
-  //    inside the kernel, once per sample, so the label launch AND the fetch launch of the staged path
-  //    leave the chain.
   static const bool armed_ok = getenv("PCGMIX_NO_ARMED") == nullptr;
   const bool arm_base = armed_ok && readback && num_classes <= 256 &&
                         c->payload.size() <= (size_t)pcgmix::kPackPayBytes &&
                         !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15);
   const bool arm_plain = arm_base && small;
   const bool arm_warp = arm_base && knots && pcgmix::mix_tq_armed_ok(B, C, T, n_knots);
-  if (arm_plain || arm_warp) {
-    const int my_slot = c->next;               // (splice + warp only: the slot that carries the knots)
-    Slot& sl = c->slot[my_slot];
-    const double* op_dev = nullptr;
-    if ((e = labels_prepare(c, B, s)) != hipSuccess) return (int)e;
-    if ((e = armed_prepare(c, s)) != hipSuccess) return (int)e;
-    if (arm_warp) {
-      const size_t nkb = (size_t)B * n_knots * C * sizeof(double);
-      if ((e = slot_reserve(c, my_slot, nkb)) != hipSuccess) return (int)e;
-      if ((e = spline_op_device(c, T, n_knots, &op_dev)) != hipSuccess) return (int)e;
-      std::memcpy(sl.pinned, knots, nkb);
-    }
-    pcgmix::ArmedArgs a;
-    a.ohe = target_ohe_dev;
-    a.K = num_classes;
-    a.lab64 = reinterpret_cast<unsigned long long*>(c->lab);
-    a.token = c->token;
-    a.rec_h = c->rec_h;
-    a.rec_d = c->rec_d;
-    a.abort_h = c->flag + 8;
-    a.seq = c->armed_seq;
-    a.timeout_ticks = c->armed_timeout;
-    const auto t_launch = std::chrono::steady_clock::now();
-    const int err =
-        arm_warp ? pcgmix::launch_mix_tq_armed(x, y, a, lam, reinterpret_cast<const double*>(sl.pinned),
-                                               reinterpret_cast<double*>(sl.dev), op_dev, n_knots, B, C, T, s,
-                                               c->payload.data(), (int)c->payload.size(), c->payload_dst)
-                 : pcgmix::launch_mix_armed(x, y, a, lam, B, C, T, s, c->payload.data(),
-                                            (int)c->payload.size(), c->payload_dst);
-    if (err) return err;
-    c->armed_stream = s;
-    c->armed_any = true;
-    lap(0);
-    // from here on the kernel is waiting: every way out writes its records
-    int16_t fr16[pcgmix::kPackB * 5], mix16[pcgmix::kPackB];
-    const int bad16 = pack_frames16(frames, B, T, fr16);
-    lap(1);
-    seed_for_step(c, step);
-    lap(2);
-    int64_t lab64a[pcgmix::kPackB];
-    if (bad16 || (e = labels_wait_armed(c, B, lab64a)) != hipSuccess) {
-      armed_write(c, a.seq | pcgmix::kArmedAbort, nullptr, nullptr, B);
-      if (arm_warp) (void)slot_commit(c, my_slot, s);      // the kernel may still read the slot's knots
-      return bad16 ? bad16 : (int)e;
-    }
-    lap(3);
-    draw_partners(c, lab64a, B, mix_out, nullptr, mix16);
-    lap(4);
-    if (c->armed_stall_ms > 0) {
-      timespec ts{c->armed_stall_ms / 1000, (long)(c->armed_stall_ms % 1000) * 1000000L};
-      nanosleep(&ts, nullptr);
-    }
-    armed_write(c, a.seq, fr16, mix16, B);
-    lap(5);
-    c->payload.clear();
-    c->payload_dst = nullptr;
-    ++c->armed_calls;
-    if (arm_warp && (e = slot_commit(c, my_slot, s)) != hipSuccess) return (int)e;
-    lap(6);
-    // The relays give up 1 s after the kernel STARTED, which is later than t_launch: records written
-    // within 0.4 s of the launch were in time whatever happened in between.  Otherwise (a debugger, a
-    // stopped process, a host that lost its CPU for that long): wait for the kernel and look; if the
-    // blocks gave up, the step again through the unarmed path, with the labels this call holds.
-    if (std::chrono::steady_clock::now() - t_launch > std::chrono::milliseconds(400)) {
-      ++c->armed_slow;
-      if ((e = hipStreamSynchronize(s)) != hipSuccess) return (int)e;
-      if (__atomic_load_n(c->flag + 8, __ATOMIC_ACQUIRE) == a.seq) {
-        ++c->armed_aborted;
-        return pcgmix_augment_plain_f32(c, x, y, nullptr, 0, lab64a, frames, step, lam, knots, n_knots,
-                                        mix_out, B, C, T, stream);
-      }
-    }
-    lap(7);
-    seed_ahead_post(c, step + 1);
-    ++c->calls;
-    return hipSuccess;
-  }
+  if (arm_plain || arm_warp) return step_armed(p, arm_warp);
 
-  // 1. start the label read-back first: everything below up to step 4 does not need the labels
-  //    and runs while the GPU finishes what precedes this call on `stream`
+  // start the label read-back first: what follows up to the partner draw does not need the labels
+  // and runs while the GPU finishes what precedes this call on `stream`
   if (readback && (e = labels_begin(c, target_ohe_dev, num_classes, B, s)) != hipSuccess)
     return (int)e;
-  lap(0);
-
-  // 1b. Small plain batches (BASELINE configs[1]: B = 256): the index block travels in the splice
-  //     kernel's ARGUMENTS — no staging slot, no host-to-device copy in the chain label kernel ->
-  //     host -> splice that bounds a strict-signature step.
-  if (small) {
-    int16_t fr16[pcgmix::kPackB * 5], mix16[pcgmix::kPackB];
-    const int bad16 = pack_frames16(frames, B, T, fr16);
-    lap(1);
-    seed_for_step(c, step);
-    lap(2);
-    std::vector<int64_t> lab64k;
-    const int64_t* labels_k = labels_host;
-    if (readback) {
-      if ((e = labels_wait(c, s)) != hipSuccess) return (int)e;
-      lab64k.resize((size_t)B);
-      for (int b = 0; b < B; ++b) lab64k[(size_t)b] = c->lab[b];
-      labels_k = lab64k.data();
-    }
-    lap(3);
-    if (bad16) return bad16;
-    draw_partners(c, labels_k, B, mix_out, nullptr, mix16);
-    lap(4);
-    lap(5);
-    const int err = pcgmix::launch_mix_karg(x, y, fr16, mix16, lam, B, C, T, s, c->payload.data(),
-                                            (int)c->payload.size(), c->payload_dst);
-    if (err) return err;
-    c->payload.clear();
-    c->payload_dst = nullptr;
-    lap(6);
-    lap(7);
-    seed_ahead_post(c, step + 1);
-    ++c->calls;
-    return hipSuccess;
-  }
-
-  // 2. staging slot, boundaries validated and packed, knots copied, generator seeded
-  const size_t n_int = (size_t)B * 6, n_int_pad = (n_int + 1) & ~(size_t)1;
-  const size_t nk = knots ? (size_t)B * n_knots * C : 0;
-  const size_t pay_off = (n_int_pad * 4 + nk * sizeof(double) + 15) & ~(size_t)15;
-  const size_t nbytes = pay_off + c->payload.size();
-  const int my_slot = c->next;           // advanced only when the step has been enqueued
-  Slot& sl = c->slot[my_slot];
-  if ((e = slot_reserve(c, my_slot, nbytes)) != hipSuccess) return (int)e;
-  lap(1);
-  int32_t* st = reinterpret_cast<int32_t*>(sl.pinned);
-  const int bad = pack_frames(frames, B, T, st, nullptr);
-  const double* op_dev = nullptr;
-  const double* knots_dev = nullptr;
-  if (knots) {
-    if ((e = spline_op_device(c, T, n_knots, &op_dev)) != hipSuccess) return (int)e;
-    std::memcpy(sl.pinned + n_int_pad * 4, knots, nk * sizeof(double));
-    knots_dev = reinterpret_cast<const double*>(sl.dev + n_int_pad * 4);
-  }
-  if (!c->payload.empty()) std::memcpy(sl.pinned + pay_off, c->payload.data(), c->payload.size());
-  seed_for_step(c, step);
-
-  lap(2);
-  // 3. wait for the labels (the one host wait the reference's signature forces,
-  //    augmentations.py:501): spin on the flag word the kernel releases; if it does not show up
-  //    within 2 ms fall back to a stream synchronisation
-  std::vector<int64_t> lab64;
-  const int64_t* labels = labels_host;
-  if (readback) {
-    if ((e = labels_wait(c, s)) != hipSuccess) return (int)e;
-    lab64.resize((size_t)B);
-    for (int b = 0; b < B; ++b) lab64[(size_t)b] = c->lab[b];
-    labels = lab64.data();
-  }
-  lap(3);
-  if (bad) return bad;                       // malformed boundaries: nothing else is enqueued
-
-  // 4. partners: groups of equal label, each permuted by a fresh Random(step).sample
-  draw_partners(c, labels, B, mix_out, st + (size_t)B * 5);
-  lap(4);
-  // 5. one H2D copy, the launch, the slot's event behind it.  (Round 4 tried the fetch on a side
-  //    stream of the context, beside the previous step's kernels: PCGmix+ train step 129.0 -> 128.0 us,
-  //    but the extra HIP stream can share a hardware queue with the stream a PIPELINED step augments on
-  //    and serialise it — cfg3 train 229 -> 282 us inside the full bench; removed,
-  //    profiles/r4_magwarp_fetch_ahead.txt.)
-  if ((e = upload_slot(sl, nbytes, s)) != hipSuccess) return (int)e;
-  lap(5);
-  const int32_t* d = reinterpret_cast<const int32_t*>(sl.dev);
-  const int err = pcgmix::launch_mix_warp(x, y, d, d + (size_t)B * 5, nullptr, lam, knots_dev, op_dev,
-                                          knots ? n_knots : 0, nullptr, B, C, T, s,
-                                          sl.dev + pay_off, c->payload_dst,
-                                          (int)(c->payload.size() / 16));
-  if (err) return err;
-  c->payload.clear();
-  c->payload_dst = nullptr;
-  lap(6);
-  if ((e = slot_commit(c, my_slot, s)) != hipSuccess) return (int)e;
-  lap(7);
-  seed_ahead_post(c, step + 1);
-  ++c->calls;
-  return hipSuccess;
+  p.lap(0);
+  return small ? step_karg(p) : step_staged(p);
 }
 
 extern "C" int pcgmix_ctx_armed_stats(pcgmix_ctx* c, long long* out3) {
