@@ -263,6 +263,20 @@ _c_float = ctypes.c_float
 _get_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_I64_ARRAYS = {}
+
+
+def _index_out(n: int):
+    """(ctypes buffer, ndarray over it) for ``n`` int64 the library fills: a fresh ctypes array handed to
+    the call as it is and wrapped by numpy costs 0.5 us, ``np.empty`` + ``.ctypes.data`` 1.45 us (the
+    ``.ctypes`` helper object) — on the host chain of a 16 us step."""
+    t = _I64_ARRAYS.get(n)
+    if t is None:
+        t = _I64_ARRAYS[n] = ctypes.c_int64 * n
+    buf = t()
+    return buf, np.ndarray((n,), np.int64, buf)
+
+
 def step_context(index: int) -> int:
     """The library's per-device step context (pinned staging ring + device twins + label
     read-back memory + spline operators), created on first use."""
@@ -326,12 +340,12 @@ def splice_plain(recipe, data: torch.Tensor, labels, frames, step: int,
     elif out.shape != data.shape or out.dtype != data.dtype or not out.is_contiguous() \
             or out.data_ptr() == data.data_ptr():
         raise ValueError("out must be a distinct contiguous tensor shaped like data")
-    mix = np.empty(B, dtype=np.int64)
+    mix_buf, mix = _index_out(B)
     stream = _get_raw_stream(idx) if _get_raw_stream is not None \
         else torch.cuda.current_stream(data.device).cuda_stream
     err = _lib.load().pcgmix_augment_plain_f32(
         _CTX.get(idx) or step_context(idx), data.data_ptr(), out.data_ptr(), ohe_ptr, n_cls, lab_ptr,
-        fr_ptr, step, _c_float(lam), knots_ptr, n_knots, mix.ctypes.data, B, C, T, stream)
+        fr_ptr, step, _c_float(lam), knots_ptr, n_knots, mix_buf, B, C, T, stream)
     if err:
         if err < 0:
             raise ValueError(_SPLICE_ERRORS.get(err, f"pcgmix_augment_plain_f32 error {err}"))
