@@ -31,7 +31,7 @@ extern "C" {
  * language binding does not need the HIP headers). */
 typedef struct ihipStream_t* pcgmix_stream_t;
 
-#define PCGMIX_ABI_VERSION 16
+#define PCGMIX_ABI_VERSION 17
 
 /* ABI version of the loaded library (== PCGMIX_ABI_VERSION it was built with). */
 int pcgmix_abi_version(void);
@@ -710,6 +710,20 @@ int pcgmix_augment_plain_f32(pcgmix_ctx* ctx, const float* x, float* y,
  * stats: out3 = steps armed | of them checked after a stream synchronisation | of them relaunched.
  * debug (tests): the relays' timeout and a host stall in front of the record write; 0, 0 = defaults. */
 int pcgmix_ctx_armed_stats(pcgmix_ctx* ctx, long long* out3);
+/* The armed plain step (no warp) in two calls, for a binding with host work of its own between the
+ * launch and the moment lambda is known — PKG/augmentations.py draws lambda from numpy's global stream
+ * there (augmentations.py:661-663), 2.7 us that otherwise stand in front of the launch.
+ * begin: validates, and if the step is eligible (conditions above) enqueues the armed kernel and returns
+ * 0; returns PCGMIX_NOT_ARMED with nothing enqueued when it is not (call pcgmix_augment_plain_f32), a
+ * hipError_t on failure.  A pending pcgmix_ctx_set_payload travels with the launch.
+ * finish: boundaries (validated: -1 / -2 as pcgmix_augment_plain_f32, the waiting kernel is released),
+ * label pick-up, partner draw into mix_out (HOST int64 (B)), records + lambda.  hipErrorNotReady without
+ * a begin.  A begin that is never finished is released by the next begin (or by the blocks' timeout). */
+#define PCGMIX_NOT_ARMED (-3)
+int pcgmix_augment_plain_begin(pcgmix_ctx* ctx, const float* x, float* y, const int64_t* target_ohe_dev,
+                               int num_classes, int B, int C, int T, pcgmix_stream_t stream);
+int pcgmix_augment_plain_finish(pcgmix_ctx* ctx, const int64_t* frames, uint64_t step, float lam,
+                                int64_t* mix_out);
 int pcgmix_ctx_armed_debug(pcgmix_ctx* ctx, unsigned long long timeout_ticks, int stall_ms);
 
 /* Diagnostic: mean host nanoseconds per pcgmix_augment_plain_f32 call since the last query, by

@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpcgmix_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
@@ -122,6 +122,8 @@ SIGNATURES = {
                                           _c_int, _ptr, _c_int, _ptr, _c_int, _c_int, _c_int, _ptr]),
     "pcgmix_ctx_phase_times": (ctypes.c_longlong, [_ptr, _ptr]),
     "pcgmix_ctx_armed_stats": (_c_int, [_ptr, _ptr]),
+    "pcgmix_augment_plain_begin": (_c_int, [_ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int, _ptr]),
+    "pcgmix_augment_plain_finish": (_c_int, [_ptr, _ptr, ctypes.c_uint64, _c_float, _ptr]),
     "pcgmix_ctx_armed_debug": (_c_int, [_ptr, ctypes.c_uint64, _c_int]),
     "pcgmix_ctx_labels_begin": (_c_int, [_ptr, _ptr, _c_int, _c_int, _ptr, _ptr]),
     "pcgmix_ctx_labels_wait": (_c_int, [_ptr, _ptr, _c_int, _ptr]),

@@ -263,7 +263,14 @@ _c_float = ctypes.c_float
 _get_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_NOT_ARMED = -3          # PCGMIX_NOT_ARMED (include/pcgmix_hip.h)
 _I64_ARRAYS = {}
+
+
+def _fresh_out_ok(out: torch.Tensor, data: torch.Tensor) -> bool:
+    return out.shape == data.shape and out.dtype == data.dtype and out.is_contiguous() \
+        and out.data_ptr() != data.data_ptr()
+
 
 
 def _index_out(n: int):
@@ -331,6 +338,30 @@ def splice_plain(recipe, data: torch.Tensor, labels, frames, step: int,
             raise ValueError("labels/frames do not match the batch size")
         lab_ptr = labels.ctypes.data
     fr_ptr, fr_keep = _frames_ptr(frames, B)
+    stream = _get_raw_stream(idx) if _get_raw_stream is not None \
+        else torch.cuda.current_stream(data.device).cuda_stream
+    if ohe_ptr is not None and n_knots == 0 and (out is None or _fresh_out_ok(out, data)):
+        # Strict signature, no warp: the ARMED kernel is launched FIRST (it needs neither lambda nor the
+        # partners: both reach it in its records), lambda is drawn from numpy's stream while the GPU
+        # gets to the kernel and the labels come back, then the second call delivers the records.
+        # (The reference draws the partners from `random` and lambda from numpy: independent streams,
+        # the order between them is free.)
+        lib = _lib.load()
+        ctx = _CTX.get(idx) or step_context(idx)
+        if out is None:
+            out = torch.empty_like(data)
+        err = lib.pcgmix_augment_plain_begin(ctx, data.data_ptr(), out.data_ptr(), ohe_ptr, n_cls, B, C, T, stream)
+        if err == 0:
+            lam, _ = hostprep.draw_lambda_knots(step, alpha, sigma, 0)
+            mix_buf, mix = _index_out(B)
+            err = lib.pcgmix_augment_plain_finish(ctx, fr_ptr, step, _c_float(lam), mix_buf)
+            if err:
+                if err < 0:
+                    raise ValueError(_SPLICE_ERRORS.get(err, f"pcgmix_augment_plain_finish error {err}"))
+                _lib.check(err, "pcgmix_augment_plain_finish")
+            return out, mix
+        if err != _NOT_ARMED:
+            _lib.check(err, "pcgmix_augment_plain_begin")
     # numpy's global stream, as the reference: seed -> beta -> normal (c_float rounds lam like
     # np.float32, :903); the block was usually drawn ahead by the library (hostprep)
     lam, knots = hostprep.draw_lambda_knots(step, alpha, sigma, B * n_knots * C)
@@ -341,8 +372,6 @@ def splice_plain(recipe, data: torch.Tensor, labels, frames, step: int,
             or out.data_ptr() == data.data_ptr():
         raise ValueError("out must be a distinct contiguous tensor shaped like data")
     mix_buf, mix = _index_out(B)
-    stream = _get_raw_stream(idx) if _get_raw_stream is not None \
-        else torch.cuda.current_stream(data.device).cuda_stream
     err = _lib.load().pcgmix_augment_plain_f32(
         _CTX.get(idx) or step_context(idx), data.data_ptr(), out.data_ptr(), ohe_ptr, n_cls, lab_ptr,
         fr_ptr, step, _c_float(lam), knots_ptr, n_knots, mix_buf, B, C, T, stream)

@@ -562,6 +562,15 @@ struct pcgmix_ctx {
   unsigned long long* rec_h = nullptr;   // host-mapped, coherent: kPackB records
   unsigned long long* rec_d = nullptr;   // device relay
   uint32_t armed_seq = 0;
+  struct ArmedOpen {                     // an armed kernel is waiting for its records
+    bool open = false, warp = false;
+    uint32_t seq = 0;
+    std::chrono::steady_clock::time_point t_launch;
+    const float* x = nullptr;
+    float* y = nullptr;
+    int B = 0, C = 0, T = 0, my_slot = 0;
+    hipStream_t s = nullptr;
+  } armed_open;
   hipStream_t armed_stream = nullptr;    // stream of the last armed launch
   bool armed_any = false;
   long long armed_calls = 0, armed_slow = 0, armed_aborted = 0;
@@ -1034,7 +1043,7 @@ hipError_t armed_prepare(pcgmix_ctx* c, hipStream_t s) {
 }
 
 // stamp = seq: the step's records; stamp = seq | kArmedAbort: every relay gives up
-void armed_write(pcgmix_ctx* c, uint32_t stamp, const int16_t* fr16, const int16_t* mix16, int B) {
+void armed_write(pcgmix_ctx* c, uint32_t stamp, const int16_t* fr16, const int16_t* mix16, int B, float lam = 0.f) {
   const unsigned long long hi = (unsigned long long)stamp << 32;
   for (int b = 0; b < B; ++b) {
     unsigned long long* r = c->rec_h + (size_t)b * pcgmix::kArmedRecWords;
@@ -1049,6 +1058,9 @@ void armed_write(pcgmix_ctx* c, uint32_t stamp, const int16_t* fr16, const int16
     }
     for (int i = 0; i < 6; ++i)
       __atomic_store_n(r + i, hi | ((unsigned long long)v[2 * i + 1] << 16) | v[2 * i], __ATOMIC_RELAXED);
+    uint32_t lam_bits;
+    std::memcpy(&lam_bits, &lam, 4);
+    __atomic_store_n(r + 6, hi | lam_bits, __ATOMIC_RELAXED);
   }
 }
 
@@ -1162,35 +1174,33 @@ struct PlainStep {
 //    The same for splice + warp (durmixmagwarp): the knots go into a pinned slot and cross the link
 //    inside the kernel, once per sample, so the label launch AND the fetch launch of the staged path
 //    leave the chain.
-int step_armed(PlainStep& p, bool arm_warp) {
+// First half: everything up to and including the launch.  lam is needed here only for the splice + warp
+// kernel (its knots come with lam out of one draw); the plain kernel takes it from the record.
+int armed_begin(PlainStep& p, bool arm_warp) {
   pcgmix_ctx* c = p.c;
-  const float* x = p.x;
-  float* y = p.y;
-  const int64_t* frames = p.frames;
-  const uint64_t step = p.step;
-  const float lam = p.lam;
-  const double* knots = p.knots;
-  const int n_knots = p.n_knots, B = p.B, C = p.C, T = p.T;
-  int64_t* mix_out = p.mix_out;
+  const int B = p.B, C = p.C, T = p.T;
   hipStream_t s = p.s;
   hipError_t e = hipSuccess;
-  const int64_t* target_ohe_dev = p.target_ohe_dev;
-  const int num_classes = p.num_classes;
-  pcgmix_stream_t stream = p.stream;
+  pcgmix_ctx::ArmedOpen& o = c->armed_open;
+  if (o.open) {                              // a begin whose finish never came (the caller raised in between)
+    armed_write(c, o.seq | pcgmix::kArmedAbort, nullptr, nullptr, o.B);
+    if (o.warp) (void)slot_commit(c, o.my_slot, o.s);
+    o.open = false;
+  }
   const int my_slot = c->next;               // (splice + warp only: the slot that carries the knots)
   Slot& sl = c->slot[my_slot];
   const double* op_dev = nullptr;
   if ((e = labels_prepare(c, B, s)) != hipSuccess) return (int)e;
   if ((e = armed_prepare(c, s)) != hipSuccess) return (int)e;
   if (arm_warp) {
-    const size_t nkb = (size_t)B * n_knots * C * sizeof(double);
+    const size_t nkb = (size_t)B * p.n_knots * C * sizeof(double);
     if ((e = slot_reserve(c, my_slot, nkb)) != hipSuccess) return (int)e;
-    if ((e = spline_op_device(c, T, n_knots, &op_dev)) != hipSuccess) return (int)e;
-    std::memcpy(sl.pinned, knots, nkb);
+    if ((e = spline_op_device(c, T, p.n_knots, &op_dev)) != hipSuccess) return (int)e;
+    std::memcpy(sl.pinned, p.knots, nkb);
   }
   pcgmix::ArmedArgs a;
-  a.ohe = target_ohe_dev;
-  a.K = num_classes;
+  a.ohe = p.target_ohe_dev;
+  a.K = p.num_classes;
   a.lab64 = reinterpret_cast<unsigned long long*>(c->lab);
   a.token = c->token;
   a.rec_h = c->rec_h;
@@ -1198,60 +1208,83 @@ int step_armed(PlainStep& p, bool arm_warp) {
   a.abort_h = c->flag + 8;
   a.seq = c->armed_seq;
   a.timeout_ticks = c->armed_timeout;
-  const auto t_launch = std::chrono::steady_clock::now();
+  o.t_launch = std::chrono::steady_clock::now();
   const int err =
-      arm_warp ? pcgmix::launch_mix_tq_armed(x, y, a, lam, reinterpret_cast<const double*>(sl.pinned),
-                                             reinterpret_cast<double*>(sl.dev), op_dev, n_knots, B, C, T, s,
+      arm_warp ? pcgmix::launch_mix_tq_armed(p.x, p.y, a, p.lam, reinterpret_cast<const double*>(sl.pinned),
+                                             reinterpret_cast<double*>(sl.dev), op_dev, p.n_knots, B, C, T, s,
                                              c->payload.data(), (int)c->payload.size(), c->payload_dst)
-               : pcgmix::launch_mix_armed(x, y, a, lam, B, C, T, s, c->payload.data(),
-                                          (int)c->payload.size(), c->payload_dst);
+               : pcgmix::launch_mix_armed(p.x, p.y, a, B, C, T, s, c->payload.data(), (int)c->payload.size(),
+                                          c->payload_dst);
   if (err) return err;
   c->armed_stream = s;
   c->armed_any = true;
+  c->payload.clear();                        // (it travelled in the launch's arguments)
+  c->payload_dst = nullptr;
+  o.open = true;
+  o.warp = arm_warp;
+  o.seq = a.seq;
+  o.x = p.x;
+  o.y = p.y;
+  o.B = B; o.C = C; o.T = T;
+  o.my_slot = my_slot;
+  o.s = s;
   p.lap(0);
-  // from here on the kernel is waiting: every way out writes its records
+  return hipSuccess;
+}
+
+// Second half: the kernel is waiting — every way out of here writes its records.
+int armed_finish(PlainStep& p) {
+  pcgmix_ctx* c = p.c;
+  pcgmix_ctx::ArmedOpen& o = c->armed_open;
+  const int B = o.B, C = o.C, T = o.T;
+  hipStream_t s = o.s;
+  hipError_t e = hipSuccess;
+  o.open = false;
   int16_t fr16[pcgmix::kPackB * 5], mix16[pcgmix::kPackB];
-  const int bad16 = pack_frames16(frames, B, T, fr16);
+  const int bad16 = pack_frames16(p.frames, B, T, fr16);
   p.lap(1);
-  seed_for_step(c, step);
+  seed_for_step(c, p.step);
   p.lap(2);
   int64_t lab64a[pcgmix::kPackB];
   if (bad16 || (e = labels_wait_armed(c, B, lab64a)) != hipSuccess) {
-    armed_write(c, a.seq | pcgmix::kArmedAbort, nullptr, nullptr, B);
-    if (arm_warp) (void)slot_commit(c, my_slot, s);      // the kernel may still read the slot's knots
+    armed_write(c, o.seq | pcgmix::kArmedAbort, nullptr, nullptr, B);
+    if (o.warp) (void)slot_commit(c, o.my_slot, s);        // the kernel may still read the slot's knots
     return bad16 ? bad16 : (int)e;
   }
   p.lap(3);
-  draw_partners(c, lab64a, B, mix_out, nullptr, mix16);
+  draw_partners(c, lab64a, B, p.mix_out, nullptr, mix16);
   p.lap(4);
   if (c->armed_stall_ms > 0) {
     timespec ts{c->armed_stall_ms / 1000, (long)(c->armed_stall_ms % 1000) * 1000000L};
     nanosleep(&ts, nullptr);
   }
-  armed_write(c, a.seq, fr16, mix16, B);
+  armed_write(c, o.seq, fr16, mix16, B, p.lam);
   p.lap(5);
-  c->payload.clear();
-  c->payload_dst = nullptr;
   ++c->armed_calls;
-  if (arm_warp && (e = slot_commit(c, my_slot, s)) != hipSuccess) return (int)e;
+  if (o.warp && (e = slot_commit(c, o.my_slot, s)) != hipSuccess) return (int)e;
   p.lap(6);
   // The relays give up 1 s after the kernel STARTED, which is later than t_launch: records written
   // within 0.4 s of the launch were in time whatever happened in between.  Otherwise (a debugger, a
   // stopped process, a host that lost its CPU for that long): wait for the kernel and look; if the
   // blocks gave up, the step again through the unarmed path, with the labels this call holds.
-  if (std::chrono::steady_clock::now() - t_launch > std::chrono::milliseconds(400)) {
+  if (std::chrono::steady_clock::now() - o.t_launch > std::chrono::milliseconds(400)) {
     ++c->armed_slow;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return (int)e;
-    if (__atomic_load_n(c->flag + 8, __ATOMIC_ACQUIRE) == a.seq) {
+    if (__atomic_load_n(c->flag + 8, __ATOMIC_ACQUIRE) == o.seq) {
       ++c->armed_aborted;
-      return pcgmix_augment_plain_f32(c, x, y, nullptr, 0, lab64a, frames, step, lam, knots, n_knots,
-                                      mix_out, B, C, T, stream);
+      return pcgmix_augment_plain_f32(c, o.x, o.y, nullptr, 0, lab64a, p.frames, p.step, p.lam, p.knots,
+                                      p.n_knots, p.mix_out, B, C, T, reinterpret_cast<pcgmix_stream_t>(s));
     }
   }
   p.lap(7);
-  seed_ahead_post(c, step + 1);
+  seed_ahead_post(c, p.step + 1);
   ++c->calls;
   return hipSuccess;
+}
+
+int step_armed(PlainStep& p, bool arm_warp) {
+  const int err = armed_begin(p, arm_warp);
+  return err ? err : armed_finish(p);
 }
 
 // Small plain batches (BASELINE configs[1]: B = 256): the index block travels in the splice
@@ -1422,6 +1455,41 @@ extern "C" int pcgmix_augment_plain_f32(pcgmix_ctx* c, const float* x, float* y,
     return (int)e;
   p.lap(0);
   return small ? step_karg(p) : step_staged(p);
+}
+
+// The armed plain step in two calls, for a caller that has host work of its own between the launch and the
+// moment lambda is known (the Python binding draws lambda from numpy's stream there): begin = validation,
+// eligibility, the launch; finish = boundaries, labels, partners, records.
+extern "C" int pcgmix_augment_plain_begin(pcgmix_ctx* c, const float* x, float* y,
+                                          const int64_t* target_ohe_dev, int num_classes, int B, int C,
+                                          int T, pcgmix_stream_t stream) {
+  if (!c || !x || !y || !target_ohe_dev || num_classes <= 0 || B <= 0 || C <= 0 || T <= 0)
+    return hipErrorInvalidValue;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (stream_is_capturing(s)) return hipErrorStreamCaptureUnsupported;
+  static const bool karg_ok = getenv("PCGMIX_NO_KARG") == nullptr;
+  static const bool armed_ok = getenv("PCGMIX_NO_ARMED") == nullptr;
+  if (!(armed_ok && karg_ok && num_classes <= 256 && c->payload.size() <= (size_t)pcgmix::kPackPayBytes &&
+        B <= pcgmix::kPackB && T <= 32767 && !(T & 3) &&
+        !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15)))
+    return PCGMIX_NOT_ARMED;
+  DeviceGuard guard(c->device);
+  if (guard.err != hipSuccess) return (int)guard.err;
+  PlainStep p{c, x, y, target_ohe_dev, num_classes, nullptr, nullptr, 0, 0.f, nullptr, 0, nullptr,
+              B, C, T, s, stream, std::chrono::steady_clock::now()};
+  return armed_begin(p, false);
+}
+
+extern "C" int pcgmix_augment_plain_finish(pcgmix_ctx* c, const int64_t* frames, uint64_t step, float lam,
+                                           int64_t* mix_out) {
+  if (!c || !frames || !mix_out) return hipErrorInvalidValue;
+  if (!c->armed_open.open) return hipErrorNotReady;
+  DeviceGuard guard(c->device);
+  if (guard.err != hipSuccess) return (int)guard.err;
+  PlainStep p{c, c->armed_open.x, c->armed_open.y, nullptr, 0, nullptr, frames, step, lam, nullptr, 0, mix_out,
+              c->armed_open.B, c->armed_open.C, c->armed_open.T, c->armed_open.s,
+              reinterpret_cast<pcgmix_stream_t>(c->armed_open.s), std::chrono::steady_clock::now()};
+  return armed_finish(p);
 }
 
 extern "C" int pcgmix_ctx_armed_stats(pcgmix_ctx* c, long long* out3) {

@@ -83,12 +83,13 @@ int launch_mix_karg(const float* x, float* y, const int16_t* frames16, const int
 // A record is six 8-byte words, each = (stamp << 32) | two int16 values; the stamp is the step's
 // sequence number, so a word is valid by itself (8-byte aligned loads and stores are single-copy
 // atomic on both sides): no flag, no ordering between words, no torn record.  Values: own
-// boundaries f[0..4], partner index, the partner's boundaries f[0..4], 0.
+// boundaries f[0..4], partner index, the partner's boundaries f[0..4], 0; word 6 = the step's lambda
+// (float bits) for the plain launch, which may be made before lambda is drawn.
 // stamp | kArmedAbort in a record = "give up": written by the host (bad input after the launch) or
 // by a relay that saw nothing within timeout_ticks of the 100 MHz clock (then also *abort_h = seq);
 // every wave leaves without touching y.
 constexpr uint32_t kArmedAbort = 0x80000000u;
-constexpr int kArmedRecWords = 8;            // 64 bytes per sample, six words used
+constexpr int kArmedRecWords = 8;            // 64 bytes per sample: six index words, lambda, (device) knots-ready
 struct ArmedArgs {
   const int64_t* ohe;                        // (B, K) one-hot on the device
   int K;
@@ -100,9 +101,8 @@ struct ArmedArgs {
   uint32_t seq;                              // 1 .. 0x7fffffff
   unsigned long long timeout_ticks;
 };
-int launch_mix_armed(const float* x, float* y, const ArmedArgs& a, float lam, int B, int C, int T,
-                     hipStream_t s, const void* pay = nullptr, int pay_bytes = 0,
-                     void* pay_dst = nullptr);
+int launch_mix_armed(const float* x, float* y, const ArmedArgs& a, int B, int C, int T, hipStream_t s,
+                     const void* pay = nullptr, int pay_bytes = 0, void* pay_dst = nullptr);
 // The same for the splice + warp kernel (durmixmagwarp): knots_host = this step's knots (B, n_knots, C)
 // float64 in device-readable pinned memory, knots_dev = device scratch of the same size (each sample's
 // relay copies its knots there once), spline_op the constant operator on the device.

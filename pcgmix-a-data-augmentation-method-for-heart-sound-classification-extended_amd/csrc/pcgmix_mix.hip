@@ -621,8 +621,8 @@ __device__ long long g_armed_clock[2][kPackB + 1][4];
 #endif
 template <int U>
 __global__ __launch_bounds__(kThreads) void mix_armed_kernel(
-    const float* __restrict__ x, float* __restrict__ y, const ArmedArgs a, float lam, float oml,
-    int B, int C, int T, int epb, int chunks, const PayPack pay, uint4* __restrict__ pay_dst) {
+    const float* __restrict__ x, float* __restrict__ y, const ArmedArgs a, int B, int C, int T, int epb,
+    int chunks, const PayPack pay, uint4* __restrict__ pay_dst) {
   extern __shared__ __align__(16) double lds[];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(kThreads) void mix_armed_kernel(
   if (b >= B) return;
   const unsigned long long t0 = wall_clock64();
   const uint32_t go = a.seq, stop = a.seq | kArmedAbort;
-  const int word = lane < 6 ? lane : 5;
+  const int word = lane < 7 ? lane : 6;          // six index words and lambda (word 6: float bits)
   if (blockIdx.x == 0 && threadIdx.x == 0) { PCGMIX_ACLOCK(b, 0); }
   if (blockIdx.x == 0 && threadIdx.x < 64) {     // this sample's relay: host record -> device record
     const unsigned long long* src = a.rec_h + (size_t)b * kArmedRecWords + word;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(kThreads) void mix_armed_kernel(
       w = (unsigned long long)stop << 32;
       if (lane == 0) __hip_atomic_store(a.abort_h, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (lane < 6)
+    if (lane < 7)
       __hip_atomic_store(a.rec_d + (size_t)b * kArmedRecWords + lane, w, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     if (lane == 0) { PCGMIX_ACLOCK(b, 1); }
@@ -676,11 +676,12 @@ __global__ __launch_bounds__(kThreads) void mix_armed_kernel(
   }
   if (blockIdx.x == 1 && threadIdx.x == 0) { PCGMIX_ACLOCK(b, 2); }
   const int lo = (int)(uint32_t)w;
-  int f1[5], f2[5], m;
+  int f1[5], f2[5], m, lam_bits;
   {
     const int w0 = __builtin_amdgcn_readlane(lo, 0), w1 = __builtin_amdgcn_readlane(lo, 1),
               w2 = __builtin_amdgcn_readlane(lo, 2), w3 = __builtin_amdgcn_readlane(lo, 3),
               w4 = __builtin_amdgcn_readlane(lo, 4), w5 = __builtin_amdgcn_readlane(lo, 5);
+    lam_bits = __builtin_amdgcn_readlane(lo, 6);
     auto lo16 = [](int v) { return (int)((unsigned)v << 16) >> 16; };
     f1[0] = lo16(w0); f1[1] = w0 >> 16; f1[2] = lo16(w1); f1[3] = w1 >> 16; f1[4] = lo16(w2);
     m = w2 >> 16;
@@ -703,6 +704,8 @@ __global__ __launch_bounds__(kThreads) void mix_armed_kernel(
   }
   // two chunks of the sample per block: (256,4,5000) is 2,560 chunks, more blocks than the chip holds at
   // once (2,048 of four waves) — the last fifth would start, and begin to wait, when the first ones leave
+  // lambda travels with the record: a caller may launch before it has drawn it (pcgmix_augment_plain_begin)
+  const float lam = __int_as_float(lam_bits), oml = 1.0f - lam;
   for (int chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x)
     mix_body<4, false, U>(x, y, lam, oml, nullptr, nullptr, 0, nullptr, C, T, epb, b, m, sm, lds, chunk);
   if (blockIdx.x == 1 && threadIdx.x == 0) { PCGMIX_ACLOCK(b, 3); }
@@ -980,9 +983,8 @@ extern "C" int pcgmix_armed_phase_clock(long long* out) {
 }
 #endif
 
-int pcgmix::launch_mix_armed(const float* x, float* y, const ArmedArgs& a, float lam, int B, int C,
-                             int T, hipStream_t s, const void* pay_host, int pay_bytes,
-                             void* pay_dst) {
+int pcgmix::launch_mix_armed(const float* x, float* y, const ArmedArgs& a, int B, int C, int T,
+                             hipStream_t s, const void* pay_host, int pay_bytes, void* pay_dst) {
   using namespace pcgmix;
   if (pay_bytes < 0 || pay_bytes > kPackPayBytes ||
       (pay_bytes > 0 && (!pay_host || !pay_dst || (reinterpret_cast<uintptr_t>(pay_dst) & 15))))
@@ -1004,17 +1006,16 @@ int pcgmix::launch_mix_armed(const float* x, float* y, const ArmedArgs& a, float
   const int U = choose_unroll(B, plane, false);
   const int epb = kThreads * 4 * (U == 4 ? 2 : U);
   const unsigned chunks = (unsigned)((plane + epb - 1) / epb);
-  const float oml = 1.0f - lam;
   // every block resident at once: at most 2,048 blocks of four waves, each taking its sample's chunks
   // blockIdx.x, blockIdx.x + gridDim.x, ...
   unsigned per_sample = chunks;
   while (per_sample > 1 && per_sample * (unsigned)B > 2048u) per_sample = (per_sample + 1) / 2;
   dim3 grid(per_sample, (unsigned)B), block(kThreads);
   if (U >= 2)
-    hipLaunchKernelGGL((mix_armed_kernel<2>), grid, block, 0, s, x, y, a, lam, oml, B, C, T, epb,
+    hipLaunchKernelGGL((mix_armed_kernel<2>), grid, block, 0, s, x, y, a, B, C, T, epb,
                        (int)chunks, pay, static_cast<uint4*>(pay_dst));
   else
-    hipLaunchKernelGGL((mix_armed_kernel<1>), grid, block, 0, s, x, y, a, lam, oml, B, C, T, epb,
+    hipLaunchKernelGGL((mix_armed_kernel<1>), grid, block, 0, s, x, y, a, B, C, T, epb,
                        (int)chunks, pay, static_cast<uint4*>(pay_dst));
   return (int)hipGetLastError();
 }
