@@ -206,3 +206,31 @@ def test_late_records_are_noticed_and_the_splice_is_launched_again(device):
         _lib.check(lib.pcgmix_ctx_armed_debug(ctx, 0, 0), "debug")
     y, _, mix, _ = _step(augmentations, "durratiomixup", data, labels, frames, wav, 6, device)
     assert np.array_equal(y.cpu().numpy(), ref["y"]) and _stats(device)[2] == after[2]
+
+
+def test_begin_without_finish_is_released_by_the_next_begin(device):
+    """The two-call form (pcgmix_augment_plain_begin / _finish): a begin whose finish never comes — the
+    binding raised between the calls — leaves a kernel waiting; the next begin releases it.  Shapes the
+    armed kernel does not take are reported (PCGMIX_NOT_ARMED) with nothing enqueued, and a finish
+    without a begin is refused."""
+    lib = _lib.load()
+    ctx = augmentations.step_context(device.index)
+    B, C, T = 48, 4, 5000
+    x, frames, labels, wav = synthetic.make_batch(B, C, T, sample_rate=2000, seed=21)
+    data = torch.from_numpy(x).to(device)
+    tgt = torch.nn.functional.one_hot(torch.from_numpy(labels), 2).to(device)
+    lost = torch.empty_like(data)
+    st = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    assert lib.pcgmix_augment_plain_begin(ctx, data.data_ptr(), lost.data_ptr(), tgt.data_ptr(), 2, B, C, T, st) == 0
+    y, _, mix, _ = _step(augmentations, "durratiomixup", data, labels, frames, wav, 12, device)   # begins again
+    torch.cuda.synchronize()                   # returns: the abandoned kernel was released
+    ref = O.augment("durratiomixup", x, labels, frames, wav, 12)
+    assert np.array_equal(mix, ref["mix"]) and np.array_equal(y.cpu().numpy(), ref["y"])
+    odd = torch.empty(B, C, T - 2, device=device)            # T % 4 != 0
+    assert lib.pcgmix_augment_plain_begin(ctx, odd.data_ptr(), torch.empty_like(odd).data_ptr(), tgt.data_ptr(), 2,
+                                          B, C, T - 2, st) == -3
+    fr = np.ascontiguousarray(frames)
+    mix_out = np.empty(B, dtype=np.int64)
+    assert lib.pcgmix_augment_plain_finish(ctx, fr.ctypes.data, 12, ctypes.c_float(0.5), mix_out.ctypes.data) != 0
+    y2, _, mix2, _ = _step(augmentations, "durratiomixup", data, labels, frames, wav, 12, device)
+    assert np.array_equal(mix2, ref["mix"]) and np.array_equal(y2.cpu().numpy(), ref["y"])
