@@ -237,8 +237,7 @@ struct PyRandom {
 
   // Random._randbelow_with_getrandbits(n), n >= 1
   uint64_t randbelow(uint64_t n) {
-    int k = 0;
-    for (uint64_t v = n; v; v >>= 1) ++k;  // n.bit_length()
+    const int k = 64 - __builtin_clzll(n);  // n.bit_length(), n >= 1
     uint64_t r = getrandbits(k);
     while (r >= n) r = getrandbits(k);
     return r;
