@@ -768,10 +768,14 @@ __global__ __launch_bounds__(kThreads) void mix_warp_tq_armed_kernel(
       if (wall_clock64() - t0 > 2 * a.timeout_ticks) break;
       __builtin_amdgcn_s_sleep(4);
     }
-    if (lane == 0) rec_s[6] = ready ? 1ull : 0ull;
+    if (lane == 0) {
+      rec_s[6] = ready ? 1ull : 0ull;
+      if (!ready)                                // cannot happen while the grid is resident; the host must know
+        __hip_atomic_store(a.abort_h, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   __syncthreads();
-  if (!rec_s[6]) return;                         // block-uniform: the relay never came (its block gave up?)
+  if (!rec_s[6]) return;                         // block-uniform
   auto await = [&](StateMap& sm, int& m) -> bool {
     const uint32_t go = a.seq, stop = a.seq | kArmedAbort;
     const int word = lane < 6 ? lane : 5;
