@@ -9,12 +9,16 @@ Workload (BASELINE.json configs[1]): synthetic 2.5 s @ 2 kHz heart cycles, batch
 ``durratiomixup`` feeding the 1D-CNN, i.e. (256, 4, 5000) float32 — the Potes 1D-CNN needs its
 four band-pass channels.  One step = one ``augment()`` call through the
 reference's own call signature (device-resident input -> device-resident output, labels read
-back, partner permutation drawn, indices uploaded, one fused HIP launch).  Every rank augments
-its own batch (no collective on the data path: weak scaling).
+back, partner permutation drawn, one fused HIP launch — made before the labels are known, its
+blocks wait for the index records the host writes: DESIGN.md §3.6 "armed").  Every rank augments
+its own batch (no collective on the data path: weak scaling) and pins itself to CPUs of its GPU's
+NUMA node (``config.host_affinity``; PCGMIX_BENCH_NO_AFFINITY=1 leaves it to the scheduler).
 
 One JSON line is printed by rank 0.  Besides the contract keys it carries
-  roofline      the splice kernel against the HBM roofline (12*C*T algorithmic bytes/sample),
-                kernel time measured with HIP events on the launch stream inside the timed steps
+  roofline      the splice kernel against the HBM roofline (12*C*T algorithmic bytes/sample and the
+                bytes this batch needs), kernel time measured with HIP events on the launch stream
+                around back-to-back launches of the same splice body (the timed steps' own kernel
+                contains a wait for the host: ``roofline.step_kernel``)
   cpu_baseline  the CPU oracle (reference structure: per-sample Python loop) timed on this
                 host on a bounded number of batches of the same workload
   extra         secondary measurements (other shapes/methods, saturating batch, train step/s)
