@@ -292,6 +292,9 @@ def draw_lambda_knots(step: int, alpha: float, sigma: float, count: int):
     Outside that restatement's contract (alpha <= 0: the reference does not seed; alpha > 1:
     gamma-based beta; an odd count: numpy's Gaussian cache would be left full; a foreign bit
     generator) the draws are numpy's own calls."""
+    if count == 0 and alpha > 0.0:          # plain splice: numpy's own two calls, nothing else (0.5 us less)
+        np.random.seed(step)
+        return float(np.random.beta(alpha, alpha)), None
     lock, addr = _numpy_global_state()
     if 0.0 < alpha <= 1.0 and count > 0 and not (count & 1) and addr is not None \
             and 0 <= step <= 0xFFFFFFFF:
